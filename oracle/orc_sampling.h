@@ -1,0 +1,160 @@
+/*
+ * oracle/orc_sampling.h -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+ *
+ * CPU restatement of src/utils/sampling.rs (reference) over a *position space*
+ * [0, n): the reference's functions consume an iterator of candidates; since
+ * its filters never touch the RNG, "collect the candidates, then sample
+ * positions" consumes the RNG identically.
+ *
+ * In ORC_RNG_REF mode every function is the reference loop, draw for draw.
+ * In ORC_RNG_PHILOX mode each draw is addressed by a counter (orc_rng.h) and
+ * `orc_reservoir` offers two algorithms:
+ *   ORC_RES_LITERAL  the reference loop with one addressed draw per item m>=k;
+ *   ORC_RES_SLOTS    a closed form of the SAME output distribution that needs
+ *                    O(k) draws instead of O(n) (derivation in DESIGN.md
+ *                    "Reservoir by slots"; equality of the two distributions is
+ *                    checked exhaustively in tests/test_reservoir_equivalence.py).
+ */
+#ifndef ORC_SAMPLING_H
+#define ORC_SAMPLING_H
+
+#include "orc_rng.h"
+
+#define ORC_RES_SLOTS 0
+#define ORC_RES_LITERAL 1
+
+typedef struct {
+    orc_rng *rng;
+    orc_callkey ck; /* philox mode */
+} orc_ctx;
+
+static inline void orc_ctx_init(orc_ctx *c, orc_rng *rng, uint32_t tag) {
+    c->rng = rng;
+    c->ck.k[0] = c->ck.k[1] = 0;
+    if (rng->mode == ORC_RNG_PHILOX) c->ck = orc_philox_callkey(rng->seed, rng->call_id, tag);
+}
+static inline orc_draw orc_ctx_draw(orc_ctx *c, uint64_t id, uint32_t d0, uint32_t d1) {
+    c->rng->raw_draws++;
+    return orc_philox_draw(c->ck, id, d0, d1);
+}
+
+/* Reservoir by slots (philox mode). n > k >= 1.  dst[s] = position held by
+ * reservoir slot s after the reference loop of sampling.rs:17-24 has run over
+ * positions k..n-1, sampled slot by slot from its exact conditional law:
+ * given the last-hit positions of slots 0..s-1 (descending list L), the last
+ * hit of slot s is uniform inside each gap between them, and a gap [lo,hi]
+ * whose items may still choose among (hi - t) values is hit with probability
+ * (hi-lo+1)/(hi-t).  `scratch` holds k int64. */
+static inline void orc_reservoir_slots(orc_ctx *c, uint64_t id, uint32_t d0_base, int64_t n, int64_t k,
+                                       int64_t *dst, int64_t *scratch) {
+    int64_t *L = scratch; /* claimed positions, descending */
+    int64_t q = 0;
+    for (int64_t s = 0; s < k; s++) {
+        int64_t res = s; /* never hit: the slot keeps the item that filled it */
+        int64_t hi = n - 1, t = s;
+        uint32_t g = 0;
+        orc_draw d = {0};
+        int64_t found = -1;
+        for (int64_t idx = 0; idx <= q; idx++) {
+            int64_t lo = (idx < q) ? L[idx] + 1 : k;
+            if (hi >= lo) {
+                if ((g & 1u) == 0) d = orc_ctx_draw(c, id, d0_base + (uint32_t)s, g >> 1);
+                uint64_t x = (g & 1u) ? d.b : d.a;
+                g++;
+                uint64_t r = orc_bounded(x, (uint64_t)(hi - t));
+                if (r <= (uint64_t)(hi - lo)) {
+                    found = hi - (int64_t)r;
+                    break;
+                }
+            }
+            if (idx < q) {
+                hi = L[idx] - 1;
+                t -= 1;
+            }
+        }
+        if (found >= 0) {
+            res = found;
+            /* insert into the descending list */
+            int64_t p = q;
+            while (p > 0 && L[p - 1] < found) {
+                L[p] = L[p - 1];
+                p--;
+            }
+            L[p] = found;
+            q++;
+        }
+        dst[s] = res;
+    }
+}
+
+/* src/utils/sampling.rs:6-26 reservoir_sampling over positions [0,n) into k
+ * slots; returns min(n,k).  NOTE the reference quirk kept on purpose: the
+ * index for item i is drawn from 0..i (not 0..=i), sampling.rs:19. */
+static inline int64_t orc_reservoir(orc_ctx *c, uint64_t id, uint32_t d0_base, int64_t n, int64_t k, int64_t *dst,
+                                    int64_t *scratch, int algo) {
+    int64_t filled = n < k ? n : k;
+    for (int64_t i = 0; i < filled; i++) dst[i] = i; /* sampling.rs:12-15 */
+    if (n <= k) return filled;
+    if (c->rng->mode == ORC_RNG_REF) {
+        for (int64_t i = k; i < n; i++) { /* sampling.rs:17-24 */
+            uint64_t j = orc_ref_gen_range_u64(c->rng, (uint64_t)i);
+            if (j < (uint64_t)k) dst[j] = i;
+        }
+    } else if (algo == ORC_RES_LITERAL) {
+        for (int64_t i = k; i < n; i++) {
+            orc_draw d = orc_ctx_draw(c, id, (uint32_t)i, 0x4C495400u);
+            uint64_t j = orc_bounded(d.a, (uint64_t)i);
+            if (j < (uint64_t)k) dst[j] = i;
+        }
+    } else {
+        orc_reservoir_slots(c, id, d0_base, n, k, dst, scratch);
+    }
+    return filled;
+}
+
+/* src/utils/sampling.rs:57-69 replacement_sampling: k draws from [0,n), n>0 */
+static inline int64_t orc_replacement(orc_ctx *c, uint64_t id, int64_t n, int64_t k, int64_t *dst) {
+    for (int64_t s = 0; s < k; s++) {
+        if (c->rng->mode == ORC_RNG_REF)
+            dst[s] = (int64_t)orc_ref_gen_range_u64(c->rng, (uint64_t)n);
+        else
+            dst[s] = (int64_t)orc_bounded(orc_ctx_draw(c, id, (uint32_t)s, 0x52455000u).a, (uint64_t)n);
+    }
+    return k;
+}
+
+/* src/utils/sampling.rs:28-55 reservoir_sampling_weighted over positions
+ * [0,n) with weights w[pos]; returns min(n,k), or -1 where the reference
+ * panics (empty float range: running weight sum <= 0, sampling.rs:49).
+ * Philox mode keeps the left-to-right running sum of the reference. */
+static inline int64_t orc_reservoir_weighted(orc_ctx *c, uint64_t id, int64_t n, int64_t k, const double *w,
+                                             int64_t *dst) {
+    int64_t filled = 0;
+    double w_sum = 0.0;
+    for (int64_t i = 0; i < k && i < n; i++) { /* sampling.rs:37-45 */
+        dst[i] = i;
+        w_sum = w_sum + w[i];
+        filled++;
+    }
+    for (int64_t i = k; i < n; i++) { /* sampling.rs:47-53 */
+        w_sum = w_sum + w[i];
+        if (!(0.0 < w_sum)) return -1;
+        double j;
+        uint64_t slot_x = 0;
+        if (c->rng->mode == ORC_RNG_REF) {
+            j = orc_ref_gen_range_f64(c->rng, w_sum);
+        } else {
+            orc_draw d = orc_ctx_draw(c, id, (uint32_t)i, 0x57475400u);
+            j = orc_u64_to_f64_01(d.a) * w_sum + 0.0;
+            slot_x = d.b;
+        }
+        if (j < w[i]) {
+            uint64_t slot = (c->rng->mode == ORC_RNG_REF) ? orc_ref_gen_range_u64(c->rng, (uint64_t)k)
+                                                          : orc_bounded(slot_x, (uint64_t)k);
+            dst[slot] = i;
+        }
+    }
+    return filled;
+}
+
+#endif
