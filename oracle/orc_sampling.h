@@ -10,9 +10,9 @@
  * In ORC_RNG_PHILOX mode each draw is addressed by a counter (orc_rng.h) and
  * `orc_reservoir` offers two algorithms:
  *   ORC_RES_LITERAL  the reference loop with one addressed draw per item m>=k;
- *   ORC_RES_SLOTS    a closed form of the SAME output distribution that needs
- *                    O(k) draws instead of O(n) (derivation in DESIGN.md
- *                    "Reservoir by slots"; equality of the two distributions is
+ *   ORC_RES_TICKETS  a closed form of the SAME output distribution that needs
+ *                    k draws instead of n-k (derivation in DESIGN.md
+ *                    "Reservoir by tickets"; equality of the two distributions is
  *                    checked exhaustively in tests/test_reservoir_equivalence.py).
  */
 #ifndef ORC_SAMPLING_H
@@ -20,7 +20,7 @@
 
 #include "orc_rng.h"
 
-#define ORC_RES_SLOTS 0
+#define ORC_RES_TICKETS 0
 #define ORC_RES_LITERAL 1
 
 typedef struct {
@@ -38,52 +38,36 @@ static inline orc_draw orc_ctx_draw(orc_ctx *c, uint64_t id, uint32_t d0, uint32
     return orc_philox_draw(c->ck, id, d0, d1);
 }
 
-/* Reservoir by slots (philox mode). n > k >= 1.  dst[s] = position held by
- * reservoir slot s after the reference loop of sampling.rs:17-24 has run over
- * positions k..n-1, sampled slot by slot from its exact conditional law:
- * given the last-hit positions of slots 0..s-1 (descending list L), the last
- * hit of slot s is uniform inside each gap between them, and a gap [lo,hi]
- * whose items may still choose among (hi - t) values is hit with probability
- * (hi-lo+1)/(hi-t).  `scratch` holds k int64. */
-static inline void orc_reservoir_slots(orc_ctx *c, uint64_t id, uint32_t d0_base, int64_t n, int64_t k,
-                                       int64_t *dst, int64_t *scratch) {
-    int64_t *L = scratch; /* claimed positions, descending */
-    int64_t q = 0;
+/* Reservoir by tickets (philox mode). n > k >= 1.
+ * The reference loop of sampling.rs:17-24 (item i >= k draws j from 0..i and
+ * overwrites slot j when j < k) leaves in slot s the LAST item that hit it.
+ * Conditioning slot by slot, the last hit of slot s is uniform over the
+ * (n-k) positions k..n-1 not claimed by slots 0..s-1, and "never hit" has
+ * weight (k-1) minus the blanks already used -- i.e. the k slots draw k
+ * tickets WITHOUT replacement from an urn of (n-k) position tickets and
+ * (k-1) blanks (derivation: DESIGN.md "Reservoir by tickets"; exhaustive
+ * check: tests/test_reservoir_equivalence.py).  A blank leaves item s in
+ * slot s.  The ordered draw is a partial Fisher-Yates over ticket indices
+ * [0, n-1): ticket tau < n-k is position k+tau, the rest are blanks.
+ * One bounded draw per slot; slots 2q and 2q+1 share one Philox block.
+ * `scratch` holds 2k int64 (the displaced-entry list of the shuffle). */
+static inline void orc_reservoir_tickets(orc_ctx *c, uint64_t id, uint32_t d0_base, int64_t n, int64_t k,
+                                         int64_t *dst, int64_t *scratch) {
+    int64_t *keys = scratch, *vals = scratch + k;
+    orc_draw d = {0};
     for (int64_t s = 0; s < k; s++) {
-        int64_t res = s; /* never hit: the slot keeps the item that filled it */
-        int64_t hi = n - 1, t = s;
-        uint32_t g = 0;
-        orc_draw d = {0};
-        int64_t found = -1;
-        for (int64_t idx = 0; idx <= q; idx++) {
-            int64_t lo = (idx < q) ? L[idx] + 1 : k;
-            if (hi >= lo) {
-                if ((g & 1u) == 0) d = orc_ctx_draw(c, id, d0_base + (uint32_t)s, g >> 1);
-                uint64_t x = (g & 1u) ? d.b : d.a;
-                g++;
-                uint64_t r = orc_bounded(x, (uint64_t)(hi - t));
-                if (r <= (uint64_t)(hi - lo)) {
-                    found = hi - (int64_t)r;
-                    break;
-                }
-            }
-            if (idx < q) {
-                hi = L[idx] - 1;
-                t -= 1;
-            }
+        int64_t m = (n - 1) - s; /* tickets left in the urn */
+        if ((s & 1) == 0) d = orc_ctx_draw(c, id, d0_base + (uint32_t)(s >> 1), 0);
+        uint64_t x = (s & 1) ? d.b : d.a;
+        int64_t r = (int64_t)orc_bounded(x, (uint64_t)m), last = m - 1;
+        int64_t tr = r, tl = last;
+        for (int64_t j = 0; j < s; j++) { /* latest entry for an index wins */
+            if (keys[j] == r) tr = vals[j];
+            if (keys[j] == last) tl = vals[j];
         }
-        if (found >= 0) {
-            res = found;
-            /* insert into the descending list */
-            int64_t p = q;
-            while (p > 0 && L[p - 1] < found) {
-                L[p] = L[p - 1];
-                p--;
-            }
-            L[p] = found;
-            q++;
-        }
-        dst[s] = res;
+        keys[s] = r; /* the last ticket of the urn moves into the hole */
+        vals[s] = tl;
+        dst[s] = (tr < n - k) ? k + tr : s;
     }
 }
 
@@ -107,7 +91,7 @@ static inline int64_t orc_reservoir(orc_ctx *c, uint64_t id, uint32_t d0_base, i
             if (j < (uint64_t)k) dst[j] = i;
         }
     } else {
-        orc_reservoir_slots(c, id, d0_base, n, k, dst, scratch);
+        orc_reservoir_tickets(c, id, d0_base, n, k, dst, scratch);
     }
     return filled;
 }
@@ -118,7 +102,10 @@ static inline int64_t orc_replacement(orc_ctx *c, uint64_t id, int64_t n, int64_
         if (c->rng->mode == ORC_RNG_REF)
             dst[s] = (int64_t)orc_ref_gen_range_u64(c->rng, (uint64_t)n);
         else
-            dst[s] = (int64_t)orc_bounded(orc_ctx_draw(c, id, (uint32_t)s, 0x52455000u).a, (uint64_t)n);
+        {
+            orc_draw d = orc_ctx_draw(c, id, (uint32_t)(s >> 1), 0x52455000u);
+            dst[s] = (int64_t)orc_bounded((s & 1) ? d.b : d.a, (uint64_t)n);
+        }
     }
     return k;
 }

@@ -71,7 +71,7 @@ ORC_API int64_t orc_reservoir_positions(orc_rng *rng, uint32_t tag, uint64_t id,
                                         int64_t *dst) {
     orc_ctx c;
     orc_ctx_init(&c, rng, tag);
-    int64_t *scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
+    int64_t *scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? 2 * k : 2));
     int64_t r = orc_reservoir(&c, id, 0, n, k, dst, scratch, algo);
     free(scratch);
     return r;
@@ -213,7 +213,7 @@ static void sst_init(orc_sampler_state *st, int64_t k) {
     memset(st, 0, sizeof(*st));
     st->k = k;
     st->dst = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
-    st->scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
+    st->scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? 2 * k : 2));
 }
 static void sst_free(orc_sampler_state *st) {
     free(st->cand);
@@ -540,8 +540,8 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
                     vpush(&ct, t);
                 }
             }
-            int64_t pos, scratch;
-            int64_t success = orc_reservoir(&c, (uint64_t)i, (uint32_t)l, cn.n, 1, &pos, &scratch, reservoir_algo);
+            int64_t pos, scratch[2];
+            int64_t success = orc_reservoir(&c, (uint64_t)i, (uint32_t)l, cn.n, 1, &pos, scratch, reservoir_algo);
             int64_t next, next_t;
             if (success == 0) { /* :144-148 restart from an earlier position */
                 uint64_t rr;

@@ -76,7 +76,7 @@ def _rng(mode, call=0):
 
 
 @pytest.mark.parametrize("mode", ["ref", "philox"])
-@pytest.mark.parametrize("algo", [orc.RES_SLOTS, orc.RES_LITERAL])
+@pytest.mark.parametrize("algo", [orc.RES_TICKETS, orc.RES_LITERAL])
 def test_uniform_invariants(karate_csc, mode, algo):
     ptrs, idx = karate_csc
     for sampler in (orc.SAMPLER_UNIFORM, orc.SAMPLER_UNIFORM_REPL):

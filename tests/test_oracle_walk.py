@@ -51,7 +51,7 @@ def test_random_walk_dead_end_pads_minus_one():
 
 
 @pytest.mark.parametrize("mode", ["ref", "philox"])
-@pytest.mark.parametrize("algo", [orc.RES_SLOTS, orc.RES_LITERAL])
+@pytest.mark.parametrize("algo", [orc.RES_TICKETS, orc.RES_LITERAL])
 def test_tempo_random_walk_window(karate_csr, mode, algo):
     """random_walk.rs:333-383: ts U{-1..4}, start ts [0,-1,2,3], L=10, window (0,2)."""
     ptrs, idx, n = karate_csr

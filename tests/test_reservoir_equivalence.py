@@ -1,4 +1,4 @@
-"""The O(k) "reservoir by slots" closed form has EXACTLY the output distribution of the reference's
+"""The k-draw "reservoir by tickets" closed form has EXACTLY the output distribution of the reference's
 reservoir loop (src/utils/sampling.rs:6-26, including its 0..i quirk).
 
 Both laws are enumerated exhaustively with rational arithmetic (no RNG, no C code): the reference loop
@@ -30,40 +30,29 @@ def law_reference_loop(n, k):
     return law
 
 
-def law_slots(n, k):
-    """Enumerates the closed form: every bounded draw r ~ U[0, hi - t)."""
+def law_tickets(n, k):
+    """Enumerates the closed form: k ordered tickets without replacement from an urn of (n-k) position
+    tickets and (k-1) blanks, drawn by partial Fisher-Yates with r_s ~ U[0, n-1-s)."""
     law = Counter()
-
-    def rec(s, claimed, dst, prob):
-        if s == k:
-            law[tuple(dst)] += prob
-            return
-        L = sorted(claimed, reverse=True)
-        q = len(L)
-
-        def seg(idx, hi, t, p):
-            lo = L[idx] + 1 if idx < q else k
-            if hi >= lo:
-                rng_range = hi - t
-                hit = hi - lo + 1
-                for r in range(hit):                       # hit at position hi - r
-                    rec(s + 1, claimed | {hi - r}, dst + [hi - r], p * Fraction(1, rng_range))
-                p = p * Fraction(rng_range - hit, rng_range)
-            if idx < q:
-                if p:
-                    seg(idx + 1, L[idx] - 1, t - 1, p)
-            elif p:
-                rec(s + 1, claimed, dst + [s], p)          # never hit: keeps item s
-
-        seg(0, n - 1, s, prob)
-
-    rec(0, frozenset(), [], Fraction(1))
+    ranges = [range(n - 1 - s) for s in range(k)]
+    total = 1
+    for r in ranges:
+        total *= len(r)
+    for rs in product(*ranges):
+        urn = list(range(n - 1))
+        dst = []
+        for s, r in enumerate(rs):
+            last = n - 2 - s
+            t = urn[r]
+            urn[r] = urn[last]
+            dst.append(k + t if t < n - k else s)
+        law[tuple(dst)] += Fraction(1, total)
     return law
 
 
 @pytest.mark.parametrize("n,k", [(2, 1), (3, 1), (5, 1), (3, 2), (4, 2), (6, 2), (7, 3), (6, 4), (8, 3), (7, 5)])
-def test_slots_law_equals_reference_loop_law_exactly(n, k):
-    a, b = law_reference_loop(n, k), law_slots(n, k)
+def test_tickets_law_equals_reference_loop_law_exactly(n, k):
+    a, b = law_reference_loop(n, k), law_tickets(n, k)
     assert sum(a.values()) == 1 and sum(b.values()) == 1
     assert a == b
 
@@ -74,7 +63,7 @@ def test_quirk_item_k_never_leaves_unless_evicted():
     assert all(3 in dst for dst in law)
 
 
-@pytest.mark.parametrize("algo", [orc.RES_SLOTS, orc.RES_LITERAL])
+@pytest.mark.parametrize("algo", [orc.RES_TICKETS, orc.RES_LITERAL])
 @pytest.mark.parametrize("n,k", [(6, 2), (7, 3), (9, 4)])
 def test_c_oracle_philox_algorithms_follow_the_law(algo, n, k):
     law = law_reference_loop(n, k)
@@ -100,7 +89,7 @@ def test_c_oracle_ref_mode_follows_the_law():
 
 
 def test_small_n_takes_everything_in_order():
-    for algo in (orc.RES_SLOTS, orc.RES_LITERAL):
+    for algo in (orc.RES_TICKETS, orc.RES_LITERAL):
         assert orc.reservoir_positions(orc.rng_philox(1), 3, 5, algo=algo).tolist() == [0, 1, 2]
         assert orc.reservoir_positions(orc.rng_philox(1), 5, 5, algo=algo).tolist() == [0, 1, 2, 3, 4]
         assert orc.reservoir_positions(orc.rng_philox(1), 0, 5, algo=algo).tolist() == []
