@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sampled edges/sec of neighbor_sampling_homogenous, fanout [15,10], batch 1024,
+on a synthetic RMAT scale-24 graph (BASELINE.json configs[1]), HIP path through the C ABI.
+
+A "step" is one 1024-seed batch.  Steps are submitted `--batches-per-launch` at a time (one kernel
+launch covers that many independent batches; seeds, CSC and output slabs are resident in HBM).
+N > 1: one process per GPU (torchrun), CSC replicated, every rank samples its own K batches with no
+data-path collective (weak scaling); the only collectives are the barrier / MAX / SUM of the timing
+protocol.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tch-geometric_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--warmup", type=int, default=1024)
+    ap.add_argument("--scale", type=int, default=24)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--fanout", type=str, default="15,10")
+    ap.add_argument("--batches-per-launch", type=int, default=1024)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from tch_geometric import _cabi  # raises if the gfx950 library is missing (no fallback)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
+                         % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    fanout = [int(x) for x in args.fanout.split(",")]
+    n_nodes = 1 << args.scale
+    n_edges = n_nodes * args.edge_factor
+    K, W, G, B = args.steps, args.warmup, args.batches_per_launch, args.batch
+
+    # ---- graph: R-MAT edges -> CSC with the reference's sort key (storage.rs:118-123); resident in HBM
+    t_build = time.time()
+    row, col = _cabi.rmat_edges(args.scale, n_edges, 0x5EED0000 + args.scale, dev)
+    ptrs, indices, perm = _cabi.coo_to_csx(row, col, n_nodes, n_nodes, True)
+    del row, col, perm
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    t_build = time.time() - t_build
+    graph = _cabi.graph_view(ptrs, indices)
+
+    # ---- this rank's batches: global batch ids [rank*(W+K), (rank+1)*(W+K))
+    first = rank * (W + K)
+    seeds = _cabi.seed_batches(0xBA7C4, first, W + K, B, n_nodes, dev)
+    out = _cabi.NsBatchedOut(min(G, max(W, K)), B, fanout, dev)
+    acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
+
+    def run(lo, hi, events=None):
+        for s in range(lo, hi, G):
+            e = min(hi, s + G)
+            if events is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            _cabi.ns_homo_batched(graph, seeds[s:e], fanout, 0, first + s, out)
+            if events is not None:
+                ev1.record()
+                events.append((ev0, ev1))
+            nb = e - s
+            ne = out.counts[:nb, 1].sum()
+            # frontier slots expanded = seeds + samples that existed when the last hop started
+            nf = out.layer_offsets[:nb, len(fanout) - 1, 0].sum() if fanout else torch.zeros((), dtype=torch.int64,
+                                                                                             device=dev)
+            acc.add_(torch.stack([ne, nf, torch.ones((), dtype=torch.int64, device=dev)]))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(0, W)
+    acc.zero_()
+    events = []
+    fence()
+    t0 = time.perf_counter()
+    run(W, W + K, events)
+    fence()
+    dt = time.perf_counter() - t0
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = acc.clone()
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt_max = float(tmax.item())
+    edges_all, frontier_all, launches_all = (int(x) for x in tot.tolist())
+
+    # ---- roofline of the dominant kernel (this rank): algorithmic bytes / HIP-event kernel time
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    my_edges, my_frontier, my_launches = (int(x) for x in acc.tolist())
+    # per hop: 24 B per frontier slot (8 id + 16 ptrs pair) + 40 B per sampled edge (8 gather + 32 written);
+    # per batch: 16 B per seed (read + copy into `samples`)            -- SURVEY.md 8(d)
+    alg_bytes = 24 * my_frontier + 40 * my_edges + 16 * B * K
+    bytes_per_launch = alg_bytes / my_launches
+    achieved = bytes_per_launch / avg_kernel_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [15,10] on RMAT-24",
+        "value": edges_all / dt_max,
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt_max / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {
+            "workload": "neighbor_sampling_homogenous, RMAT scale-%d (%d nodes / %d edges, CSC i64), fanout %s, "
+                        "batch %d, default sampler (uniform w/o replacement), no filter" %
+                        (args.scale, n_nodes, n_edges, fanout, B),
+            "batches_per_launch": G,
+            "rng": "philox4x32-10 counter-addressed, seed 0, call_id = global batch id",
+            "parallelism": "replicated CSC, %d x independent seed batches" % world,
+            "sampled_edges_per_step": edges_all / (K * world),
+            "graph_build_s": round(t_build, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel": "ns_homo_uniform_kernel",
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": avg_kernel_s * 1e3,
+            "launches": my_launches,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[W:], fanout)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, ptrs, indices, seeds, fanout):
+    """The oracle's ref-mode (sequential Xoshiro256++, the reference's algorithm draw for draw) timed on
+    this box's host cores over a bounded sample of the same batches; threads own whole batches."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc  # the checker, used here only as the timed CPU baseline
+
+    hp, hi = ptrs.cpu().numpy(), indices.cpu().numpy()
+    hs = seeds.cpu().numpy()
+    threads = max(1, min(16, os.cpu_count() or 1))
+    n0 = min(threads, hs.shape[0])
+    sec0, _ = orc.bench_ns_homo(hp, hi, hs[:n0], fanout, threads)          # calibration: one batch per thread
+    per_round = max(sec0, 1e-4)
+    n = int(min(hs.shape[0], max(n0, threads * max(1, round(args.cpu_seconds / per_round)))))
+    sec, edges = orc.bench_ns_homo(hp, hi, hs[:n], fanout, threads)
+    sec1, edges1 = orc.bench_ns_homo(hp, hi, hs[:max(1, n // threads)], fanout, 1)
+    return {
+        "value": edges / sec,
+        "unit": "edges/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d of the timed 1024-seed batches, oracle ref-mode (rand-0.8.5 Xoshiro256++ stream, "
+                  "reservoir loop of sampling.rs), %d threads each owning whole batches, %.1f s wall; "
+                  "single thread: %.3g edges/s over %d batches" %
+                  (n, threads, sec, edges1 / sec1, max(1, n // threads)),
+        "single_thread_value": edges1 / sec1,
+    }
+
+
+if __name__ == "__main__":
+    main()

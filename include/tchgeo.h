@@ -1,0 +1,141 @@
+/*
+ * tchgeo.h -- C ABI of the MI355X (gfx950) graph-sampling backend that replaces
+ * tch-geometric's CPU samplers (reference: the files under src/algo) behind its Python
+ * operator surface (reference: src/python.rs, tch_geometric/tch_geometric.pyi).
+ *
+ * Conventions
+ *  - plain C: raw device pointers + sizes, no torch / HIP types in signatures
+ *    (`stream` is a hipStream_t passed as void*; NULL = the default stream);
+ *  - every entry point is stream-ordered and never synchronises, allocates or
+ *    frees: the caller owns every buffer, including outputs and workspaces;
+ *  - all indices are int64 (reference: src/utils/types.rs:4-9), weights are
+ *    float64 (python.rs:214), timestamps int64 (python.rs:149);
+ *  - return value: TG_OK or a TG_ERR_* code; tg_last_error() gives the text of
+ *    the last failure on the calling thread;
+ *  - randomness: counter-addressed Philox4x32-10.  A draw is named by
+ *    (seed, call_id, operator tag, id, d0, d1); results do not depend on
+ *    launch geometry, and equal the CPU oracle's philox-mode bit for bit.
+ *    (The reference's own stream -- one sequential Xoshiro256++ threaded
+ *    through every vertex with data-dependent rejection, utils/random.rs +
+ *    rand 0.8.5 -- cannot be reproduced by any parallel device; DESIGN.md.)
+ */
+#ifndef TCHGEO_H
+#define TCHGEO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_API __attribute__((visibility("default")))
+
+#define TG_OK 0
+#define TG_ERR_INVALID 1     /* bad argument (null pointer, negative size, unsupported fan-out ...) */
+#define TG_ERR_HIP 2         /* a HIP runtime call failed */
+#define TG_ERR_UNSUPPORTED 3 /* valid request this build does not implement */
+
+#define TG_MAX_HOPS 8
+#define TG_MAX_FANOUT 32 /* per-hop fan-out handled by the register-resident sampler */
+
+/* Adjacency resident in HBM, borrowed for the call: replaces
+ * SparseGraph{ptrs,indices} (src/data/graph.rs:34-38) and EdgeAttr
+ * (graph.rs:104-120).  CSC for neighbor sampling / HGT, CSR for walks and
+ * negative sampling; rows must be sorted ascending inside a column
+ * (to_csc/to_csr guarantee it, src/data/storage.rs:112,119). */
+typedef struct {
+    const int64_t *ptrs;       /* [n_major + 1] */
+    const int64_t *indices;    /* [n_edges] */
+    const double *weights;     /* [n_edges] or NULL  (WeightedSampler, neighbor_sampling.rs:131-158) */
+    const int64_t *timestamps; /* [n_edges] or NULL  (TemporalFilter, neighbor_sampling.rs:36-77) */
+    int64_t n_major;
+    int64_t n_edges;
+} tg_graph;
+
+typedef struct {
+    uint64_t seed;
+    uint64_t call_id; /* batch b of a batched call uses call_id + b */
+} tg_rng;
+
+/* Sampler variants of python.rs:210-216 */
+#define TG_SAMPLER_UNIFORM 0      /* UnweightedSampler<false> -- the default (python.rs:215) */
+#define TG_SAMPLER_UNIFORM_REPL 1 /* UnweightedSampler<true> */
+#define TG_SAMPLER_WEIGHTED 2     /* WeightedSampler<f64> */
+/* Filter variants of python.rs:218-249 */
+#define TG_FILTER_NONE (-1)
+#define TG_FILTER_STATIC 0   /* TEMPORAL_SAMPLE_STATIC   (neighbor_sampling.rs:32) */
+#define TG_FILTER_RELATIVE 1 /* TEMPORAL_SAMPLE_RELATIVE */
+#define TG_FILTER_DYNAMIC 2  /* TEMPORAL_SAMPLE_DYNAMIC */
+
+typedef struct {
+    int32_t sampler;     /* TG_SAMPLER_* */
+    int32_t filter_mode; /* TG_FILTER_* */
+    int32_t forward;     /* TemporalFilter FORWARD */
+    int32_t _reserved;
+    int64_t win_lo, win_hi;       /* inclusive window (python.rs:150) */
+    const int64_t *seeds_state;   /* [n_batches * n_seeds] initial filter state, or NULL */
+} tg_ns_config;
+
+/* Per-batch output slabs of neighbor_sampling_homogenous.  Batch b owns
+ * samples[b*cap_nodes ..], rows/cols/edge_index[b*cap_edges ..],
+ * layer_offsets[b*n_hops*3 ..], counts[b*2 ..] = {n_samples, n_edges}.
+ * `states` ([n_batches*cap_nodes]) is workspace for temporal filters, else NULL. */
+typedef struct {
+    int64_t *samples;
+    int64_t *rows;
+    int64_t *cols;
+    int64_t *edge_index;
+    int64_t *layer_offsets;
+    int64_t *counts;
+    int64_t *states;
+    int64_t cap_nodes; /* >= tg_ns_homo_capacity() */
+    int64_t cap_edges;
+} tg_ns_out;
+
+TG_API const char *tg_version(void);
+TG_API const char *tg_last_error(void);
+
+/* Worst-case slab sizes for n_seeds seeds and fan-outs k_0..k_{H-1}:
+ * cap_edges = sum_h n_seeds*k_0*...*k_h, cap_nodes = n_seeds + cap_edges. */
+TG_API int tg_ns_homo_capacity(int64_t n_seeds, const int64_t *fanout, int32_t n_hops, int64_t *cap_nodes,
+                        int64_t *cap_edges);
+
+/* neighbor_sampling_homogenous (src/algo/neighbor_sampling.rs:162-230; binding
+ * python.rs:187-271) for n_batches independent seed batches in one launch.
+ * seeds: [n_batches * n_seeds] device int64.  Output layout per batch is the
+ * reference's: samples = seeds ++ hop-1 samples ++ ..., rows[e] = n_seeds + e,
+ * cols[e] = slot of the parent, edge_index[e] = CSC edge pointer,
+ * layer_offsets[h] = (len(samples), len(edges), len(samples)) when hop h starts. */
+TG_API int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                       const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                       const tg_ns_out *out, void *stream);
+
+/* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
+ * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */
+TG_API int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,
+                   const tg_rng *rng, int64_t *walks, void *stream);
+
+/* tempo_random_walk (random_walk.rs:80-158; binding python.rs:611-642).
+ * walks, walks_ts: [n, walk_length] device int64. */
+TG_API int tg_tempo_random_walk(const tg_graph *csr, const int64_t *node_ts, const int64_t *edge_ts, const int64_t *start,
+                         const int64_t *start_ts, int64_t n, int64_t walk_length, int64_t win0, int64_t win1,
+                         const tg_rng *rng, int64_t *walks, int64_t *walks_ts, void *stream);
+
+/* ---- synthetic inputs of the measurement harness ---- */
+
+/* R-MAT edge list: n_edges edges over 2^scale vertices, (a,b,c,d) =
+ * (0.57,0.19,0.19,0.05), one Philox word per bit; duplicates and self loops
+ * kept.  row, col: [n_edges] device int64. */
+TG_API int tg_rmat_edges(int32_t scale, int64_t n_edges, uint64_t seed, int64_t *row, int64_t *col, void *stream);
+
+/* Seed batches: out[b*n_seeds + i] = Philox(seed; first_batch + b, i) mod n_nodes. */
+TG_API int tg_seed_batches(uint64_t seed, int64_t first_batch, int64_t n_batches, int64_t n_seeds, int64_t n_nodes,
+                    int64_t *out, void *stream);
+
+/* ind2ptr (src/data/storage.rs:67-101) on the device: sorted `ind` [numel] -> out [m+1]. */
+TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -342,3 +342,18 @@ def bench_ns_homo(ptrs, indices, seeds, fanout, n_threads):
                                   C.c_int64(seeds.shape[0]), _p(fan), C.c_int32(fan.size), C.c_int32(n_threads),
                                   C.byref(edges))
     return float(sec), int(edges.value)
+
+
+# ---------------------------------------------------------------- synthetic inputs
+def rmat_edges(scale, n_edges, seed):
+    row = np.empty(n_edges, dtype=np.int64)
+    col = np.empty(n_edges, dtype=np.int64)
+    lib().orc_rmat_edges(C.c_int32(scale), C.c_int64(n_edges), C.c_uint64(seed), _p(row), _p(col))
+    return row, col
+
+
+def seed_batches(seed, first_batch, n_batches, n_seeds, n_nodes):
+    out = np.empty((n_batches, n_seeds), dtype=np.int64)
+    lib().orc_seed_batches(C.c_uint64(seed), C.c_int64(first_batch), C.c_int64(n_batches), C.c_int64(n_seeds),
+                           C.c_int64(n_nodes), _p(out))
+    return out

@@ -815,3 +815,34 @@ ORC_API double orc_bench_ns_homo(const int64_t *ptrs, const int64_t *indices, co
     free(th);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------ */
+/* Synthetic inputs: CPU twins of the device generators */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_rmat_edges(int32_t scale, int64_t n_edges, uint64_t seed, int64_t *row, int64_t *col) {
+    const uint32_t T_A = 2448131358u, T_AB = 3264175144u, T_ABC = 4080218931u; /* 0.57, 0.76, 0.95 of 2^32 */
+    orc_callkey ck = orc_philox_callkey(seed, 0, ORC_TAG_RMAT);
+    for (int64_t e = 0; e < n_edges; e++) {
+        int64_t r = 0, c = 0;
+        orc_draw d = {0};
+        for (int bit = 0; bit < scale; bit++) {
+            if ((bit & 3) == 0) d = orc_philox_draw(ck, (uint64_t)e, (uint32_t)(bit >> 2), 0);
+            uint32_t u = d.w[bit & 3];
+            int rb = u >= T_AB;
+            int cb = (u >= T_A && u < T_AB) || u >= T_ABC;
+            r = (r << 1) | rb;
+            c = (c << 1) | cb;
+        }
+        row[e] = r;
+        col[e] = c;
+    }
+}
+ORC_API void orc_seed_batches(uint64_t seed, int64_t first_batch, int64_t n_batches, int64_t n_seeds, int64_t n_nodes,
+                              int64_t *out) {
+    orc_callkey ck = orc_philox_callkey(seed, 0, ORC_TAG_SEEDS);
+    for (int64_t b = 0; b < n_batches; b++)
+        for (int64_t i = 0; i < n_seeds; i++) {
+            orc_draw d = orc_philox_draw(ck, (uint64_t)(first_batch + b), (uint32_t)i, (uint32_t)((uint64_t)i >> 32));
+            out[b * n_seeds + i] = (int64_t)orc_bounded(d.a, (uint64_t)n_nodes);
+        }
+}

@@ -1,0 +1,302 @@
+// neighbor_sampling_homogenous on gfx950 -- replaces the hot loop of
+// src/algo/neighbor_sampling.rs:188-223 (reference) for the unweighted,
+// unfiltered samplers (UnweightedSampler<false|true> + IdentityFilter).
+//
+// Shape of the work.  The reference emits a forest without node dedup
+// (neighbor_sampling.rs:212-217), so a batch's output positions follow from a
+// prefix sum of per-vertex sample counts; no hash table is needed.  One
+// workgroup owns one seed batch and walks its hops in order (hop h+1's
+// frontier is hop h's output), so hops are separated by a workgroup barrier
+// only -- no grid sync, no temporaries in HBM, and thousands of batches run
+// side by side in one launch to cover HBM latency.
+//
+// Per hop and 64-vertex chunk of the frontier (one wavefront):
+//   pass A  lane = frontier vertex: load ptrs[w], ptrs[w+1] -> count
+//           min(deg,k) (or k with replacement); wave sum -> LDS chunk total
+//   scan    wave 0 turns chunk totals into exclusive offsets (LDS)
+//   pass B  lane = frontier vertex: draw its <=k neighbour positions from
+//           counter-addressed Philox ("reservoir by tickets", k bounded draws,
+//           register-resident shuffle list), stage them in LDS in OUTPUT order;
+//           then the wave walks that staged slice with consecutive lanes:
+//           gather indices[edge_ptr] and write samples/rows/cols/edge_index
+//           fully coalesced.
+// Algorithmic HBM bytes per hop (F frontier slots, S sampled edges):
+//   reads 8F (frontier id) + 16F (ptrs pair) + 8S (gather), writes 32S.
+#include "tg_device.h"
+#include "tg_host.h"
+
+namespace tg {
+
+constexpr int NS_CHUNKS_PER_ROUND = 1024; // 64-vertex chunks whose totals fit the LDS scan array
+
+struct NsHomoParams {
+    const int64_t *ptrs;
+    const int64_t *indices;
+    const int64_t *seeds;
+    int64_t n_seeds;
+    int32_t n_hops;
+    int32_t kmax; // max fan-out over hops (sizes the LDS staging)
+    int32_t fanout[TG_MAX_HOPS];
+    int64_t cap_nodes, cap_edges;
+    int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts;
+    uint64_t seed, call_id;
+};
+
+__host__ __device__ inline size_t ns_wave_lds_bytes(int kmax) {
+    return 64 * sizeof(int64_t) + (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
+}
+__host__ __device__ inline size_t ns_block_lds_bytes(int kmax, int n_waves) {
+    return (((size_t)(NS_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) +
+           (size_t)n_waves * ns_wave_lds_bytes(kmax);
+}
+
+// Reservoir by tickets for one vertex with n > k candidates: slot s receives
+// position k+ticket or keeps position s on a blank.  The shuffle's
+// displaced entries live in registers; loops are fully unrolled so that no
+// array is indexed dynamically.
+template <int KMAX>
+__device__ __forceinline__ void sample_tickets(CallKey ck, uint64_t id, uint32_t n, int k, uint32_t *spos,
+                                               uint8_t *slane, uint32_t out_base, int lane) {
+    uint32_t keys[KMAX], vals[KMAX];
+    Draw d;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (s < k) {
+            const uint32_t m = (n - 1u) - (uint32_t)s;
+            if ((s & 1) == 0) d = draw(ck, id, (uint32_t)(s >> 1), 0u);
+            const uint32_t r = bounded32(d.half(s & 1), m);
+            const uint32_t last = m - 1u;
+            uint32_t tr = r, tl = last;
+#pragma unroll
+            for (int j = 0; j < s; ++j) {
+                tr = (keys[j] == r) ? vals[j] : tr;
+                tl = (keys[j] == last) ? vals[j] : tl;
+            }
+            keys[s] = r;
+            vals[s] = tl;
+            const uint32_t pos = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+            spos[out_base + s] = pos;
+            slane[out_base + s] = (uint8_t)lane;
+        }
+    }
+}
+
+template <int KMAX, bool REPLACE>
+__global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int64_t b = blockIdx.x;
+
+    uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *wbase = smem + ((((size_t)(NS_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15) +
+                           (size_t)wave * ns_wave_lds_bytes(p.kmax);
+    int64_t *ebase = reinterpret_cast<int64_t *>(wbase);
+    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 64 * sizeof(int64_t));
+    uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 64 * sizeof(int64_t) + (size_t)64 * p.kmax * sizeof(uint32_t));
+
+    int64_t *samples = p.samples + b * p.cap_nodes;
+    int64_t *rows = p.rows + b * p.cap_edges;
+    int64_t *cols = p.cols + b * p.cap_edges;
+    int64_t *eidx = p.edge_index + b * p.cap_edges;
+    const int64_t n_seeds = p.n_seeds;
+
+    for (int64_t i = tid; i < n_seeds; i += blockDim.x) samples[i] = p.seeds[b * n_seeds + i]; // :184
+    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, TAG_NS_HOMO);
+    __syncthreads();
+
+    int64_t begin = 0, end = n_seeds; // frontier = samples[begin, end)   (:187)
+    int64_t ne = 0;                   // edges emitted so far; samples so far = n_seeds + ne
+    for (int h = 0; h < p.n_hops; ++h) {
+        const int k = p.fanout[h];
+        if (tid == 0) { // :193
+            int64_t *lo = p.layer_offsets + (b * p.n_hops + h) * 3;
+            lo[0] = n_seeds + ne;
+            lo[1] = ne;
+            lo[2] = n_seeds + ne;
+        }
+        const int64_t hop_edge_base = ne;
+        for (int64_t round_begin = begin; round_begin < end; round_begin += (int64_t)NS_CHUNKS_PER_ROUND * 64) {
+            const int64_t round_end = min(end, round_begin + (int64_t)NS_CHUNKS_PER_ROUND * 64);
+            const int nc = (int)((round_end - round_begin + 63) >> 6);
+            // ---- pass A: per-chunk sample counts
+            for (int c = wave; c < nc; c += n_waves) {
+                const int64_t i = round_begin + (int64_t)c * 64 + lane;
+                uint32_t cnt = 0;
+                if (i < round_end) {
+                    const int64_t w = samples[i];
+                    const int64_t deg = p.ptrs[w + 1] - p.ptrs[w];
+                    cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+                }
+                const uint32_t tot = wave_sum(cnt);
+                if (lane == 0) chunk_off[c] = tot;
+            }
+            __syncthreads();
+            // ---- scan of chunk totals (wave 0)
+            if (wave == 0) {
+                uint32_t carry = 0;
+                for (int c0 = 0; c0 < nc; c0 += 64) {
+                    const uint32_t v = (c0 + lane < nc) ? chunk_off[c0 + lane] : 0u;
+                    const uint32_t incl = wave_inclusive_scan(v);
+                    if (c0 + lane < nc) chunk_off[c0 + lane] = carry + incl - v;
+                    carry += __shfl(incl, 63, 64);
+                }
+                if (lane == 0) chunk_off[nc] = carry;
+            }
+            __syncthreads();
+            // ---- pass B: sample, stage in output order, coalesced emit
+            for (int c = wave; c < nc; c += n_waves) {
+                const int64_t i0 = round_begin + (int64_t)c * 64;
+                const int64_t i = i0 + lane;
+                int64_t e0 = 0, deg = 0;
+                if (i < round_end) {
+                    const int64_t w = samples[i];
+                    e0 = p.ptrs[w];
+                    deg = p.ptrs[w + 1] - e0;
+                }
+                const uint32_t cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+                const uint32_t incl = wave_inclusive_scan(cnt);
+                const uint32_t excl = incl - cnt;
+                const uint32_t total = __shfl(incl, 63, 64);
+                ebase[lane] = e0;
+                if (cnt > 0) {
+                    const uint32_t n = (uint32_t)deg;
+                    if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
+                        Draw d;
+                        for (int s = 0; s < k; ++s) {
+                            if ((s & 1) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 1), D1_REPLACE);
+                            spos[excl + s] = bounded32(d.half(s & 1), n);
+                            slane[excl + s] = (uint8_t)lane;
+                        }
+                    } else if (deg <= k) { // sampling.rs:12-15: the reservoir is just filled
+                        for (uint32_t s = 0; s < cnt; ++s) {
+                            spos[excl + s] = s;
+                            slane[excl + s] = (uint8_t)lane;
+                        }
+                    } else {
+                        sample_tickets<KMAX>(ck, (uint64_t)i, n, k, spos, slane, excl, lane);
+                    }
+                }
+                wave_lds_handoff();
+                const int64_t e_chunk = ne + (int64_t)chunk_off[c];
+#pragma unroll 4
+                for (uint32_t q = lane; q < total; q += 64) {
+                    const int l = slane[q];
+                    const int64_t ep = ebase[l] + (int64_t)spos[q];
+                    const int64_t v = p.indices[ep]; // :211
+                    const int64_t e = e_chunk + q;
+                    samples[n_seeds + e] = v;   // :215
+                    rows[e] = n_seeds + e;      // :217 j
+                    cols[e] = i0 + l;           // :217 i
+                    eidx[e] = ep;               // :217 edge_ptr
+                }
+                wave_lds_handoff();
+            }
+            __syncthreads();
+            ne += chunk_off[nc];
+            __syncthreads(); // chunk_off is rewritten by the next round
+        }
+        (void)hop_edge_base;
+        begin = end; // :221-222
+        end = n_seeds + ne;
+    }
+    if (tid == 0) {
+        p.counts[b * 2 + 0] = n_seeds + ne;
+        p.counts[b * 2 + 1] = ne;
+    }
+}
+
+template <int KMAX, bool REPLACE>
+static int launch_uniform(const NsHomoParams &p, int64_t n_batches, hipStream_t stream) {
+    // few batches: wide workgroups for latency; many batches: narrow ones for occupancy
+    int threads = (n_batches < 512) ? 1024 : 256;
+    while (threads > 64 && ns_block_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads >>= 1; // default LDS limit
+    const size_t lds = ns_block_lds_bytes(p.kmax, threads / 64);
+    hipLaunchKernelGGL((ns_homo_uniform_kernel<KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads), lds, stream,
+                       p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+} // namespace tg
+
+extern "C" int tg_ns_homo_capacity(int64_t n_seeds, const int64_t *fanout, int32_t n_hops, int64_t *cap_nodes,
+                                   int64_t *cap_edges) {
+    TG_REQUIRE(n_seeds >= 0 && n_hops >= 0 && (fanout || n_hops == 0), "tg_ns_homo_capacity: bad arguments");
+    int64_t layer = n_seeds, edges = 0;
+    for (int h = 0; h < n_hops; ++h) {
+        TG_REQUIRE(fanout[h] >= 1, "tg_ns_homo_capacity: fanout[%d] = %lld must be >= 1", h, (long long)fanout[h]);
+        TG_REQUIRE(layer == 0 || fanout[h] <= INT64_MAX / 4 / (layer > 0 ? layer : 1),
+                   "tg_ns_homo_capacity: capacity overflows int64");
+        layer *= fanout[h];
+        edges += layer;
+    }
+    if (cap_nodes) *cap_nodes = n_seeds + edges;
+    if (cap_edges) *cap_edges = edges;
+    return TG_OK;
+}
+
+int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                               const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                               const tg_ns_out *out, hipStream_t stream); // ns_homo_scan.hip
+
+extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                                  const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                                  const tg_ns_out *out, void *stream) {
+    TG_REQUIRE(csc && csc->ptrs && (csc->indices || csc->n_edges == 0), "tg_ns_homo_batched: null graph");
+    TG_REQUIRE(rng && out, "tg_ns_homo_batched: null rng/out");
+    TG_REQUIRE(n_batches >= 0 && n_seeds >= 0, "tg_ns_homo_batched: negative sizes");
+    TG_REQUIRE(n_batches <= 0x7fffffff, "tg_ns_homo_batched: too many batches for one launch");
+    TG_REQUIRE(n_hops >= 0 && n_hops <= TG_MAX_HOPS, "tg_ns_homo_batched: n_hops %d outside [0, %d]", n_hops,
+               TG_MAX_HOPS);
+    TG_REQUIRE(seeds || n_seeds == 0, "tg_ns_homo_batched: null seeds");
+    TG_REQUIRE(out->samples && out->counts && (out->layer_offsets || n_hops == 0),
+               "tg_ns_homo_batched: null output buffers");
+    int64_t need_nodes = 0, need_edges = 0;
+    int rc = tg_ns_homo_capacity(n_seeds, fanout, n_hops, &need_nodes, &need_edges);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(out->cap_nodes >= need_nodes && out->cap_edges >= need_edges,
+               "tg_ns_homo_batched: output slabs too small (need %lld nodes / %lld edges per batch)",
+               (long long)need_nodes, (long long)need_edges);
+    TG_REQUIRE(need_edges == 0 || (out->rows && out->cols && out->edge_index),
+               "tg_ns_homo_batched: null edge output buffers");
+    if (n_batches == 0) return TG_OK;
+
+    const int sampler = cfg ? cfg->sampler : TG_SAMPLER_UNIFORM;
+    const int filter = cfg ? cfg->filter_mode : TG_FILTER_NONE;
+    TG_REQUIRE(sampler >= TG_SAMPLER_UNIFORM && sampler <= TG_SAMPLER_WEIGHTED, "tg_ns_homo_batched: bad sampler %d",
+               sampler);
+    TG_REQUIRE(filter >= TG_FILTER_NONE && filter <= TG_FILTER_DYNAMIC, "tg_ns_homo_batched: bad filter %d", filter);
+    if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE)
+        return tg_ns_homo_filtered_launch(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out,
+                                          (hipStream_t)stream);
+
+    tg::NsHomoParams p;
+    p.ptrs = csc->ptrs;
+    p.indices = csc->indices;
+    p.seeds = seeds;
+    p.n_seeds = n_seeds;
+    p.n_hops = n_hops;
+    p.kmax = 1;
+    for (int h = 0; h < TG_MAX_HOPS; ++h) p.fanout[h] = 0;
+    for (int h = 0; h < n_hops; ++h) {
+        TG_REQUIRE(fanout[h] <= TG_MAX_FANOUT, "tg_ns_homo_batched: fanout[%d] = %lld exceeds TG_MAX_FANOUT = %d", h,
+                   (long long)fanout[h], TG_MAX_FANOUT);
+        p.fanout[h] = (int32_t)fanout[h];
+        if (p.fanout[h] > p.kmax) p.kmax = p.fanout[h];
+    }
+    p.cap_nodes = out->cap_nodes;
+    p.cap_edges = out->cap_edges;
+    p.samples = out->samples;
+    p.rows = out->rows;
+    p.cols = out->cols;
+    p.edge_index = out->edge_index;
+    p.layer_offsets = out->layer_offsets;
+    p.counts = out->counts;
+    p.seed = rng->seed;
+    p.call_id = rng->call_id;
+    hipStream_t s = (hipStream_t)stream;
+    const bool repl = sampler == TG_SAMPLER_UNIFORM_REPL;
+    if (p.kmax <= 16)
+        return repl ? tg::launch_uniform<16, true>(p, n_batches, s) : tg::launch_uniform<16, false>(p, n_batches, s);
+    return repl ? tg::launch_uniform<32, true>(p, n_batches, s) : tg::launch_uniform<32, false>(p, n_batches, s);
+}

@@ -1,0 +1,110 @@
+// Device-side building blocks shared by the gfx950 kernels: counter-addressed
+// Philox4x32-10 draws, bounded integers, wave64 scans.  Written for CDNA4 only
+// (64-lane wavefronts are assumed everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+// operator tags of the draw address (must match the spec in DESIGN.md "Randomness")
+constexpr uint32_t TAG_NS_HOMO = 1u;
+constexpr uint32_t TAG_NS_HETERO = 2u;
+constexpr uint32_t TAG_RW = 3u;
+constexpr uint32_t TAG_RW_TEMPO = 4u;
+constexpr uint32_t TAG_NEG_HOMO = 5u;
+constexpr uint32_t TAG_NEG_HETERO = 6u;
+constexpr uint32_t TAG_HGT = 7u;
+constexpr uint32_t TAG_RMAT = 8u;
+constexpr uint32_t TAG_SEEDS = 9u;
+
+constexpr uint32_t D1_REPLACE = 0x52455000u;  // "REP"
+constexpr uint32_t D1_LITERAL = 0x4C495400u;  // "LIT"
+constexpr uint32_t D1_WEIGHTED = 0x57475400u; // "WGT"
+constexpr uint32_t D1_RESTART = 0x52535400u;  // "RST"
+
+struct Draw {
+    uint32_t w[4];
+    __device__ __forceinline__ uint64_t a() const { return (uint64_t)w[0] | ((uint64_t)w[1] << 32); }
+    __device__ __forceinline__ uint64_t b() const { return (uint64_t)w[2] | ((uint64_t)w[3] << 32); }
+    __device__ __forceinline__ uint64_t half(int h) const { return h ? b() : a(); }
+};
+
+struct CallKey {
+    uint32_t k0, k1;
+};
+
+__device__ __forceinline__ Draw philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    Draw d;
+    d.w[0] = c0;
+    d.w[1] = c1;
+    d.w[2] = c2;
+    d.w[3] = c3;
+    return d;
+}
+
+// per-call key: Philox(key = seed, ctr = (call_id, tag, "tchg")) words 0,1
+__device__ __forceinline__ CallKey call_key(uint64_t seed, uint64_t call_id, uint32_t tag) {
+    const Draw d = philox4x32_10((uint32_t)call_id, (uint32_t)(call_id >> 32), tag, 0x74636867u, (uint32_t)seed,
+                                 (uint32_t)(seed >> 32));
+    return CallKey{d.w[0], d.w[1]};
+}
+
+// the draw named (call key, id, d0, d1)
+__device__ __forceinline__ Draw draw(CallKey ck, uint64_t id, uint32_t d0, uint32_t d1) {
+    return philox4x32_10(d0, d1, (uint32_t)id, (uint32_t)(id >> 32), ck.k0, ck.k1);
+}
+
+// floor(x * range / 2^64)
+__device__ __forceinline__ uint64_t bounded64(uint64_t x, uint64_t range) { return __umul64hi(x, range); }
+// same value for range < 2^32, with 32-bit partial products
+__device__ __forceinline__ uint32_t bounded32(uint64_t x, uint32_t range) {
+    const uint64_t lo = (x & 0xffffffffull) * range;
+    const uint64_t hi = (x >> 32) * range;
+    return (uint32_t)((hi + (lo >> 32)) >> 32);
+}
+__device__ __forceinline__ float u32_to_f32_01(uint32_t w) { return __uint_as_float(0x3F800000u | (w >> 9)) - 1.0f; }
+__device__ __forceinline__ double u64_to_f64_01(uint64_t x) {
+    return __longlong_as_double((long long)(0x3FF0000000000000ull | (x >> 12))) - 1.0;
+}
+
+// ---- wave64 helpers -------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T> __device__ __forceinline__ T wave_inclusive_scan(T v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// orders LDS traffic between lanes of ONE wave (the lanes run in lockstep; this
+// only stops the compiler from moving accesses across the hand-off)
+__device__ __forceinline__ void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+} // namespace tg

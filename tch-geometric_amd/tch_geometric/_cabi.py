@@ -1,0 +1,184 @@
+"""ctypes binding of the C ABI declared in include/tchgeo.h (libtchgeo_hip.so).
+
+There is no CPU fallback: if the gfx950 library is missing this module raises
+at import, and every wrapper raises on a non-zero status code.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtchgeo_hip.so")
+
+TG_OK = 0
+TG_MAX_HOPS = 8
+TG_MAX_FANOUT = 32
+SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL, SAMPLER_WEIGHTED = 0, 1, 2
+FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
+
+EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
+           "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr"]
+
+
+class TgGraph(C.Structure):
+    _fields_ = [("ptrs", C.c_void_p), ("indices", C.c_void_p), ("weights", C.c_void_p), ("timestamps", C.c_void_p),
+                ("n_major", C.c_int64), ("n_edges", C.c_int64)]
+
+
+class TgRng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("call_id", C.c_uint64)]
+
+
+class TgNsConfig(C.Structure):
+    _fields_ = [("sampler", C.c_int32), ("filter_mode", C.c_int32), ("forward", C.c_int32), ("_reserved", C.c_int32),
+                ("win_lo", C.c_int64), ("win_hi", C.c_int64), ("seeds_state", C.c_void_p)]
+
+
+class TgNsOut(C.Structure):
+    _fields_ = [("samples", C.c_void_p), ("rows", C.c_void_p), ("cols", C.c_void_p), ("edge_index", C.c_void_p),
+                ("layer_offsets", C.c_void_p), ("counts", C.c_void_p), ("states", C.c_void_p),
+                ("cap_nodes", C.c_int64), ("cap_edges", C.c_int64)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("tch_geometric: %s is missing -- build it with `make -C tch-geometric_amd` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+lib = C.CDLL(LIB_PATH)
+lib.tg_version.restype = C.c_char_p
+lib.tg_last_error.restype = C.c_char_p
+
+
+class TchGeoError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != TG_OK:
+        raise TchGeoError("tchgeo error %d: %s" % (rc, lib.tg_last_error().decode()))
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def graph_view(ptrs, indices, weights=None, timestamps=None):
+    g = TgGraph()
+    g.ptrs, g.indices = ptrs.data_ptr(), indices.data_ptr()
+    g.weights = weights.data_ptr() if weights is not None else None
+    g.timestamps = timestamps.data_ptr() if timestamps is not None else None
+    g.n_major, g.n_edges = ptrs.numel() - 1, indices.numel()
+    g._keep = (ptrs, indices, weights, timestamps)  # the struct only borrows the device memory
+    return g
+
+
+def ns_homo_capacity(n_seeds, fanout):
+    cn, ce = C.c_int64(0), C.c_int64(0)
+    fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
+    check(lib.tg_ns_homo_capacity(C.c_int64(n_seeds), fan, C.c_int32(len(fanout)), C.byref(cn), C.byref(ce)))
+    return cn.value, ce.value
+
+
+class NsBatchedOut:
+    """Per-batch output slabs (device) of tg_ns_homo_batched."""
+
+    def __init__(self, n_batches, n_seeds, fanout, device, with_states=False):
+        self.n_batches, self.n_seeds, self.n_hops = n_batches, n_seeds, len(fanout)
+        self.cap_nodes, self.cap_edges = ns_homo_capacity(n_seeds, fanout)
+        o = dict(dtype=torch.int64, device=device)
+        self.samples = torch.empty((n_batches, max(self.cap_nodes, 1)), **o)
+        self.rows = torch.empty((n_batches, max(self.cap_edges, 1)), **o)
+        self.cols = torch.empty((n_batches, max(self.cap_edges, 1)), **o)
+        self.edge_index = torch.empty((n_batches, max(self.cap_edges, 1)), **o)
+        self.layer_offsets = torch.zeros((n_batches, max(self.n_hops, 1), 3), **o)
+        self.counts = torch.zeros((n_batches, 2), **o)
+        self.states = torch.empty((n_batches, max(self.cap_nodes, 1)), **o) if with_states else None
+
+    def struct(self):
+        s = TgNsOut()
+        s.samples, s.rows, s.cols = self.samples.data_ptr(), self.rows.data_ptr(), self.cols.data_ptr()
+        s.edge_index, s.layer_offsets = self.edge_index.data_ptr(), self.layer_offsets.data_ptr()
+        s.counts = self.counts.data_ptr()
+        s.states = self.states.data_ptr() if self.states is not None else None
+        s.cap_nodes, s.cap_edges = self.samples.shape[1], self.rows.shape[1]
+        return s
+
+    def batch(self, b, counts=None):
+        """-> (samples, rows, cols, edge_index, layer_offsets) of batch b, trimmed (host sync)."""
+        c = (counts if counts is not None else self.counts.cpu())[b]
+        ns, ne = int(c[0]), int(c[1])
+        lo = [tuple(int(x) for x in row) for row in self.layer_offsets[b, :self.n_hops].cpu()]
+        return self.samples[b, :ns], self.rows[b, :ne], self.cols[b, :ne], self.edge_index[b, :ne], lo
+
+
+def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UNIFORM, filter_mode=FILTER_NONE,
+                    forward=False, window=(0, 0), seeds_state=None):
+    """seeds: [n_batches, n_seeds] int64 on the graph's device; `out` an NsBatchedOut."""
+    assert seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.dim() == 2
+    cfg = TgNsConfig()
+    cfg.sampler, cfg.filter_mode, cfg.forward = sampler, filter_mode, int(bool(forward))
+    cfg.win_lo, cfg.win_hi = window
+    cfg.seeds_state = seeds_state.data_ptr() if seeds_state is not None else None
+    rng = TgRng(seed, call_id)
+    fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
+    so = out.struct()
+    check(lib.tg_ns_homo_batched(C.byref(graph), ptr(seeds), C.c_int64(seeds.shape[0]), C.c_int64(seeds.shape[1]),
+                                 fan, C.c_int32(len(fanout)), C.byref(cfg), C.byref(rng), C.byref(so),
+                                 stream_ptr(seeds.device)))
+    return out
+
+
+def random_walk(graph, start, walk_length, p, q, seed, call_id):
+    walks = torch.empty((start.numel(), walk_length + 1), dtype=torch.int64, device=start.device)
+    rng = TgRng(seed, call_id)
+    check(lib.tg_random_walk(C.byref(graph), ptr(start), C.c_int64(start.numel()), C.c_int64(walk_length),
+                             C.c_float(p), C.c_float(q), C.byref(rng), ptr(walks), stream_ptr(start.device)))
+    return walks
+
+
+def tempo_random_walk(graph, node_ts, edge_ts, start, start_ts, walk_length, window, seed, call_id):
+    walks = torch.empty((start.numel(), walk_length), dtype=torch.int64, device=start.device)
+    wts = torch.empty((start.numel(), walk_length), dtype=torch.int64, device=start.device)
+    rng = TgRng(seed, call_id)
+    check(lib.tg_tempo_random_walk(C.byref(graph), ptr(node_ts), ptr(edge_ts), ptr(start), ptr(start_ts),
+                                   C.c_int64(start.numel()), C.c_int64(walk_length), C.c_int64(window[0]),
+                                   C.c_int64(window[1]), C.byref(rng), ptr(walks), ptr(wts),
+                                   stream_ptr(start.device)))
+    return walks, wts
+
+
+def rmat_edges(scale, n_edges, seed, device):
+    row = torch.empty(n_edges, dtype=torch.int64, device=device)
+    col = torch.empty(n_edges, dtype=torch.int64, device=device)
+    check(lib.tg_rmat_edges(C.c_int32(scale), C.c_int64(n_edges), C.c_uint64(seed), ptr(row), ptr(col),
+                            stream_ptr(device)))
+    return row, col
+
+
+def seed_batches(seed, first_batch, n_batches, n_seeds, n_nodes, device):
+    out = torch.empty((n_batches, n_seeds), dtype=torch.int64, device=device)
+    check(lib.tg_seed_batches(C.c_uint64(seed), C.c_int64(first_batch), C.c_int64(n_batches), C.c_int64(n_seeds),
+                              C.c_int64(n_nodes), ptr(out), stream_ptr(device)))
+    return out
+
+
+def ind2ptr(ind, m):
+    out = torch.empty(m + 1, dtype=torch.int64, device=ind.device)
+    check(lib.tg_ind2ptr(ptr(ind), C.c_int64(ind.numel()), C.c_int64(m), ptr(out), stream_ptr(ind.device)))
+    return out
+
+
+def coo_to_csx(row, col, size0, size1, csc):
+    """Device ingest with the reference's sort key (storage.rs:112,119): stable sort by
+    major*size + minor, then ind2ptr.  Returns (ptrs, indices, perm)."""
+    key = (col * size0 + row) if csc else (row * size1 + col)
+    _, perm = torch.sort(key, stable=True)
+    del key
+    major = (col if csc else row)[perm]
+    indices = (row if csc else col)[perm].contiguous()
+    ptrs = ind2ptr(major.contiguous(), size1 if csc else size0)
+    return ptrs, indices, perm

@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports every symbol include/tchgeo.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tch-geometric_amd", "lib", "libtchgeo_hip.so")
+HEADER = os.path.join(ROOT, "include", "tchgeo.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tch-geometric_amd"), "-s"])
+    return C.CDLL(LIB)
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"TG_API\s+[\w\s\*]+?\b(tg_\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 9 and "tg_ns_homo_batched" in names
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+
+
+def test_python_binding_lists_the_same_exports(lib):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "_cabi_probe", os.path.join(ROOT, "tch-geometric_amd", "tch_geometric", "_cabi.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert sorted(mod.EXPORTS) == declared_symbols()
+
+
+def test_version_and_capacity(lib):
+    lib.tg_version.restype = C.c_char_p
+    assert lib.tg_version().startswith(b"tchgeo-gfx950")
+    cn, ce = C.c_int64(), C.c_int64()
+    fan = (C.c_int64 * 2)(15, 10)
+    assert lib.tg_ns_homo_capacity(C.c_int64(1024), fan, 2, C.byref(cn), C.byref(ce)) == 0
+    assert (cn.value, ce.value) == (1024 + 15360 + 153600, 15360 + 153600)   # S <= 168 960
+    fan0 = (C.c_int64 * 2)(15, 0)
+    assert lib.tg_ns_homo_capacity(C.c_int64(4), fan0, 2, C.byref(cn), C.byref(ce)) == 1   # TG_ERR_INVALID
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    lib.tg_last_error.restype = C.c_char_p
+    assert lib.tg_ns_homo_batched(None, None, C.c_int64(1), C.c_int64(1), None, 0, None, None, None, None) == 1
+    assert b"null graph" in lib.tg_last_error()
+    assert lib.tg_rmat_edges(0, C.c_int64(4), C.c_uint64(0), None, None, None) == 1
