@@ -128,7 +128,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))  # PMC passes of an identical launch (profiles/r01/pmc_summary.json)
+            if tj.get("batches_per_launch") == G and args.scale == 24 and B == 1024 and fanout == [15, 10]:
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 

@@ -135,6 +135,11 @@ TG_API int tg_seed_batches(uint64_t seed, int64_t first_batch, int64_t n_batches
 /* ind2ptr (src/data/storage.rs:67-101) on the device: sorted `ind` [numel] -> out [m+1]. */
 TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out, void *stream);
 
+/* Harness calibration (not part of the sampling path): n_threads lanes each issue per_thread
+ * independent random 8-byte loads from table[0..n_table); sink: [n_threads]. */
+TG_API int tg_probe_random_gather(const int64_t *table, int64_t n_table, int64_t n_threads, int64_t per_thread,
+                                  uint64_t seed, int64_t *sink, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

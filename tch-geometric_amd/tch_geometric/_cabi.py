@@ -18,7 +18,7 @@ SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL, SAMPLER_WEIGHTED = 0, 1, 2
 FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
-           "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr"]
+           "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather"]
 
 
 class TgGraph(C.Structure):
@@ -182,3 +182,10 @@ def coo_to_csx(row, col, size0, size1, csc):
     indices = (row if csc else col)[perm].contiguous()
     ptrs = ind2ptr(major.contiguous(), size1 if csc else size0)
     return ptrs, indices, perm
+
+
+def probe_random_gather(table, n_threads, per_thread, seed=1):
+    sink = torch.empty(n_threads, dtype=torch.int64, device=table.device)
+    check(lib.tg_probe_random_gather(ptr(table), C.c_int64(table.numel()), C.c_int64(n_threads),
+                                     C.c_int64(per_thread), C.c_uint64(seed), ptr(sink), stream_ptr(table.device)))
+    return sink
