@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libtg_oracle.so")
 
 RNG_REF, RNG_PHILOX = 0, 1
-RES_TICKETS, RES_LITERAL = 0, 1
+RES_TICKETS, RES_LITERAL, RES_AUTO = 0, 1, -1
 SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL, SAMPLER_WEIGHTED = 0, 1, 2
 FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 TAG_NS_HOMO, TAG_NS_HETERO, TAG_RW, TAG_RW_TEMPO, TAG_NEG_HOMO, TAG_NEG_HETERO, TAG_HGT = 1, 2, 3, 4, 5, 6, 7
@@ -184,7 +184,7 @@ def ns_capacity(B, fanout):
 
 
 def ns_homo(ptrs, indices, inputs, fanout, rng, sampler=SAMPLER_UNIFORM, weights=None, filter_mode=FILTER_NONE,
-            forward=False, window=None, timestamps=None, inputs_state=None, reservoir_algo=RES_TICKETS):
+            forward=False, window=None, timestamps=None, inputs_state=None, reservoir_algo=RES_AUTO):
     """neighbor_sampling_homogenous -> (samples, rows, cols, edge_index, layer_offsets)."""
     ptrs, indices, inputs = _i64(ptrs), _i64(indices), _i64(inputs)
     fan = _i64(fanout)
@@ -219,7 +219,7 @@ def _rel_key(et):
 
 def ns_hetero(node_types, edge_types, col_ptrs, row_indices, inputs, num_neighbors, num_hops, rng,
               sampler=SAMPLER_UNIFORM, weights=None, filter_mode=FILTER_NONE, forward=False, window=None,
-              timestamps=None, inputs_state=None, reservoir_algo=RES_TICKETS):
+              timestamps=None, inputs_state=None, reservoir_algo=RES_AUTO):
     """neighbor_sampling_heterogenous in canonical (edge_types) relation order.
 
     dicts are keyed like python.rs: relations by "src__rel__dst", node types by name."""
@@ -284,7 +284,7 @@ def random_walk(row_ptrs, col_indices, start, walk_length, p, q, rng):
 
 
 def tempo_random_walk(row_ptrs, col_indices, node_ts, edge_ts, start, start_ts, walk_length, window, rng,
-                      reservoir_algo=RES_TICKETS):
+                      reservoir_algo=RES_AUTO):
     ptrs, indices, start = _i64(row_ptrs), _i64(col_indices), _i64(start)
     node_ts, edge_ts, start_ts = _i64(node_ts), _i64(edge_ts), _i64(start_ts)
     walks = np.empty((start.size, walk_length), dtype=np.int64)
@@ -323,10 +323,13 @@ def neg_hetero(node_types, edge_types, row_ptrs, col_indices, sizes, inputs, num
     n_in = _i64([a.size for a in IN])
     has = (C.c_int32 * T)(*[int(t in inputs) for t in node_types])
     sc = np.zeros(T, dtype=np.int64)
+    status = C.c_int32(0)
     h = lib().orc_neg_hetero(C.c_int32(T), C.c_int32(R), rel_src, rel_dst, _ptr_array(P), _ptr_array(I), _p(SZ),
                              _ptr_array(IN), _p(n_in), has, C.c_int64(num_neg), C.c_int64(try_count),
-                             C.c_int32(int(inbound)), C.byref(rng), _p(sc))
+                             C.c_int32(int(inbound)), C.byref(rng), _p(sc), C.byref(status))
     try:
+        if status.value != 0:
+            raise RuntimeError("oracle neg_hetero: the reference would panic (inbound has_edge row out of range)")
         samples, rows, cols, _, _ = _unpack_het(h, node_types, rels, 0)
     finally:
         lib().orc_het_free(C.c_void_p(h))

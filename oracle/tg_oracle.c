@@ -257,8 +257,13 @@ static int64_t orc_sample_vertex(orc_ctx *c, const orc_ns_cfg *cfg, orc_sampler_
         cnt = orc_reservoir_weighted(c, id, n, k, st->cw, st->dst);
         if (cnt < 0) return -1;
         break;
-    default:
-        cnt = orc_reservoir(c, id, 0, n, k, st->dst, st->scratch, cfg->reservoir_algo);
+    default: {
+        /* philox-mode spec: a filter forces a scan of the column anyway, so the per-item form is used
+         * there (one pass); without a filter the k-draw ticket form (same law) */
+        int algo = cfg->reservoir_algo;
+        if (algo == ORC_RES_AUTO) algo = (cfg->filter_mode != ORC_FILTER_NONE) ? ORC_RES_LITERAL : ORC_RES_TICKETS;
+        cnt = orc_reservoir(c, id, 0, n, k, st->dst, st->scratch, algo);
+    }
     }
     for (int64_t s = 0; s < cnt; s++) out_eptr[s] = need_list ? st->cand[st->dst[s]] : b + st->dst[s];
     return cnt;
@@ -541,14 +546,16 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
                 }
             }
             int64_t pos, scratch[2];
-            int64_t success = orc_reservoir(&c, (uint64_t)i, (uint32_t)l, cn.n, 1, &pos, scratch, reservoir_algo);
+            const uint64_t step_id = (uint64_t)i * (uint64_t)L + (uint64_t)l; /* philox address of this step */
+            int algo = reservoir_algo == ORC_RES_AUTO ? ORC_RES_LITERAL : reservoir_algo;
+            int64_t success = orc_reservoir(&c, step_id, 0, cn.n, 1, &pos, scratch, algo);
             int64_t next, next_t;
             if (success == 0) { /* :144-148 restart from an earlier position */
                 uint64_t rr;
                 if (rng->mode == ORC_RNG_REF)
                     rr = orc_ref_gen_range_u64(rng, (uint64_t)(l + 1));
                 else
-                    rr = orc_bounded(orc_ctx_draw(&c, (uint64_t)i, (uint32_t)l, 0x52535400u).a, (uint64_t)(l + 1));
+                    rr = orc_bounded(orc_ctx_draw(&c, step_id, 0, 0x52535400u).a, (uint64_t)(l + 1));
                 next_t = walks_ts[i * L + (int64_t)rr];
                 next = walks[i * L + (int64_t)rr];
             } else {
@@ -667,8 +674,9 @@ ORC_API orc_het_out *orc_neg_hetero(int32_t T, int32_t R, const int32_t *rel_src
                                     const int64_t *const *ptrs, const int64_t *const *indices, const int64_t *sizes,
                                     const int64_t *const *inputs, const int64_t *n_inputs, const int32_t *has_input,
                                     int64_t num_neg, int64_t try_count, int32_t inbound, orc_rng *rng,
-                                    int64_t *sample_count) {
+                                    int64_t *sample_count, int32_t *status) {
     orc_het_out *o = het_alloc(T, R, 0);
+    *status = 0;
     imap *maps = (imap *)calloc((size_t)T, sizeof(imap));
     for (int t = 0; t < T; t++) { /* :77-91 */
         imap_init(&maps[t], 64);
@@ -706,6 +714,10 @@ ORC_API orc_het_out *orc_neg_hetero(int32_t T, int32_t R, const int32_t *rel_src
                     else
                         w = (int64_t)orc_bounded(orc_ctx_draw(&c, (uint64_t)i, (uint32_t)jn, (uint32_t)tr).a,
                                                  (uint64_t)node_count);
+                    if (inbound && w >= sizes[r * 2 + 0]) { /* :113 indexes ptrs[w]: the reference panics */
+                        *status = -1;
+                        break;
+                    }
                     int he = inbound ? orc_has_edge(ptrs[r], indices[r], w, v)
                                      : orc_has_edge(ptrs[r], indices[r], v, w); /* :112-115 */
                     if (!he && v != w) { /* :117 */

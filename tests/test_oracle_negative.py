@@ -38,6 +38,9 @@ def test_negative_heterogeneous(mode, inbound):
     """negative_sampling.rs:173-233: 3 negatives, 10 tries."""
     counts, edges = load_fake_hetero()
     node_types, edge_types = sorted(counts), sorted(edges)
+    if inbound:   # has_edge(w, v) indexes the src->dst CSR by a dst id: only defined when |dst| <= |src|
+        edge_types = [e for e in edge_types if counts[e[2]] <= counts[e[0]]]
+        node_types = sorted({e[0] for e in edge_types} | {e[2] for e in edge_types})
     P, I, S = {}, {}, {}
     for et in edge_types:
         p, i, _ = orc.to_csr(edges[et], (counts[et[0]], counts[et[2]]))
@@ -60,4 +63,14 @@ def test_negative_heterogeneous(mode, inbound):
             else:
                 assert not has_edge(P[r], I[r], v, w)
             assert v != w
-    assert total > 3 * 20 * 3 * 0.9
+    assert total > len(node_types) * 20 * 3 * 0.9
+
+
+def test_negative_heterogeneous_inbound_out_of_range_is_the_reference_panic():
+    counts, edges = load_fake_hetero()
+    et = ("v0", "e0", "v2")      # 897 src rows, 982 dst nodes: w can exceed the CSR's row count
+    p, i, _ = orc.to_csr(edges[et], (counts["v0"], counts["v2"]))
+    with pytest.raises(RuntimeError):
+        orc.neg_hetero(["v0", "v2"], [et], {rel_key(et): p}, {rel_key(et): i},
+                       {rel_key(et): (counts["v0"], counts["v2"])}, {"v0": np.arange(200)}, 5, 5, True,
+                       orc.rng_philox(1))
