@@ -1,10 +1,317 @@
-// neighbor_sampling_homogenous with a temporal filter and/or the weighted
-// sampler: every candidate edge must be inspected (timestamps / weights), so
-// the work shape is one wavefront per frontier vertex streaming its column.
+// neighbor_sampling_homogenous with a TemporalFilter and/or the WeightedSampler
+// (reference: src/algo/neighbor_sampling.rs:36-77 filter, :131-158 weighted
+// sampler, src/utils/sampling.rs:6-55).  Every candidate edge has to be looked at
+// (its timestamp / weight), so the work shape differs from ns_homo.hip:
+//
+//   P1  one WAVEFRONT per frontier vertex streams its column once, coalesced:
+//       lanes test the filter, ballot + popcount give each admissible edge its
+//       rank in the reference's candidate order, and the reservoir is resolved
+//       from one addressed Philox draw per candidate beyond the first k (the
+//       per-item form of the reference loop; for weights this IS the reference
+//       algorithm, with its left-to-right running sum kept exactly).  The <=k
+//       chosen edge pointers are parked at a fixed stride in the batch's `rows`
+//       slab (free until the hop's rows are written, -1 padded).
+//   P2  as in ns_homo.hip: lane = vertex, counts -> LDS scan -> output-ordered
+//       LDS staging -> coalesced gather + write of samples / cols / edge_index
+//       (+ the filter state of the new sample).
+//   P3  rows[e] = n_seeds + e for the hop (the parked pointers are consumed).
+// HBM-bound on 8 B (timestamp) [+ 8 B (weight)] per inspected edge.
 #include "tg_device.h"
 #include "tg_host.h"
 
-int tg_ns_homo_filtered_launch(const tg_graph *, const int64_t *, int64_t, int64_t, const int64_t *, int32_t,
-                               const tg_ns_config *, const tg_rng *, const tg_ns_out *, hipStream_t) {
-    return tg::fail(TG_ERR_UNSUPPORTED, "tg_ns_homo_batched: filtered / weighted sampling not built yet");
+namespace tg {
+
+constexpr int NSS_CHUNKS_PER_ROUND = 1024;
+
+struct NsScanParams {
+    const int64_t *ptrs;
+    const int64_t *indices;
+    const double *weights;
+    const int64_t *timestamps;
+    const int64_t *seeds;
+    const int64_t *seeds_state;
+    int64_t n_seeds;
+    int32_t n_hops, kmax;
+    int32_t fanout[TG_MAX_HOPS];
+    int32_t sampler, filter_mode, forward;
+    int64_t win_lo, win_hi;
+    int64_t cap_nodes, cap_edges;
+    int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts, *states;
+    uint64_t seed, call_id;
+};
+
+__host__ __device__ inline size_t nss_wave_lds_bytes(int kmax) {
+    // slot_ptr[k] i64 | tgt[k] i64 | slot_rank[k] u32 (padded) | ebuf[64*k] i64 | elane[64*k] u8 (padded)
+    return (size_t)kmax * 8 * 2 + (((size_t)kmax * 4 + 15) & ~(size_t)15) + (size_t)64 * kmax * 8 +
+           (((size_t)64 * kmax + 15) & ~(size_t)15);
+}
+__host__ __device__ inline size_t nss_block_lds_bytes(int kmax, int n_waves) {
+    return (((size_t)(NSS_CHUNKS_PER_ROUND + 1) * 4 + 15) & ~(size_t)15) + (size_t)n_waves * nss_wave_lds_bytes(kmax);
+}
+
+// neighbor_sampling.rs:55-67
+__device__ __forceinline__ bool filter_pass(const NsScanParams &p, int64_t state, int64_t e) {
+    if (p.filter_mode == TG_FILTER_NONE) return true;
+    const int64_t t = p.timestamps[e];
+    int64_t x;
+    if (p.filter_mode == TG_FILTER_STATIC)
+        x = t;
+    else
+        x = p.forward ? (t - state) : -(t - state);
+    return p.win_lo <= x && x <= p.win_hi;
+}
+
+// serial (left-to-right) inclusive prefix of one f64 per lane, starting from `carry`:
+// keeps the reference's summation order of sampling.rs:40,48 bit for bit
+__device__ __forceinline__ double wave_serial_prefix(double v, double carry, double *total) {
+    const int lane = lane_id();
+    double running = carry, mine = 0.0;
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) {
+        running = running + __shfl(v, l, 64);
+        if (lane == l) mine = running;
+    }
+    *total = running;
+    return mine;
+}
+
+__global__ void ns_homo_scan_kernel(const NsScanParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int64_t b = blockIdx.x;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
+    unsigned char *wbase = smem + ((((size_t)(NSS_CHUNKS_PER_ROUND + 1) * 4) + 15) & ~(size_t)15) +
+                           (size_t)wave * nss_wave_lds_bytes(p.kmax);
+    int64_t *slot_ptr = reinterpret_cast<int64_t *>(wbase);
+    int64_t *tgt = slot_ptr + p.kmax;
+    uint32_t *slot_rank = reinterpret_cast<uint32_t *>(tgt + p.kmax);
+    int64_t *ebuf = reinterpret_cast<int64_t *>(wbase + (size_t)p.kmax * 16 + (((size_t)p.kmax * 4 + 15) & ~(size_t)15));
+    uint8_t *elane = reinterpret_cast<uint8_t *>(ebuf + (size_t)64 * p.kmax);
+
+    int64_t *samples = p.samples + b * p.cap_nodes;
+    int64_t *rows = p.rows + b * p.cap_edges;
+    int64_t *cols = p.cols + b * p.cap_edges;
+    int64_t *eidx = p.edge_index + b * p.cap_edges;
+    const bool has_state = p.filter_mode != TG_FILTER_NONE;
+    int64_t *states = has_state ? p.states + b * p.cap_nodes : nullptr;
+    const int64_t n_seeds = p.n_seeds;
+
+    for (int64_t i = tid; i < n_seeds; i += blockDim.x) {
+        samples[i] = p.seeds[b * n_seeds + i];
+        if (has_state) states[i] = p.seeds_state[b * n_seeds + i];
+    }
+    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, TAG_NS_HOMO);
+    __shared__ int panic_flag; // the reference panics (empty float range) -- reported through counts
+    if (tid == 0) panic_flag = 0;
+    __syncthreads();
+
+    int64_t begin = 0, end = n_seeds, ne = 0;
+    for (int h = 0; h < p.n_hops; ++h) {
+        const int k = p.fanout[h];
+        if (tid == 0) {
+            int64_t *lo = p.layer_offsets + (b * p.n_hops + h) * 3;
+            lo[0] = n_seeds + ne;
+            lo[1] = ne;
+            lo[2] = n_seeds + ne;
+        }
+        int64_t *park = rows + ne; // (end-begin)*k entries, free until P3
+        const int64_t hop_ne0 = ne;
+
+        // ================= P1: one wavefront per frontier vertex
+        for (int64_t i = begin + wave; i < end; i += n_waves) {
+            const int64_t w = samples[i];
+            const int64_t st = has_state ? states[i] : 0;
+            const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
+            uint32_t n = 0; // admissible candidates seen so far
+            if (lane < k) slot_rank[lane] = 0;
+            wave_lds_handoff();
+            if (p.sampler == TG_SAMPLER_UNIFORM_REPL) {
+                // sampling.rs:57-69 needs the candidate count first, then k draws, then a second pass to
+                // turn candidate ranks into edge pointers
+                for (int64_t base = e0; base < e1; base += 64) {
+                    const int64_t e = base + lane;
+                    n += (uint32_t)__popcll(__ballot(e < e1 && filter_pass(p, st, e)));
+                }
+                if (n > 0) {
+                    if (lane < k) {
+                        const Draw d = draw(ck, (uint64_t)i, (uint32_t)(lane >> 1), D1_REPLACE);
+                        tgt[lane] = (int64_t)bounded64(d.half(lane & 1), (uint64_t)n);
+                    }
+                    wave_lds_handoff();
+                    uint32_t seen = 0;
+                    for (int64_t base = e0; base < e1; base += 64) {
+                        const int64_t e = base + lane;
+                        const bool ok = e < e1 && filter_pass(p, st, e);
+                        const uint64_t mask = __ballot(ok);
+                        if (ok) {
+                            const int64_t rank = seen + (uint32_t)__popcll(mask & lt_mask);
+                            for (int s = 0; s < k; ++s)
+                                if (tgt[s] == rank) slot_ptr[s] = e;
+                        }
+                        seen += (uint32_t)__popcll(mask);
+                    }
+                }
+            } else {
+                double w_sum = 0.0;
+                for (int64_t base = e0; base < e1; base += 64) {
+                    const int64_t e = base + lane;
+                    const bool ok = e < e1 && filter_pass(p, st, e);
+                    const uint64_t mask = __ballot(ok);
+                    const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
+                    uint32_t hit_slot = 0xffffffffu;
+                    if (p.sampler == TG_SAMPLER_WEIGHTED) { // sampling.rs:28-55
+                        const double wv = ok ? p.weights[e] : 0.0;
+                        double tot;
+                        const double pref = wave_serial_prefix(wv, w_sum, &tot);
+                        w_sum = tot;
+                        if (ok && rank >= (uint32_t)k) {
+                            if (!(0.0 < pref)) {
+                                panic_flag = 1;
+                            } else {
+                                const Draw d = draw(ck, (uint64_t)i, rank, D1_WEIGHTED);
+                                const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                                if (j < wv) hit_slot = (uint32_t)bounded64(d.b(), (uint64_t)k);
+                            }
+                        }
+                    } else if (ok && rank >= (uint32_t)k) { // sampling.rs:17-24, one addressed draw per item
+                        const Draw d = draw(ck, (uint64_t)i, rank, D1_LITERAL);
+                        const uint64_t j = bounded64(d.a(), (uint64_t)rank);
+                        if (j < (uint64_t)k) hit_slot = (uint32_t)j;
+                    }
+                    if (ok && rank < (uint32_t)k) slot_ptr[rank] = e; // sampling.rs:12-15 / :37-45
+                    if (hit_slot != 0xffffffffu) atomicMax(&slot_rank[hit_slot], rank);
+                    wave_lds_handoff();
+                    if (hit_slot != 0xffffffffu && slot_rank[hit_slot] == rank) slot_ptr[hit_slot] = e; // last hit wins
+                    wave_lds_handoff();
+                    n += (uint32_t)__popcll(mask);
+                }
+            }
+            wave_lds_handoff();
+            const uint32_t cnt = (p.sampler == TG_SAMPLER_UNIFORM_REPL) ? (n > 0 ? (uint32_t)k : 0u)
+                                                                       : min(n, (uint32_t)k);
+            if (lane < k) park[(i - begin) * k + lane] = ((uint32_t)lane < cnt) ? slot_ptr[lane] : -1;
+            wave_lds_handoff();
+        }
+        __syncthreads();
+
+        // ================= P2: compaction + emit
+        for (int64_t round_begin = begin; round_begin < end; round_begin += (int64_t)NSS_CHUNKS_PER_ROUND * 64) {
+            const int64_t round_end = min(end, round_begin + (int64_t)NSS_CHUNKS_PER_ROUND * 64);
+            const int nc = (int)((round_end - round_begin + 63) >> 6);
+            for (int c = wave; c < nc; c += n_waves) {
+                const int64_t i = round_begin + (int64_t)c * 64 + lane;
+                uint32_t cnt = 0;
+                if (i < round_end)
+                    for (int s = 0; s < k; ++s) cnt += (park[(i - begin) * k + s] >= 0);
+                const uint32_t tot = wave_sum(cnt);
+                if (lane == 0) chunk_off[c] = tot;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t carry = 0;
+                for (int c0 = 0; c0 < nc; c0 += 64) {
+                    const uint32_t v = (c0 + lane < nc) ? chunk_off[c0 + lane] : 0u;
+                    const uint32_t incl = wave_inclusive_scan(v);
+                    if (c0 + lane < nc) chunk_off[c0 + lane] = carry + incl - v;
+                    carry += __shfl(incl, 63, 64);
+                }
+                if (lane == 0) chunk_off[nc] = carry;
+            }
+            __syncthreads();
+            for (int c = wave; c < nc; c += n_waves) {
+                const int64_t i0 = round_begin + (int64_t)c * 64;
+                const int64_t i = i0 + lane;
+                uint32_t cnt = 0;
+                if (i < round_end)
+                    for (int s = 0; s < k; ++s) cnt += (park[(i - begin) * k + s] >= 0);
+                const uint32_t incl = wave_inclusive_scan(cnt);
+                const uint32_t excl = incl - cnt;
+                const uint32_t total = __shfl(incl, 63, 64);
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    ebuf[excl + s] = park[(i - begin) * k + s];
+                    elane[excl + s] = (uint8_t)lane;
+                }
+                wave_lds_handoff();
+                const int64_t e_chunk = ne + (int64_t)chunk_off[c];
+#pragma unroll 2
+                for (uint32_t q = lane; q < total; q += 64) {
+                    const int l = elane[q];
+                    const int64_t ep = ebuf[q];
+                    const int64_t e = e_chunk + q;
+                    samples[n_seeds + e] = p.indices[ep];
+                    cols[e] = i0 + l;
+                    eidx[e] = ep;
+                    if (has_state) // neighbor_sampling.rs:69-76
+                        states[n_seeds + e] = (p.filter_mode == TG_FILTER_DYNAMIC) ? p.timestamps[ep] : states[i0 + l];
+                }
+                wave_lds_handoff();
+            }
+            __syncthreads();
+            ne += chunk_off[nc];
+            __syncthreads();
+        }
+        // ================= P3: rows of this hop (its parked pointers are all consumed)
+        for (int64_t e = hop_ne0 + tid; e < ne; e += blockDim.x) rows[e] = n_seeds + e;
+        __syncthreads();
+        begin = end;
+        end = n_seeds + ne;
+    }
+    if (tid == 0) {
+        p.counts[b * 2 + 0] = panic_flag ? -1 : n_seeds + ne;
+        p.counts[b * 2 + 1] = ne;
+    }
+}
+
+} // namespace tg
+
+int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                               const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                               const tg_ns_out *out, hipStream_t stream) {
+    tg::NsScanParams p;
+    p.ptrs = csc->ptrs;
+    p.indices = csc->indices;
+    p.weights = csc->weights;
+    p.timestamps = csc->timestamps;
+    p.seeds = seeds;
+    p.seeds_state = cfg->seeds_state;
+    p.n_seeds = n_seeds;
+    p.n_hops = n_hops;
+    p.kmax = 1;
+    for (int h = 0; h < TG_MAX_HOPS; ++h) p.fanout[h] = 0;
+    for (int h = 0; h < n_hops; ++h) {
+        TG_REQUIRE(fanout[h] <= 64, "tg_ns_homo_batched: fanout[%d] = %lld exceeds 64 (filtered / weighted path)", h,
+                   (long long)fanout[h]);
+        p.fanout[h] = (int32_t)fanout[h];
+        if (p.fanout[h] > p.kmax) p.kmax = p.fanout[h];
+    }
+    p.sampler = cfg->sampler;
+    p.filter_mode = cfg->filter_mode;
+    p.forward = cfg->forward;
+    p.win_lo = cfg->win_lo;
+    p.win_hi = cfg->win_hi;
+    TG_REQUIRE(p.sampler != TG_SAMPLER_WEIGHTED || csc->weights, "tg_ns_homo_batched: weighted sampler without weights");
+    if (p.filter_mode != TG_FILTER_NONE) {
+        TG_REQUIRE(csc->timestamps, "tg_ns_homo_batched: temporal filter without edge timestamps");
+        TG_REQUIRE(cfg->seeds_state || n_seeds == 0, "tg_ns_homo_batched: temporal filter without seeds_state");
+        TG_REQUIRE(out->states, "tg_ns_homo_batched: temporal filter needs the `states` workspace");
+    }
+    p.cap_nodes = out->cap_nodes;
+    p.cap_edges = out->cap_edges;
+    p.samples = out->samples;
+    p.rows = out->rows;
+    p.cols = out->cols;
+    p.edge_index = out->edge_index;
+    p.layer_offsets = out->layer_offsets;
+    p.counts = out->counts;
+    p.states = out->states;
+    p.seed = rng->seed;
+    p.call_id = rng->call_id;
+    int threads = (n_batches < 256) ? 1024 : 256;
+    while (threads > 64 && tg::nss_block_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads >>= 1;
+    const size_t lds = tg::nss_block_lds_bytes(p.kmax, threads / 64);
+    hipLaunchKernelGGL(tg::ns_homo_scan_kernel, dim3((unsigned)n_batches), dim3(threads), lds, stream, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
 }
