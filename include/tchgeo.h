@@ -71,10 +71,15 @@ typedef struct {
     int32_t sampler;     /* TG_SAMPLER_* */
     int32_t filter_mode; /* TG_FILTER_* */
     int32_t forward;     /* TemporalFilter FORWARD */
-    int32_t _reserved;
+    uint32_t rng_tag;    /* operator tag of the draw address; 0 = the homogeneous default.  The heterogeneous
+                            sampler runs one relation-hop at a time with TG_TAG_NS_HETERO | relation << 8 */
     int64_t win_lo, win_hi;       /* inclusive window (python.rs:150) */
     const int64_t *seeds_state;   /* [n_batches * n_seeds] initial filter state, or NULL */
+    int64_t id_base;              /* draw id of slot i is id_base + i (slot of the vertex in its sample list) */
 } tg_ns_config;
+
+#define TG_TAG_NS_HOMO 1u
+#define TG_TAG_NS_HETERO 2u
 
 /* Per-batch output slabs of neighbor_sampling_homogenous.  Batch b owns
  * samples[b*cap_nodes ..], rows/cols/edge_index[b*cap_edges ..],

@@ -40,6 +40,8 @@ struct NsHomoParams {
     int64_t cap_nodes, cap_edges;
     int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts;
     uint64_t seed, call_id;
+    uint32_t tag;
+    int64_t id_base;
 };
 
 __host__ __device__ inline size_t ns_wave_lds_bytes(int kmax) {
@@ -101,7 +103,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
     const int64_t n_seeds = p.n_seeds;
 
     for (int64_t i = tid; i < n_seeds; i += blockDim.x) samples[i] = p.seeds[b * n_seeds + i]; // :184
-    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, TAG_NS_HOMO);
+    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
     __syncthreads();
 
     int64_t begin = 0, end = n_seeds; // frontier = samples[begin, end)   (:187)
@@ -163,7 +165,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                     if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
                         Draw d;
                         for (int s = 0; s < k; ++s) {
-                            if ((s & 1) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 1), D1_REPLACE);
+                            if ((s & 1) == 0) d = draw(ck, (uint64_t)(p.id_base + i), (uint32_t)(s >> 1), D1_REPLACE);
                             spos[excl + s] = bounded32(d.half(s & 1), n);
                             slane[excl + s] = (uint8_t)lane;
                         }
@@ -173,7 +175,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                             slane[excl + s] = (uint8_t)lane;
                         }
                     } else {
-                        sample_tickets<KMAX>(ck, (uint64_t)i, n, k, spos, slane, excl, lane);
+                        sample_tickets<KMAX>(ck, (uint64_t)(p.id_base + i), n, k, spos, slane, excl, lane);
                     }
                 }
                 wave_lds_handoff();
@@ -294,6 +296,8 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     p.counts = out->counts;
     p.seed = rng->seed;
     p.call_id = rng->call_id;
+    p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
+    p.id_base = cfg ? cfg->id_base : 0;
     hipStream_t s = (hipStream_t)stream;
     const bool repl = sampler == TG_SAMPLER_UNIFORM_REPL;
     if (p.kmax <= 16)

@@ -38,6 +38,8 @@ struct NsScanParams {
     int64_t cap_nodes, cap_edges;
     int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts, *states;
     uint64_t seed, call_id;
+    uint32_t tag;
+    int64_t id_base;
 };
 
 __host__ __device__ inline size_t nss_wave_lds_bytes(int kmax) {
@@ -102,7 +104,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
         samples[i] = p.seeds[b * n_seeds + i];
         if (has_state) states[i] = p.seeds_state[b * n_seeds + i];
     }
-    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, TAG_NS_HOMO);
+    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
     __shared__ int panic_flag; // the reference panics (empty float range) -- reported through counts
     if (tid == 0) panic_flag = 0;
     __syncthreads();
@@ -136,7 +138,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                 }
                 if (n > 0) {
                     if (lane < k) {
-                        const Draw d = draw(ck, (uint64_t)i, (uint32_t)(lane >> 1), D1_REPLACE);
+                        const Draw d = draw(ck, (uint64_t)(p.id_base + i), (uint32_t)(lane >> 1), D1_REPLACE);
                         tgt[lane] = (int64_t)bounded64(d.half(lane & 1), (uint64_t)n);
                     }
                     wave_lds_handoff();
@@ -170,13 +172,13 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                             if (!(0.0 < pref)) {
                                 panic_flag = 1;
                             } else {
-                                const Draw d = draw(ck, (uint64_t)i, rank, D1_WEIGHTED);
+                                const Draw d = draw(ck, (uint64_t)(p.id_base + i), rank, D1_WEIGHTED);
                                 const double j = u64_to_f64_01(d.a()) * pref + 0.0;
                                 if (j < wv) hit_slot = (uint32_t)bounded64(d.b(), (uint64_t)k);
                             }
                         }
                     } else if (ok && rank >= (uint32_t)k) { // sampling.rs:17-24, one addressed draw per item
-                        const Draw d = draw(ck, (uint64_t)i, rank, D1_LITERAL);
+                        const Draw d = draw(ck, (uint64_t)(p.id_base + i), rank, D1_LITERAL);
                         const uint64_t j = bounded64(d.a(), (uint64_t)rank);
                         if (j < (uint64_t)k) hit_slot = (uint32_t)j;
                     }
@@ -308,6 +310,8 @@ int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_
     p.states = out->states;
     p.seed = rng->seed;
     p.call_id = rng->call_id;
+    p.tag = cfg->rng_tag ? cfg->rng_tag : TG_TAG_NS_HOMO;
+    p.id_base = cfg->id_base;
     int threads = (n_batches < 256) ? 1024 : 256;
     while (threads > 64 && tg::nss_block_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads >>= 1;
     const size_t lds = tg::nss_block_lds_bytes(p.kmax, threads / 64);

@@ -1,0 +1,509 @@
+// Host side of the MI355X backend: the CPython module `tch_geometric.tch_geometric`.
+//
+// Mirrors the reference's PyO3 module (src/python.rs:785-803): same function
+// names, positional order, duck-typed sampler / filter arguments
+// (python.rs:107-168), return tuples and ValueError behaviour
+// (src/utils/tensor.rs:11-45).  The reference's host is Rust; no Rust toolchain
+// exists in this pipeline, so the host is C++ (pybind11).  It owns nothing but
+// argument handling and buffer allocation: every sampler runs in the gfx950
+// library behind include/tchgeo.h -- there is no CPU path here.
+//
+// Device rule (relaxed from the reference's "must be on Cpu", tensor.rs:50-52):
+// tensors may live on a HIP device (adjacency stays resident in HBM, zero copy)
+// or on the CPU (uploaded for the call); results come back on the device of
+// the `inputs` / `start` tensor.
+//
+// Randomness: the reference draws from a process-global SmallRng seeded from
+// entropy that Python cannot reseed (utils/random.rs:8-22).  Here the global
+// state is (seed, call counter); `seed(s)` (additive to the surface) makes
+// results reproducible, and equal to the CPU oracle's philox-mode.
+#include <torch/extension.h>
+
+#include <atomic>
+#include <mutex>
+#include <random>
+#include <sstream>
+
+#include "../../include/tchgeo.h"
+
+namespace py = pybind11;
+using at::Tensor;
+
+namespace {
+
+// ---------------------------------------------------------------- global RNG state
+std::mutex g_rng_mu;
+uint64_t g_seed = [] {
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}();
+uint64_t g_call = 0;
+
+tg_rng next_rng() { // one call id per operator call (utils/random.rs:19-22 derives one child rng per call)
+    std::lock_guard<std::mutex> lk(g_rng_mu);
+    tg_rng r{g_seed, g_call};
+    g_call += 1;
+    return r;
+}
+
+// ---------------------------------------------------------------- errors (utils/tensor.rs:11-27)
+const char *kind_name(at::ScalarType t) {
+    switch (t) {
+    case at::kLong: return "Int64";
+    case at::kInt: return "Int";
+    case at::kShort: return "Int16";
+    case at::kChar: return "Int8";
+    case at::kByte: return "Uint8";
+    case at::kBool: return "Bool";
+    case at::kDouble: return "Double";
+    case at::kFloat: return "Float";
+    case at::kHalf: return "Half";
+    case at::kBFloat16: return "BFloat16";
+    default: return "Unknown";
+    }
+}
+void check_kind(const Tensor &t, at::ScalarType want) {
+    if (t.scalar_type() != want) {
+        std::ostringstream os;
+        os << "Tensor must be a is of invalid type. Expected " << kind_name(want) << " but got "
+           << kind_name(t.scalar_type());
+        throw py::value_error(os.str());
+    }
+}
+void check_rc(int rc) {
+    if (rc == TG_OK) return;
+    std::string msg = std::string("tchgeo: ") + tg_last_error();
+    if (rc == TG_ERR_INVALID) throw py::value_error(msg);
+    throw std::runtime_error(msg);
+}
+
+// ---------------------------------------------------------------- devices and streams
+c10::Device compute_device(std::initializer_list<const Tensor *> ts) {
+    for (const Tensor *t : ts)
+        if (t && t->defined() && t->is_cuda()) return t->device();
+    py::object cuda = py::module_::import("torch").attr("cuda");
+    if (!cuda.attr("is_available")().cast<bool>())
+        throw std::runtime_error("tch_geometric (MI355X backend): no HIP device is visible and this build has no CPU "
+                                 "path");
+    return c10::Device(c10::kCUDA, (c10::DeviceIndex)cuda.attr("current_device")().cast<int>());
+}
+void *stream_of(const c10::Device &dev) {
+    py::object s = py::module_::import("torch").attr("cuda").attr("current_stream")(py::int_((int)dev.index()));
+    return reinterpret_cast<void *>(s.attr("cuda_stream").cast<uintptr_t>());
+}
+struct DeviceGuard { // run the call with `dev` current (kernels launch on the current device)
+    py::object ctx;
+    explicit DeviceGuard(const c10::Device &dev) {
+        ctx = py::module_::import("torch").attr("cuda").attr("device")(py::int_((int)dev.index()));
+        ctx.attr("__enter__")();
+    }
+    ~DeviceGuard() { ctx.attr("__exit__")(py::none(), py::none(), py::none()); }
+};
+Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
+    check_kind(t, want);
+    return t.to(dev).contiguous(); // tensor_to_slice assumes contiguity (utils/tensor.rs:57-59)
+}
+Tensor back(const Tensor &t, const c10::Device &out_dev) { return t.device() == out_dev ? t : t.to(out_dev); }
+at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions().dtype(at::kLong).device(dev); }
+
+std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257
+    return std::get<0>(e) + "__" + std::get<1>(e) + "__" + std::get<2>(e);
+}
+
+// ---------------------------------------------------------------- sampler / filter extraction (python.rs:107-168)
+struct SamplerArg {
+    int kind = TG_SAMPLER_UNIFORM; // python.rs:215 default
+    py::object weights;            // Tensor (homogeneous) or dict[str, Tensor]
+};
+SamplerArg parse_sampler(const py::object &o) {
+    SamplerArg s;
+    if (o.is_none()) return s;
+    if (py::hasattr(o, "with_replacement")) { // tried first, python.rs:132-135
+        s.kind = o.attr("with_replacement").cast<bool>() ? TG_SAMPLER_UNIFORM_REPL : TG_SAMPLER_UNIFORM;
+    } else if (py::hasattr(o, "weights")) {
+        s.kind = TG_SAMPLER_WEIGHTED;
+        s.weights = o.attr("weights");
+    } else {
+        throw py::type_error("sampler must expose `.with_replacement` or `.weights`");
+    }
+    return s;
+}
+struct FilterArg {
+    int mode = TG_FILTER_NONE;
+    bool forward = false;
+    int64_t win_lo = 0, win_hi = 0;
+    py::object timestamps; // Tensor or dict
+    py::object state;      // Tensor or dict
+};
+FilterArg parse_filter(const py::object &o) {
+    FilterArg f;
+    if (o.is_none()) return f;
+    py::tuple t = o.cast<py::tuple>();
+    if (t.size() != 2) throw py::type_error("filter must be a (TemporalEdgeFilter, initial_state) tuple");
+    py::object ft = t[0];
+    auto window = ft.attr("window").cast<std::pair<int64_t, int64_t>>();
+    const int64_t mode = ft.attr("mode").cast<int64_t>();
+    f.forward = ft.attr("forward").cast<bool>();
+    if (mode < 0 || mode > 2) return f; // python.rs:249: any other mode falls through to IdentityFilter
+    f.mode = (int)mode;
+    if (mode == TG_FILTER_STATIC) f.forward = true; // python.rs:219-224 builds <true, STATIC> for both
+    f.win_lo = window.first;
+    f.win_hi = window.second;
+    f.timestamps = ft.attr("timestamps");
+    f.state = t[1];
+    return f;
+}
+Tensor as_homogeneous(const py::object &o) { // MixedData::build_homogenous python.rs:86-92
+    if (py::isinstance<py::dict>(o)) throw py::value_error("Unknown error: \"data must be homogenous\"");
+    return o.cast<Tensor>();
+}
+Tensor from_dict(const py::object &o, const std::string &key) { // MixedData::build_heterogenous python.rs:94-104
+    if (!py::isinstance<py::dict>(o)) throw py::value_error("Unknown error: \"data must be heterogenous\"");
+    py::dict d = o.cast<py::dict>();
+    if (!d.contains(py::str(key))) throw py::key_error(key);
+    return d[py::str(key)].cast<Tensor>();
+}
+
+// ---------------------------------------------------------------- one batched launch of the neighbor sampler
+struct NsResult {
+    Tensor samples, rows, cols, edge_index, states;
+    std::vector<std::tuple<int64_t, int64_t, int64_t>> layer_offsets;
+    int64_t n_samples = 0, n_edges = 0;
+};
+NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indices, const Tensor &weights,
+                const Tensor &timestamps, const Tensor &seeds, const Tensor &seeds_state,
+                const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f, const tg_rng &rng,
+                uint32_t tag, int64_t id_base) {
+    const int32_t H = (int32_t)fanout.size();
+    int64_t cap_nodes = 0, cap_edges = 0;
+    check_rc(tg_ns_homo_capacity(seeds.numel(), fanout.data(), H, &cap_nodes, &cap_edges));
+    NsResult r;
+    r.samples = at::empty({std::max<int64_t>(cap_nodes, 1)}, i64(dev));
+    r.rows = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
+    r.cols = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
+    r.edge_index = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
+    Tensor lo = at::zeros({std::max<int32_t>(H, 1) * 3}, i64(dev));
+    Tensor counts = at::zeros({2}, i64(dev));
+    if (f.mode != TG_FILTER_NONE) r.states = at::empty({std::max<int64_t>(cap_nodes, 1)}, i64(dev));
+
+    tg_graph g{};
+    g.ptrs = ptrs.data_ptr<int64_t>();
+    g.indices = indices.data_ptr<int64_t>();
+    g.weights = weights.defined() ? weights.data_ptr<double>() : nullptr;
+    g.timestamps = timestamps.defined() ? timestamps.data_ptr<int64_t>() : nullptr;
+    g.n_major = ptrs.numel() - 1;
+    g.n_edges = indices.numel();
+    tg_ns_config cfg{};
+    cfg.sampler = s.kind;
+    cfg.filter_mode = f.mode;
+    cfg.forward = f.forward ? 1 : 0;
+    cfg.rng_tag = tag;
+    cfg.win_lo = f.win_lo;
+    cfg.win_hi = f.win_hi;
+    cfg.seeds_state = seeds_state.defined() ? seeds_state.data_ptr<int64_t>() : nullptr;
+    cfg.id_base = id_base;
+    tg_ns_out out{};
+    out.samples = r.samples.data_ptr<int64_t>();
+    out.rows = r.rows.data_ptr<int64_t>();
+    out.cols = r.cols.data_ptr<int64_t>();
+    out.edge_index = r.edge_index.data_ptr<int64_t>();
+    out.layer_offsets = lo.data_ptr<int64_t>();
+    out.counts = counts.data_ptr<int64_t>();
+    out.states = r.states.defined() ? r.states.data_ptr<int64_t>() : nullptr;
+    out.cap_nodes = r.samples.numel();
+    out.cap_edges = r.rows.numel();
+    check_rc(tg_ns_homo_batched(&g, seeds.numel() ? seeds.data_ptr<int64_t>() : nullptr, 1, seeds.numel(),
+                                fanout.data(), H, &cfg, &rng, &out, stream_of(dev)));
+    Tensor c = counts.cpu(), l = lo.cpu(); // the only synchronisation of the call
+    r.n_samples = c[0].item<int64_t>();
+    r.n_edges = c[1].item<int64_t>();
+    if (r.n_samples < 0) // sampling.rs:49: gen_range over an empty float range panics in the reference
+        throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+    for (int h = 0; h < H; ++h)
+        r.layer_offsets.emplace_back(l[3 * h].item<int64_t>(), l[3 * h + 1].item<int64_t>(),
+                                     l[3 * h + 2].item<int64_t>());
+    return r;
+}
+
+void validate_fanout(const std::vector<int64_t> &f) {
+    for (int64_t k : f)
+        if (k < 1) throw py::value_error("num_neighbors entries must be >= 1 (the reference panics on 0)");
+}
+
+// ---------------------------------------------------------------- python.rs:27-53 to_csc / to_csr
+std::tuple<int64_t, int64_t> graph_size(const py::object &size) { // GraphSize python.rs:12-25
+    if (py::isinstance<py::int_>(size)) {
+        const int64_t n = size.cast<int64_t>();
+        return {n, n};
+    }
+    auto p = size.cast<std::pair<int64_t, int64_t>>();
+    return {p.first, p.second};
+}
+std::tuple<Tensor, Tensor, Tensor> to_csx(const Tensor &row_col, const py::object &size, bool csc) {
+    auto [size0, size1] = graph_size(size);
+    const c10::Device dev = compute_device({&row_col});
+    DeviceGuard guard(dev);
+    Tensor rc = on(row_col, dev, at::kLong);
+    Tensor row = rc.select(0, 0), col = rc.select(0, 1);
+    // storage.rs:112,119: perm = argsort(major * size_minor + minor); stable, so duplicate edges keep input order
+    Tensor key = csc ? col * size0 + row : row * size1 + col;
+    Tensor perm = std::get<1>(at::sort(key, /*stable=*/true, /*dim=*/0, /*descending=*/false));
+    Tensor major = (csc ? col : row).index_select(0, perm).contiguous();
+    Tensor indices = (csc ? row : col).index_select(0, perm).contiguous();
+    const int64_t m = csc ? size1 : size0;
+    Tensor ptrs = at::empty({m + 1}, i64(dev));
+    check_rc(tg_ind2ptr(major.numel() ? major.data_ptr<int64_t>() : nullptr, major.numel(), m,
+                        ptrs.data_ptr<int64_t>(), stream_of(dev)));
+    const c10::Device out_dev = row_col.device();
+    return {back(ptrs, out_dev), back(indices, out_dev), back(perm, out_dev)};
+}
+
+// ---------------------------------------------------------------- python.rs:187-271
+py::tuple neighbor_sampling_homogenous(const Tensor &col_ptrs, const Tensor &row_indices, const Tensor &inputs,
+                                       const std::vector<int64_t> &num_neighbors, const py::object &sampler,
+                                       const py::object &filter) {
+    const SamplerArg s = parse_sampler(sampler);
+    const FilterArg f = parse_filter(filter);
+    validate_fanout(num_neighbors);
+    const c10::Device dev = compute_device({&col_ptrs, &row_indices, &inputs});
+    DeviceGuard guard(dev);
+    Tensor ptrs = on(col_ptrs, dev, at::kLong), idx = on(row_indices, dev, at::kLong);
+    Tensor seeds = on(inputs, dev, at::kLong).reshape({-1});
+    Tensor w, ts, st;
+    if (s.kind == TG_SAMPLER_WEIGHTED) w = on(as_homogeneous(s.weights), dev, at::kDouble); // python.rs:214
+    if (f.mode != TG_FILTER_NONE) {
+        ts = on(as_homogeneous(f.timestamps), dev, at::kLong); // python.rs:149
+        st = on(as_homogeneous(f.state), dev, at::kLong).reshape({-1});
+        if (st.numel() != seeds.numel()) throw py::value_error("filter state must have one entry per input");
+    }
+    NsResult r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0);
+    const c10::Device out_dev = inputs.device();
+    return py::make_tuple(back(r.samples.narrow(0, 0, r.n_samples), out_dev),
+                          back(r.rows.narrow(0, 0, r.n_edges), out_dev), back(r.cols.narrow(0, 0, r.n_edges), out_dev),
+                          back(r.edge_index.narrow(0, 0, r.n_edges), out_dev), r.layer_offsets);
+}
+
+// ---------------------------------------------------------------- python.rs:275-395
+// neighbor_sampling.rs:233-356 driven one (hop, relation) at a time on the device; relations are visited in
+// `edge_types` order (the reference's HashMap order is not reproducible).
+py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_types,
+                                         const std::vector<std::tuple<std::string, std::string, std::string>> &edge_types,
+                                         const py::dict &col_ptrs, const py::dict &row_indices, const py::dict &inputs,
+                                         const py::dict &num_neighbors, int64_t num_hops, const py::object &sampler,
+                                         const py::object &filter) {
+    const SamplerArg s = parse_sampler(sampler);
+    const FilterArg f = parse_filter(filter);
+    const size_t T = node_types.size();
+    std::map<std::string, size_t> tix;
+    for (size_t t = 0; t < T; ++t) tix[node_types[t]] = t;
+
+    const Tensor *first = nullptr;
+    Tensor first_holder;
+    for (auto item : col_ptrs) {
+        first_holder = item.second.cast<Tensor>();
+        first = &first_holder;
+        break;
+    }
+    const c10::Device dev = compute_device({first});
+    DeviceGuard guard(dev);
+    const tg_rng rng = next_rng();
+    const bool has_state = f.mode != TG_FILTER_NONE;
+
+    struct Rel {
+        std::string key;
+        size_t src, dst;
+        Tensor ptrs, idx, w, ts;
+        std::vector<int64_t> fanout;
+        bool active;
+        std::vector<Tensor> rows, cols, eidx;
+        int64_t n_edges = 0;
+        std::vector<std::tuple<int64_t, int64_t, int64_t>> layer_offsets;
+    };
+    std::vector<Rel> rels;
+    for (const auto &et : edge_types) {
+        Rel r;
+        r.key = rel_key(et);
+        if (!col_ptrs.contains(py::str(r.key))) continue; // graphs are keyed by col_ptrs (python.rs:294)
+        r.src = tix.at(std::get<0>(et));
+        r.dst = tix.at(std::get<2>(et));
+        r.ptrs = on(col_ptrs[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
+        r.idx = on(row_indices[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
+        r.active = num_neighbors.contains(py::str(r.key)); // the hop loop iterates num_neighbors (:294)
+        if (r.active) {
+            r.fanout = num_neighbors[py::str(r.key)].cast<std::vector<int64_t>>();
+            validate_fanout(r.fanout);
+            if ((int64_t)r.fanout.size() < num_hops) throw py::index_error("num_neighbors[" + r.key + "] is shorter than num_hops");
+        }
+        if (s.kind == TG_SAMPLER_WEIGHTED) r.w = on(from_dict(s.weights, r.key), dev, at::kDouble);
+        if (has_state) r.ts = on(from_dict(f.timestamps, r.key), dev, at::kLong);
+        rels.push_back(std::move(r));
+    }
+
+    // per node type: every chunk appended so far, the current frontier and its global begin index
+    std::vector<std::vector<Tensor>> chunks(T), st_chunks(T), new_chunks(T), new_st(T);
+    std::vector<Tensor> frontier(T), frontier_st(T);
+    std::vector<int64_t> len(T, 0), fbegin(T, 0);
+    c10::Device out_dev = dev;
+    bool out_dev_set = false;
+    for (size_t t = 0; t < T; ++t) { // :264-278
+        if (inputs.contains(py::str(node_types[t]))) {
+            Tensor in = inputs[py::str(node_types[t])].cast<Tensor>();
+            if (!out_dev_set) {
+                out_dev = in.device();
+                out_dev_set = true;
+            }
+            frontier[t] = on(in, dev, at::kLong).reshape({-1});
+            if (has_state) frontier_st[t] = on(from_dict(f.state, node_types[t]), dev, at::kLong).reshape({-1});
+        } else {
+            frontier[t] = at::empty({0}, i64(dev));
+            if (has_state) frontier_st[t] = at::empty({0}, i64(dev));
+        }
+        chunks[t].push_back(frontier[t]);
+        if (has_state) st_chunks[t].push_back(frontier_st[t]);
+        len[t] = frontier[t].numel();
+    }
+
+    for (int64_t ell = 0; ell < num_hops; ++ell) { // :292
+        for (size_t t = 0; t < T; ++t) {
+            new_chunks[t].clear();
+            new_st[t].clear();
+        }
+        for (size_t ri = 0; ri < rels.size(); ++ri) { // :294, canonical order
+            Rel &r = rels[ri];
+            if (!r.active) continue;
+            r.layer_offsets.emplace_back(len[r.src], r.n_edges, len[r.dst]); // :314-315
+            const Tensor &F = frontier[r.dst];
+            if (F.numel() == 0) continue;
+            NsResult o = run_ns(dev, r.ptrs, r.idx, r.w, r.ts, F, has_state ? frontier_st[r.dst] : Tensor(),
+                                {r.fanout[(size_t)ell]}, s, f, rng, TG_TAG_NS_HETERO | ((uint32_t)ri << 8),
+                                fbegin[r.dst]);
+            const int64_t cnt = o.n_edges, nF = F.numel();
+            if (cnt == 0) continue;
+            Tensor fresh = o.samples.narrow(0, nF, cnt); // :338
+            r.rows.push_back(at::arange(len[r.src], len[r.src] + cnt, i64(dev))); // :335,340 j
+            r.cols.push_back(o.cols.narrow(0, 0, cnt) + fbegin[r.dst]);            // :340 i
+            r.eidx.push_back(o.edge_index.narrow(0, 0, cnt));
+            r.n_edges += cnt;
+            chunks[r.src].push_back(fresh);
+            new_chunks[r.src].push_back(fresh);
+            if (has_state) {
+                Tensor fs = o.states.narrow(0, nF, cnt); // :339
+                st_chunks[r.src].push_back(fs);
+                new_st[r.src].push_back(fs);
+            }
+            len[r.src] += cnt;
+        }
+        for (size_t t = 0; t < T; ++t) { // :345-348
+            fbegin[t] += frontier[t].numel();
+            frontier[t] = new_chunks[t].empty() ? at::empty({0}, i64(dev)) : at::cat(new_chunks[t]);
+            if (has_state) frontier_st[t] = new_st[t].empty() ? at::empty({0}, i64(dev)) : at::cat(new_st[t]);
+        }
+    }
+
+    py::dict samples, rows, cols, eidx, los;
+    for (size_t t = 0; t < T; ++t) samples[py::str(node_types[t])] = back(at::cat(chunks[t]), out_dev);
+    auto cat_or_empty = [&](const std::vector<Tensor> &v) { return v.empty() ? at::empty({0}, i64(dev)) : at::cat(v); };
+    for (Rel &r : rels) {
+        rows[py::str(r.key)] = back(cat_or_empty(r.rows), out_dev);
+        cols[py::str(r.key)] = back(cat_or_empty(r.cols), out_dev);
+        eidx[py::str(r.key)] = back(cat_or_empty(r.eidx), out_dev);
+        los[py::str(r.key)] = r.layer_offsets;
+    }
+    return py::make_tuple(samples, rows, cols, eidx, los);
+}
+
+// ---------------------------------------------------------------- python.rs:584-608
+Tensor random_walk(const Tensor &row_ptrs, const Tensor &col_indices, const Tensor &start, int64_t walk_length, float p,
+                   float q) {
+    const c10::Device dev = compute_device({&row_ptrs, &col_indices, &start});
+    DeviceGuard guard(dev);
+    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
+    Tensor st = on(start, dev, at::kLong).reshape({-1});
+    if (walk_length < 0) throw py::value_error("walk_length must be >= 0");
+    Tensor walks = at::empty({st.numel(), walk_length + 1}, i64(dev));
+    tg_graph g{};
+    g.ptrs = ptrs.data_ptr<int64_t>();
+    g.indices = idx.data_ptr<int64_t>();
+    g.n_major = ptrs.numel() - 1;
+    g.n_edges = idx.numel();
+    const tg_rng rng = next_rng();
+    check_rc(tg_random_walk(&g, st.numel() ? st.data_ptr<int64_t>() : nullptr, st.numel(), walk_length, p, q, &rng,
+                            walks.data_ptr<int64_t>(), stream_of(dev)));
+    return back(walks, start.device()); // random_walk.rs:19-23 allocates on start.device()
+}
+
+// ---------------------------------------------------------------- python.rs:611-642
+std::tuple<Tensor, Tensor> tempo_random_walk(const Tensor &row_ptrs, const Tensor &col_indices,
+                                             const Tensor &node_timestamps, const Tensor &edge_timestamps,
+                                             const Tensor &start, const Tensor &start_timestamps, int64_t walk_length,
+                                             std::pair<int64_t, int64_t> window) {
+    const c10::Device dev = compute_device({&row_ptrs, &col_indices, &start});
+    DeviceGuard guard(dev);
+    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
+    Tensor nts = on(node_timestamps, dev, at::kLong), ets = on(edge_timestamps, dev, at::kLong);
+    Tensor st = on(start, dev, at::kLong).reshape({-1}), sts = on(start_timestamps, dev, at::kLong).reshape({-1});
+    if (walk_length < 0) throw py::value_error("walk_length must be >= 0");
+    if (sts.numel() != st.numel()) throw py::value_error("start_timestamps must have one entry per start node");
+    Tensor walks = at::full({st.numel(), walk_length}, -1, i64(dev));
+    Tensor wts = at::full({st.numel(), walk_length}, -1, i64(dev));
+    tg_graph g{};
+    g.ptrs = ptrs.data_ptr<int64_t>();
+    g.indices = idx.data_ptr<int64_t>();
+    g.n_major = ptrs.numel() - 1;
+    g.n_edges = idx.numel();
+    const tg_rng rng = next_rng();
+    check_rc(tg_tempo_random_walk(&g, nts.data_ptr<int64_t>(), ets.numel() ? ets.data_ptr<int64_t>() : nullptr,
+                                  st.numel() ? st.data_ptr<int64_t>() : nullptr,
+                                  sts.numel() ? sts.data_ptr<int64_t>() : nullptr, st.numel(), walk_length,
+                                  window.first, window.second, &rng, walks.data_ptr<int64_t>(),
+                                  wts.data_ptr<int64_t>(), stream_of(dev)));
+    return {back(walks, start.device()), back(wts, start.device())};
+}
+
+[[noreturn]] void out_of_scope(const char *name) {
+    throw std::runtime_error(std::string(name) + " is outside this backend's scope (SURVEY.md section 8: not on the "
+                                                 "mini-batch construction hot path)");
+}
+
+} // namespace
+
+void register_more(py::module_ &m); // negative sampling + hgt (python_module_more.cpp)
+
+PYBIND11_MODULE(tch_geometric, m) {
+    m.doc() = "MI355X-native backend behind tch-geometric's operator surface (reference: src/python.rs)";
+    // additive: the reference's RNG cannot be seeded from Python (utils/random.rs:14-17 is not exported)
+    m.def("seed", [](uint64_t s) {
+        std::lock_guard<std::mutex> lk(g_rng_mu);
+        g_seed = s;
+        g_call = 0;
+    }, py::arg("seed"), "Seed the global (seed, call counter) state; every operator call consumes one call id.");
+    m.def("rng_state", [] {
+        std::lock_guard<std::mutex> lk(g_rng_mu);
+        return std::make_pair(g_seed, g_call);
+    });
+    m.def("set_rng_state", [](uint64_t s, uint64_t c) {
+        std::lock_guard<std::mutex> lk(g_rng_mu);
+        g_seed = s;
+        g_call = c;
+    });
+    m.def("backend_version", [] { return std::string(tg_version()); });
+
+    m.def("to_csc", [](const Tensor &rc, const py::object &size) { return to_csx(rc, size, true); }, py::arg("row_col"),
+          py::arg("size"));
+    m.def("to_csr", [](const Tensor &rc, const py::object &size) { return to_csx(rc, size, false); },
+          py::arg("row_col"), py::arg("size"));
+    m.def("neighbor_sampling_homogenous", &neighbor_sampling_homogenous, py::arg("col_ptrs"), py::arg("row_indices"),
+          py::arg("inputs"), py::arg("num_neighbors"), py::arg("sampler") = py::none(), py::arg("filter") = py::none());
+    m.def("neighbor_sampling_heterogenous", &neighbor_sampling_heterogenous, py::arg("node_types"),
+          py::arg("edge_types"), py::arg("col_ptrs"), py::arg("row_indices"), py::arg("inputs"),
+          py::arg("num_neighbors"), py::arg("num_hops"), py::arg("sampler") = py::none(),
+          py::arg("filter") = py::none());
+    m.def("random_walk", &random_walk, py::arg("row_ptrs"), py::arg("col_indices"), py::arg("start"),
+          py::arg("walk_length"), py::arg("p"), py::arg("q"));
+    m.def("tempo_random_walk", &tempo_random_walk, py::arg("row_ptrs"), py::arg("col_indices"),
+          py::arg("node_timestamps"), py::arg("edge_timestamps"), py::arg("start"), py::arg("start_timestamps"),
+          py::arg("walk_length"), py::arg("window"));
+    m.def("budget_sampling", [](py::args, py::kwargs) { out_of_scope("budget_sampling"); });
+    m.def("biased_tempo_random_walk", [](py::args, py::kwargs) { out_of_scope("biased_tempo_random_walk"); });
+    register_more(m);
+}

@@ -1,6 +1,12 @@
 """MI355X-native backend behind tch-geometric's operator surface.
 
-Mirrors the reference package layout (tch_geometric/__init__.py:1-2 re-exports the native module)."""
-import torch  # noqa: F401  (the reference imports torch first so libtorch symbols are loaded)
+Same layout as the reference package (tch_geometric/__init__.py:1-2): import torch first so that
+libtorch is loaded, then re-export the native module.  There is no CPU fallback: the import fails if
+the gfx950 library or the host module has not been built (python __graft_entry__.py)."""
+import torch  # noqa: F401
 
-from . import _cabi  # noqa: F401  raises if the gfx950 library is missing -- no CPU fallback
+from . import _cabi  # noqa: F401  (raises if lib/libtchgeo_hip.so is missing)
+from .tch_geometric import *  # noqa: F401,F403
+from .tch_geometric import backend_version, rng_state, seed, set_rng_state  # noqa: F401
+from .utils import (TEMPORAL_SAMPLE_DYNAMIC, TEMPORAL_SAMPLE_RELATIVE, TEMPORAL_SAMPLE_STATIC,  # noqa: F401
+                    TemporalEdgeFilter, UniformEdgeSampler, WeightedEdgeSampler)

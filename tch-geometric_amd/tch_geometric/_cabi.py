@@ -31,8 +31,8 @@ class TgRng(C.Structure):
 
 
 class TgNsConfig(C.Structure):
-    _fields_ = [("sampler", C.c_int32), ("filter_mode", C.c_int32), ("forward", C.c_int32), ("_reserved", C.c_int32),
-                ("win_lo", C.c_int64), ("win_hi", C.c_int64), ("seeds_state", C.c_void_p)]
+    _fields_ = [("sampler", C.c_int32), ("filter_mode", C.c_int32), ("forward", C.c_int32), ("rng_tag", C.c_uint32),
+                ("win_lo", C.c_int64), ("win_hi", C.c_int64), ("seeds_state", C.c_void_p), ("id_base", C.c_int64)]
 
 
 class TgNsOut(C.Structure):
@@ -116,13 +116,14 @@ class NsBatchedOut:
 
 
 def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UNIFORM, filter_mode=FILTER_NONE,
-                    forward=False, window=(0, 0), seeds_state=None):
+                    forward=False, window=(0, 0), seeds_state=None, rng_tag=0, id_base=0):
     """seeds: [n_batches, n_seeds] int64 on the graph's device; `out` an NsBatchedOut."""
     assert seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.dim() == 2
     cfg = TgNsConfig()
     cfg.sampler, cfg.filter_mode, cfg.forward = sampler, filter_mode, int(bool(forward))
     cfg.win_lo, cfg.win_hi = window
     cfg.seeds_state = seeds_state.data_ptr() if seeds_state is not None else None
+    cfg.rng_tag, cfg.id_base = rng_tag, id_base
     rng = TgRng(seed, call_id)
     fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
     so = out.struct()

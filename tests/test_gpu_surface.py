@@ -1,0 +1,164 @@
+"""The operator surface (C++ host module mirroring src/python.rs) on a GPU: same call shapes as the
+reference, results equal to the oracle's philox-mode for the seeded (seed, call counter) state."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from helpers import load_fake_hetero, load_karate, rel_key, validate_neighbor_samples
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import tch_geometric
+    return tch_geometric
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("where", ["cpu", "cuda"])
+def test_to_csc_to_csr(tg, where):
+    ei, n = load_karate()
+    t = torch.from_numpy(ei).to(where)
+    for fn, ofn in ((tg.to_csc, orc.to_csc), (tg.to_csr, orc.to_csr)):
+        p, i, perm = fn(t, n)
+        op, oi, operm = ofn(ei, n)
+        assert p.device.type == where
+        assert np.array_equal(_np(p), op) and np.array_equal(_np(i), oi) and np.array_equal(_np(perm), operm)
+    # storage.rs:165-184 + GraphSize as a tuple
+    e2 = torch.tensor([[1, 2, 3, 4, 9, 5, 6, 7], [0, 0, 0, 1, 4, 1, 2, 2]]).to(where)
+    p, i, _ = tg.to_csc(e2, (10, 10))
+    assert _np(i[p[0]:p[1]]).tolist() == [1, 2, 3] and _np(i[p[1]:p[2]]).tolist() == [4, 5]
+
+
+@pytest.mark.parametrize("where", ["cpu", "cuda"])
+def test_neighbor_sampling_homogenous_call_shapes(tg, where):
+    ei, n = load_karate()
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    P, I = torch.from_numpy(ptrs).to(where), torch.from_numpy(idx).to(where)
+    inputs = torch.tensor([0, 1, 4, 5]).to(where)
+    tg.seed(1234)
+    # trailing Optionals omitted, as the reference's examples do (examples/neighbor_sampling.py:18-20)
+    s, r, c, e, lo = tg.neighbor_sampling_homogenous(P, I, inputs, [5, 5])
+    o = orc.ns_homo(ptrs, idx, [0, 1, 4, 5], [5, 5], orc.rng_philox(1234, 0))
+    assert s.device.type == where and isinstance(lo, list) and isinstance(lo[0], tuple)
+    assert lo == o[4]
+    for a, b in zip((s, r, c, e), o[:4]):
+        assert a.dtype == torch.int64 and np.array_equal(_np(a), b)
+    # second call consumes the next call id; sampler objects are duck-typed
+    s, r, c, e, lo = tg.neighbor_sampling_homogenous(P, I, inputs, [4, 3], tg.UniformEdgeSampler(True), None)
+    o = orc.ns_homo(ptrs, idx, [0, 1, 4, 5], [4, 3], orc.rng_philox(1234, 1), sampler=orc.SAMPLER_UNIFORM_REPL)
+    assert np.array_equal(_np(s), o[0]) and np.array_equal(_np(e), o[3])
+    validate_neighbor_samples(ptrs, idx, _np(r), _np(c), _np(s), _np(s), lo, [4, 3])
+    assert tg.rng_state() == (1234, 2)
+
+
+def test_weighted_and_temporal_arguments(tg):
+    ei, n = load_karate()
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    P, I = torch.from_numpy(ptrs).cuda(), torch.from_numpy(idx).cuda()
+    inputs = torch.tensor([0, 1, 4, 5]).cuda()
+    g = np.random.default_rng(0)
+    w, ts = g.uniform(0.2, 5.0, len(idx)), g.integers(0, 4, len(idx))
+    st = np.array([0, 1, 2, 3])
+    tg.seed(9)
+    out = tg.neighbor_sampling_homogenous(P, I, inputs, [4, 3], tg.WeightedEdgeSampler(torch.from_numpy(w).cuda()))
+    o = orc.ns_homo(ptrs, idx, [0, 1, 4, 5], [4, 3], orc.rng_philox(9, 0), sampler=orc.SAMPLER_WEIGHTED, weights=w)
+    assert np.array_equal(_np(out[0]), o[0]) and np.array_equal(_np(out[3]), o[3])
+    for mode, fwd in ((tg.TEMPORAL_SAMPLE_STATIC, False), (tg.TEMPORAL_SAMPLE_RELATIVE, False),
+                      (tg.TEMPORAL_SAMPLE_RELATIVE, True), (tg.TEMPORAL_SAMPLE_DYNAMIC, True)):
+        flt = (tg.TemporalEdgeFilter((0, 2), torch.from_numpy(ts).cuda(), fwd, mode), torch.from_numpy(st).cuda())
+        call = tg.rng_state()[1]
+        out = tg.neighbor_sampling_homogenous(P, I, inputs, [4, 3], None, flt)
+        o = orc.ns_homo(ptrs, idx, [0, 1, 4, 5], [4, 3], orc.rng_philox(9, call), filter_mode=mode,
+                        forward=True if mode == 0 else fwd, window=(0, 2), timestamps=ts, inputs_state=st)
+        assert out[4] == o[4]
+        for a, b in zip(out[:4], o[:4]):
+            assert np.array_equal(_np(a), b)
+    # an unknown mode falls back to the identity filter (python.rs:249)
+    flt = (tg.TemporalEdgeFilter((0, 0), torch.from_numpy(ts).cuda(), False, 7), torch.from_numpy(st).cuda())
+    call = tg.rng_state()[1]
+    out = tg.neighbor_sampling_homogenous(P, I, inputs, [4, 3], None, flt)
+    o = orc.ns_homo(ptrs, idx, [0, 1, 4, 5], [4, 3], orc.rng_philox(9, call))
+    assert np.array_equal(_np(out[0]), o[0])
+
+
+def test_error_behaviour(tg):
+    P, I = torch.tensor([0, 1, 2]).cuda(), torch.tensor([1, 0]).cuda()
+    with pytest.raises(ValueError, match="Expected Int64 but got Float"):       # utils/tensor.rs:14-15
+        tg.neighbor_sampling_homogenous(P, I, torch.tensor([0.5]).cuda(), [2])
+    with pytest.raises(ValueError, match="Expected Int64 but got Int"):
+        tg.neighbor_sampling_homogenous(P.int(), I, torch.tensor([0]).cuda(), [2])
+    with pytest.raises(ValueError, match="Expected Double but got Float"):      # weights are f64 (python.rs:214)
+        tg.neighbor_sampling_homogenous(P, I, torch.tensor([0]).cuda(), [2],
+                                        tg.WeightedEdgeSampler(torch.ones(2).cuda()))
+    with pytest.raises(ValueError):
+        tg.neighbor_sampling_homogenous(P, I, torch.tensor([0]).cuda(), [0])
+    with pytest.raises(RuntimeError, match="outside this backend's scope"):
+        tg.budget_sampling()
+    with pytest.raises(RuntimeError):                                           # sampling.rs:49 panic
+        tg.neighbor_sampling_homogenous(P, torch.tensor([1, 0]).cuda(), torch.tensor([0, 1]).cuda(), [1, 1],
+                                        tg.WeightedEdgeSampler(torch.zeros(2, dtype=torch.float64).cuda()))
+
+
+@pytest.mark.parametrize("variant", ["uniform", "replace", "weighted", "temporal"])
+def test_neighbor_sampling_heterogenous(tg, variant):
+    """neighbor_sampling.rs:572-648 config (inputs [0,1,4,5] per type, [4,3] per relation, 2 hops)."""
+    counts, edges = load_fake_hetero()
+    node_types, edge_types = sorted(counts), sorted(edges)
+    P, I, Pd, Id = {}, {}, {}, {}
+    for et in edge_types:
+        p, i, _ = orc.to_csc(edges[et], (counts[et[0]], counts[et[2]]))
+        P[rel_key(et)], I[rel_key(et)] = p, i
+        Pd[rel_key(et)], Id[rel_key(et)] = torch.from_numpy(p).cuda(), torch.from_numpy(i).cuda()
+    inputs = {t: [0, 1, 4, 5] for t in node_types}
+    inputs_d = {t: torch.tensor(v).cuda() for t, v in inputs.items()}
+    nn = {rel_key(e): [4, 3] for e in edge_types}
+    g = np.random.default_rng(3)
+    kw, sampler, flt = {}, None, None
+    if variant == "replace":
+        sampler, kw = tg.UniformEdgeSampler(True), dict(sampler=orc.SAMPLER_UNIFORM_REPL)
+    elif variant == "weighted":
+        W = {r: g.uniform(0.2, 5.0, len(I[r])) for r in I}
+        sampler = tg.WeightedEdgeSampler({r: torch.from_numpy(w).cuda() for r, w in W.items()})
+        kw = dict(sampler=orc.SAMPLER_WEIGHTED, weights=W)
+    elif variant == "temporal":
+        TS = {r: g.integers(0, 10, len(I[r])) for r in I}
+        ST = {t: np.array([3, 4, 5, 6]) for t in node_types}
+        flt = (tg.TemporalEdgeFilter((0, 4), {r: torch.from_numpy(t).cuda() for r, t in TS.items()}, True,
+                                     tg.TEMPORAL_SAMPLE_DYNAMIC),
+               {t: torch.from_numpy(v).cuda() for t, v in ST.items()})
+        kw = dict(filter_mode=orc.FILTER_DYNAMIC, forward=True, window=(0, 4), timestamps=TS, inputs_state=ST)
+    tg.seed(77)
+    s, r, c, e, lo = tg.neighbor_sampling_heterogenous(node_types, edge_types, Pd, Id, inputs_d, nn, 2, sampler, flt)
+    os_, or_, oc, oe, olo = orc.ns_hetero(node_types, edge_types, P, I, inputs, nn, 2, orc.rng_philox(77, 0), **kw)
+    for t in node_types:
+        assert np.array_equal(_np(s[t]), os_[t]), t
+    for et in edge_types:
+        k = rel_key(et)
+        assert [tuple(x) for x in lo[k]] == olo[k], k
+        assert np.array_equal(_np(r[k]), or_[k]) and np.array_equal(_np(c[k]), oc[k]) and np.array_equal(_np(e[k]), oe[k])
+        validate_neighbor_samples(P[k], I[k], _np(r[k]), _np(c[k]), _np(s[et[0]]), _np(s[et[2]]), lo[k], [4, 3])
+
+
+def test_walks_through_the_surface(tg):
+    ei, n = load_karate()
+    ptrs, idx, _ = orc.to_csr(ei, n)
+    P, I = torch.from_numpy(ptrs).cuda(), torch.from_numpy(idx).cuda()
+    tg.seed(5)
+    w = tg.random_walk(P, I, torch.tensor([0, 1, 2, 3]).cuda(), 10, 1.0, 1.5)     # random_walk.rs:301-331
+    assert w.shape == (4, 11)
+    assert np.array_equal(_np(w), orc.random_walk(ptrs, idx, [0, 1, 2, 3], 10, 1.0, 1.5, orc.rng_philox(5, 0)))
+    w = tg.random_walk(P.cpu(), I.cpu(), torch.tensor([0, 1, 2, 3]), 10, 1.0, 1.0)
+    assert w.device.type == "cpu"
+    assert np.array_equal(_np(w), orc.random_walk(ptrs, idx, [0, 1, 2, 3], 10, 1.0, 1.0, orc.rng_philox(5, 1)))
+    g = np.random.default_rng(7)
+    nts, ets = g.integers(-1, 4, n), g.integers(-1, 4, len(idx))
+    a, b = tg.tempo_random_walk(P, I, torch.from_numpy(nts).cuda(), torch.from_numpy(ets).cuda(),
+                                torch.tensor([0, 1, 2, 3]).cuda(), torch.tensor([0, -1, 2, 3]).cuda(), 10, (0, 2))
+    oa, ob = orc.tempo_random_walk(ptrs, idx, nts, ets, [0, 1, 2, 3], [0, -1, 2, 3], 10, (0, 2), orc.rng_philox(5, 2))
+    assert a.shape == (4, 10) and np.array_equal(_np(a), oa) and np.array_equal(_np(b), ob)
