@@ -126,6 +126,36 @@ TG_API int tg_tempo_random_walk(const tg_graph *csr, const int64_t *node_ts, con
                          const int64_t *start_ts, int64_t n, int64_t walk_length, int64_t win0, int64_t win1,
                          const tg_rng *rng, int64_t *walks, int64_t *walks_ts, void *stream);
 
+/* negative_sample_neighbors_homogenous / _heterogenous (src/algo/negative_sampling.rs:6-131; bindings
+ * python.rs:690-783) as one problem description.  Host arrays are indexed by node type (order of the caller's
+ * `node_types`) and relation (order of `edge_types`); the reference's HashMap visiting order is replaced by
+ * those orders. */
+typedef struct {
+    int32_t n_types, n_rels;
+    int32_t homogeneous; /* 1: the homogeneous operator (no relation draw; n_types = n_rels = 1) */
+    int32_t inbound;     /* negative_sampling.rs:112-115 */
+    const int32_t *rel_src;       /* host [n_rels] node-type index of the relation's source */
+    const int32_t *rel_dst;       /* host [n_rels] */
+    const tg_graph *graphs;       /* host [n_rels] CSR views (device pointers inside) */
+    const int64_t *node_count;    /* host [n_rels]: graph_size.1 / sizes[rel].1 (negative_sampling.rs:28,105) */
+    const int64_t *const *inputs; /* host [n_types] device pointers */
+    const int64_t *n_inputs;      /* host [n_types]; < 0: the type has no entry in `inputs` */
+    int64_t num_neg, try_count;
+} tg_neg_problem;
+
+typedef struct {
+    int64_t *const *samples; /* host [n_types] device buffers, capacity max(n_inputs[t],0) + total items */
+    int64_t *const *rows;    /* host [n_rels] device buffers, capacity n_inputs[src] * num_neg */
+    int64_t *const *cols;    /* host [n_rels] */
+    int64_t *n_samples;      /* device [n_types] */
+    int64_t *n_edges;        /* device [n_rels] */
+    int32_t *panic;          /* device [1]: 1 where the reference would panic (inbound row out of range) */
+} tg_neg_out;
+
+TG_API int tg_neg_workspace_bytes(const tg_neg_problem *problem, int64_t *bytes);
+TG_API int tg_neg_sample(const tg_neg_problem *problem, const tg_rng *rng, const tg_neg_out *out, void *workspace,
+                         void *stream);
+
 /* ---- synthetic inputs of the measurement harness ---- */
 
 /* R-MAT edge list: n_edges edges over 2^scale vertices, (a,b,c,d) =

@@ -12,14 +12,15 @@ from torch.utils import cpp_extension
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "tch_geometric", "tch_geometric" + sysconfig.get_config_var("EXT_SUFFIX"))
-SRC = [os.path.join(HERE, "python_module.cpp"), os.path.join(HERE, "python_module_more.cpp")]
+SRC = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".cpp"))
 LIBDIR = os.path.join(PKG, "lib")
 
 
 def up_to_date():
     if not os.path.exists(OUT):
         return False
-    deps = SRC + [os.path.join(PKG, "..", "include", "tchgeo.h"), os.path.join(LIBDIR, "libtchgeo_hip.so")]
+    deps = SRC + [os.path.join(HERE, "host_common.h"), os.path.join(PKG, "..", "include", "tchgeo.h"),
+                  os.path.join(LIBDIR, "libtchgeo_hip.so")]
     return all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps if os.path.exists(d))
 
 

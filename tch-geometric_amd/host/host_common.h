@@ -1,0 +1,100 @@
+// Helpers shared by the translation units of the host module (argument checks that mirror
+// src/utils/tensor.rs, device / stream plumbing, the global (seed, call counter) state).
+#pragma once
+#include <torch/extension.h>
+
+#include <mutex>
+#include <random>
+#include <sstream>
+
+#include "../../include/tchgeo.h"
+
+namespace py = pybind11;
+using at::Tensor;
+
+namespace tghost {
+
+// ---------------------------------------------------------------- global RNG state
+struct RngState {
+    std::mutex mu;
+    uint64_t seed, call = 0;
+    RngState() {
+        std::random_device rd;
+        seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+    }
+};
+RngState &rng_state(); // defined once in python_module.cpp
+
+inline tg_rng next_rng() { // one call id per operator call (utils/random.rs:19-22 derives one child rng per call)
+    RngState &st = rng_state();
+    std::lock_guard<std::mutex> lk(st.mu);
+    tg_rng r{st.seed, st.call};
+    st.call += 1;
+    return r;
+}
+
+// ---------------------------------------------------------------- errors (utils/tensor.rs:11-27)
+inline const char *kind_name(at::ScalarType t) {
+    switch (t) {
+    case at::kLong: return "Int64";
+    case at::kInt: return "Int";
+    case at::kShort: return "Int16";
+    case at::kChar: return "Int8";
+    case at::kByte: return "Uint8";
+    case at::kBool: return "Bool";
+    case at::kDouble: return "Double";
+    case at::kFloat: return "Float";
+    case at::kHalf: return "Half";
+    case at::kBFloat16: return "BFloat16";
+    default: return "Unknown";
+    }
+}
+inline void check_kind(const Tensor &t, at::ScalarType want) {
+    if (t.scalar_type() != want) {
+        std::ostringstream os;
+        os << "Tensor must be a is of invalid type. Expected " << kind_name(want) << " but got "
+           << kind_name(t.scalar_type());
+        throw py::value_error(os.str());
+    }
+}
+inline void check_rc(int rc) {
+    if (rc == TG_OK) return;
+    std::string msg = std::string("tchgeo: ") + tg_last_error();
+    if (rc == TG_ERR_INVALID) throw py::value_error(msg);
+    throw std::runtime_error(msg);
+}
+
+// ---------------------------------------------------------------- devices and streams
+inline c10::Device compute_device(std::initializer_list<const Tensor *> ts) {
+    for (const Tensor *t : ts)
+        if (t && t->defined() && t->is_cuda()) return t->device();
+    py::object cuda = py::module_::import("torch").attr("cuda");
+    if (!cuda.attr("is_available")().cast<bool>())
+        throw std::runtime_error("tch_geometric (MI355X backend): no HIP device is visible and this build has no CPU "
+                                 "path");
+    return c10::Device(c10::kCUDA, (c10::DeviceIndex)cuda.attr("current_device")().cast<int>());
+}
+inline void *stream_of(const c10::Device &dev) {
+    py::object s = py::module_::import("torch").attr("cuda").attr("current_stream")(py::int_((int)dev.index()));
+    return reinterpret_cast<void *>(s.attr("cuda_stream").cast<uintptr_t>());
+}
+struct DeviceGuard { // run the call with `dev` current (kernels launch on the current device)
+    py::object ctx;
+    explicit DeviceGuard(const c10::Device &dev) {
+        ctx = py::module_::import("torch").attr("cuda").attr("device")(py::int_((int)dev.index()));
+        ctx.attr("__enter__")();
+    }
+    ~DeviceGuard() { ctx.attr("__exit__")(py::none(), py::none(), py::none()); }
+};
+inline Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
+    check_kind(t, want);
+    return t.to(dev).contiguous(); // tensor_to_slice assumes contiguity (utils/tensor.rs:57-59)
+}
+inline Tensor back(const Tensor &t, const c10::Device &out_dev) { return t.device() == out_dev ? t : t.to(out_dev); }
+inline at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions().dtype(at::kLong).device(dev); }
+
+inline std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257
+    return std::get<0>(e) + "__" + std::get<1>(e) + "__" + std::get<2>(e);
+}
+
+} // namespace tghost

@@ -17,98 +17,18 @@
 // entropy that Python cannot reseed (utils/random.rs:8-22).  Here the global
 // state is (seed, call counter); `seed(s)` (additive to the surface) makes
 // results reproducible, and equal to the CPU oracle's philox-mode.
-#include <torch/extension.h>
+#include "host_common.h"
 
-#include <atomic>
-#include <mutex>
-#include <random>
-#include <sstream>
+using namespace tghost;
 
-#include "../../include/tchgeo.h"
-
-namespace py = pybind11;
-using at::Tensor;
+namespace tghost {
+RngState &rng_state() {
+    static RngState st;
+    return st;
+}
+} // namespace tghost
 
 namespace {
-
-// ---------------------------------------------------------------- global RNG state
-std::mutex g_rng_mu;
-uint64_t g_seed = [] {
-    std::random_device rd;
-    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
-}();
-uint64_t g_call = 0;
-
-tg_rng next_rng() { // one call id per operator call (utils/random.rs:19-22 derives one child rng per call)
-    std::lock_guard<std::mutex> lk(g_rng_mu);
-    tg_rng r{g_seed, g_call};
-    g_call += 1;
-    return r;
-}
-
-// ---------------------------------------------------------------- errors (utils/tensor.rs:11-27)
-const char *kind_name(at::ScalarType t) {
-    switch (t) {
-    case at::kLong: return "Int64";
-    case at::kInt: return "Int";
-    case at::kShort: return "Int16";
-    case at::kChar: return "Int8";
-    case at::kByte: return "Uint8";
-    case at::kBool: return "Bool";
-    case at::kDouble: return "Double";
-    case at::kFloat: return "Float";
-    case at::kHalf: return "Half";
-    case at::kBFloat16: return "BFloat16";
-    default: return "Unknown";
-    }
-}
-void check_kind(const Tensor &t, at::ScalarType want) {
-    if (t.scalar_type() != want) {
-        std::ostringstream os;
-        os << "Tensor must be a is of invalid type. Expected " << kind_name(want) << " but got "
-           << kind_name(t.scalar_type());
-        throw py::value_error(os.str());
-    }
-}
-void check_rc(int rc) {
-    if (rc == TG_OK) return;
-    std::string msg = std::string("tchgeo: ") + tg_last_error();
-    if (rc == TG_ERR_INVALID) throw py::value_error(msg);
-    throw std::runtime_error(msg);
-}
-
-// ---------------------------------------------------------------- devices and streams
-c10::Device compute_device(std::initializer_list<const Tensor *> ts) {
-    for (const Tensor *t : ts)
-        if (t && t->defined() && t->is_cuda()) return t->device();
-    py::object cuda = py::module_::import("torch").attr("cuda");
-    if (!cuda.attr("is_available")().cast<bool>())
-        throw std::runtime_error("tch_geometric (MI355X backend): no HIP device is visible and this build has no CPU "
-                                 "path");
-    return c10::Device(c10::kCUDA, (c10::DeviceIndex)cuda.attr("current_device")().cast<int>());
-}
-void *stream_of(const c10::Device &dev) {
-    py::object s = py::module_::import("torch").attr("cuda").attr("current_stream")(py::int_((int)dev.index()));
-    return reinterpret_cast<void *>(s.attr("cuda_stream").cast<uintptr_t>());
-}
-struct DeviceGuard { // run the call with `dev` current (kernels launch on the current device)
-    py::object ctx;
-    explicit DeviceGuard(const c10::Device &dev) {
-        ctx = py::module_::import("torch").attr("cuda").attr("device")(py::int_((int)dev.index()));
-        ctx.attr("__enter__")();
-    }
-    ~DeviceGuard() { ctx.attr("__exit__")(py::none(), py::none(), py::none()); }
-};
-Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
-    check_kind(t, want);
-    return t.to(dev).contiguous(); // tensor_to_slice assumes contiguity (utils/tensor.rs:57-59)
-}
-Tensor back(const Tensor &t, const c10::Device &out_dev) { return t.device() == out_dev ? t : t.to(out_dev); }
-at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions().dtype(at::kLong).device(dev); }
-
-std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257
-    return std::get<0>(e) + "__" + std::get<1>(e) + "__" + std::get<2>(e);
-}
 
 // ---------------------------------------------------------------- sampler / filter extraction (python.rs:107-168)
 struct SamplerArg {
@@ -473,18 +393,21 @@ PYBIND11_MODULE(tch_geometric, m) {
     m.doc() = "MI355X-native backend behind tch-geometric's operator surface (reference: src/python.rs)";
     // additive: the reference's RNG cannot be seeded from Python (utils/random.rs:14-17 is not exported)
     m.def("seed", [](uint64_t s) {
-        std::lock_guard<std::mutex> lk(g_rng_mu);
-        g_seed = s;
-        g_call = 0;
+        RngState &st = rng_state();
+        std::lock_guard<std::mutex> lk(st.mu);
+        st.seed = s;
+        st.call = 0;
     }, py::arg("seed"), "Seed the global (seed, call counter) state; every operator call consumes one call id.");
     m.def("rng_state", [] {
-        std::lock_guard<std::mutex> lk(g_rng_mu);
-        return std::make_pair(g_seed, g_call);
+        RngState &st = rng_state();
+        std::lock_guard<std::mutex> lk(st.mu);
+        return std::make_pair(st.seed, st.call);
     });
     m.def("set_rng_state", [](uint64_t s, uint64_t c) {
-        std::lock_guard<std::mutex> lk(g_rng_mu);
-        g_seed = s;
-        g_call = c;
+        RngState &st = rng_state();
+        std::lock_guard<std::mutex> lk(st.mu);
+        st.seed = s;
+        st.call = c;
     });
     m.def("backend_version", [] { return std::string(tg_version()); });
 

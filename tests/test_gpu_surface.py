@@ -101,7 +101,8 @@ def test_error_behaviour(tg):
     with pytest.raises(RuntimeError, match="outside this backend's scope"):
         tg.budget_sampling()
     with pytest.raises(RuntimeError):                                           # sampling.rs:49 panic
-        tg.neighbor_sampling_homogenous(P, torch.tensor([1, 0]).cuda(), torch.tensor([0, 1]).cuda(), [1, 1],
+        tg.neighbor_sampling_homogenous(torch.tensor([0, 2, 2]).cuda(), torch.tensor([0, 1]).cuda(),
+                                        torch.tensor([0]).cuda(), [1],      # 2 candidates, 1 slot: one float draw
                                         tg.WeightedEdgeSampler(torch.zeros(2, dtype=torch.float64).cuda()))
 
 
