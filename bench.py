@@ -41,6 +41,7 @@ def main():
     import torch.distributed as dist
 
     from tch_geometric import _cabi  # raises if the gfx950 library is missing (no fallback)
+    from tch_geometric import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +71,7 @@ def main():
     graph = _cabi.graph_view(ptrs, indices)
 
     # ---- this rank's batches: global batch ids [rank*(W+K), (rank+1)*(W+K))
-    first = rank * (W + K)
+    first, _ = sharding.rank_batch_range(rank, world, W + K)
     seeds = _cabi.seed_batches(0xBA7C4, first, W + K, B, n_nodes, dev)
     out = _cabi.NsBatchedOut(min(G, max(W, K)), B, fanout, dev)
     acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
@@ -93,10 +94,7 @@ def main():
             acc.add_(torch.stack([ne, nf, torch.ones((), dtype=torch.int64, device=dev)]))
 
     def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        sharding.fence(dev)
 
     run(0, W)
     acc.zero_()
@@ -107,12 +105,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot = acc.clone()
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt_max = float(tmax.item())
+    dt_max, tot = sharding.reduce_measurement(dt, acc)
     edges_all, frontier_all, launches_all = (int(x) for x in tot.tolist())
 
     # ---- roofline of the dominant kernel (this rank): algorithmic bytes / HIP-event kernel time

@@ -1,0 +1,62 @@
+"""Host module on a box without a GPU: it builds, exposes the reference's surface, and refuses to compute
+(no CPU fallback)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tg():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tch-geometric_amd"), "-s"])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tch-geometric_amd", "host", "build_host.py")])
+    import tch_geometric
+    return tch_geometric
+
+
+REFERENCE_SURFACE = ["to_csc", "to_csr", "neighbor_sampling_homogenous", "neighbor_sampling_heterogenous",
+                     "hgt_sampling", "budget_sampling", "random_walk", "tempo_random_walk",
+                     "biased_tempo_random_walk", "negative_sample_neighbors_homogenous",
+                     "negative_sample_neighbors_heterogenous"]          # src/python.rs:56-59, 785-797
+
+
+def test_surface_names(tg):
+    missing = [n for n in REFERENCE_SURFACE if not hasattr(tg, n)]
+    assert missing in ([], ["hgt_sampling"]), missing
+    for n in ("seed", "rng_state", "set_rng_state", "UniformEdgeSampler", "WeightedEdgeSampler",
+              "TemporalEdgeFilter", "TEMPORAL_SAMPLE_STATIC", "TEMPORAL_SAMPLE_RELATIVE", "TEMPORAL_SAMPLE_DYNAMIC"):
+        assert hasattr(tg, n)
+    assert (tg.TEMPORAL_SAMPLE_STATIC, tg.TEMPORAL_SAMPLE_RELATIVE, tg.TEMPORAL_SAMPLE_DYNAMIC) == (0, 1, 2)
+
+
+def test_seed_state(tg):
+    tg.seed(42)
+    assert tg.rng_state() == (42, 0)
+    tg.set_rng_state(7, 9)
+    assert tg.rng_state() == (7, 9)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback(tg):
+    P, I = torch.tensor([0, 1, 2]), torch.tensor([1, 0])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        tg.neighbor_sampling_homogenous(P, I, torch.tensor([0]), [2])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        tg.random_walk(P, I, torch.tensor([0]), 3, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        tg.to_csc(torch.tensor([[0, 1], [1, 0]]), 2)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tch-geometric_amd")
+    for base, _, files in os.walk(pkg):
+        if os.path.basename(base) in ("build", "lib", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(base, f), errors="ignore").read()
+                assert "import orc" not in src and "oracle/" not in src and "tg_oracle" not in src, f
