@@ -360,3 +360,47 @@ def seed_batches(seed, first_batch, n_batches, n_seeds, n_nodes):
     lib().orc_seed_batches(C.c_uint64(seed), C.c_int64(first_batch), C.c_int64(n_batches), C.c_int64(n_seeds),
                            C.c_int64(n_nodes), _p(out))
     return out
+
+
+# ---------------------------------------------------------------- HGT sampling
+def hgt(node_types, edge_types, col_ptrs, row_indices, row_timestamps, inputs, input_timestamps, num_samples,
+        num_hops, rng, timerange=None, edge_reservoir_algo=RES_AUTO):
+    """hgt_sampling -> (samples, sample_ts, rows, cols, edge_index) dicts (canonical node/edge type order)."""
+    L = lib()
+    L.orc_hgt.restype = C.c_void_p
+    L.orc_het_copy_sample_ts.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    T, R, H = len(node_types), len(edge_types), num_hops
+    tix = {t: i for i, t in enumerate(node_types)}
+    rels = [_rel_key(e) for e in edge_types]
+    rel_src = (C.c_int32 * R)(*[tix[e[0]] for e in edge_types])
+    rel_dst = (C.c_int32 * R)(*[tix[e[2]] for e in edge_types])
+    P = [_i64(col_ptrs[r]) for r in rels]
+    I = [_i64(row_indices[r]) for r in rels]
+    TS = None
+    if row_timestamps is not None:
+        TS = [_i64(row_timestamps[r]) if r in row_timestamps else None for r in rels]
+    IN = [_i64(inputs[t]) if t in inputs else None for t in node_types]
+    n_in = _i64([a.size if a is not None else -1 for a in IN])
+    ITS = None
+    if input_timestamps is not None:
+        ITS = [_i64(input_timestamps[t]) if t in inputs else None for t in node_types]
+    ns = _i64([[num_samples[t][h] if t in num_samples else -1 for h in range(H)] for t in node_types]).reshape(-1)
+    status = C.c_int32(0)
+    tr = timerange if timerange is not None else (0, 0)
+    h = L.orc_hgt(C.c_int32(T), C.c_int32(R), rel_src, rel_dst, _ptr_array(P), _ptr_array(I),
+                  _ptr_array(TS) if TS is not None else C.c_void_p(0), _ptr_array(IN), _p(n_in),
+                  _ptr_array(ITS) if ITS is not None else C.c_void_p(0), _p(ns), C.c_int32(H),
+                  C.c_int32(int(timerange is not None)), C.c_int64(tr[0]), C.c_int64(tr[1]),
+                  C.c_int32(edge_reservoir_algo), C.byref(rng), C.byref(status))
+    try:
+        if status.value != 0:
+            raise RuntimeError("oracle hgt: the reference would panic")
+        samples, rows, cols, eidx, _ = _unpack_het(h, node_types, rels, 0)
+        ts = {}
+        for t, name in enumerate(node_types):
+            a = np.empty(len(samples[name]), dtype=np.int64)
+            L.orc_het_copy_sample_ts(C.c_void_p(h), t, _p(a))
+            ts[name] = a
+        return samples, ts, rows, cols, eidx
+    finally:
+        L.orc_het_free(C.c_void_p(h))

@@ -340,19 +340,24 @@ ORC_API int orc_ns_homo(const int64_t *ptrs, const int64_t *indices, const int64
 typedef struct {
     int32_t T, R, H;
     vec64 *samples;       /* [T] */
+    vec64 *ts;            /* [T] sample timestamps (hgt_sampling only) */
     vec64 *rows, *cols, *eidx; /* [R] */
     int64_t *layer_offsets;    /* [R*H*3] */
 } orc_het_out;
 
 ORC_API void orc_het_free(orc_het_out *o) {
     if (!o) return;
-    for (int t = 0; t < o->T; t++) vfree(&o->samples[t]);
+    for (int t = 0; t < o->T; t++) {
+        vfree(&o->samples[t]);
+        vfree(&o->ts[t]);
+    }
     for (int r = 0; r < o->R; r++) {
         vfree(&o->rows[r]);
         vfree(&o->cols[r]);
         vfree(&o->eidx[r]);
     }
     free(o->samples);
+    free(o->ts);
     free(o->rows);
     free(o->cols);
     free(o->eidx);
@@ -363,6 +368,9 @@ ORC_API int64_t orc_het_num_samples(const orc_het_out *o, int t) { return o->sam
 ORC_API int64_t orc_het_num_edges(const orc_het_out *o, int r) { return o->rows[r].n; }
 ORC_API void orc_het_copy_samples(const orc_het_out *o, int t, int64_t *dst) {
     memcpy(dst, o->samples[t].p, sizeof(int64_t) * (size_t)o->samples[t].n);
+}
+ORC_API void orc_het_copy_sample_ts(const orc_het_out *o, int t, int64_t *dst) {
+    memcpy(dst, o->ts[t].p, sizeof(int64_t) * (size_t)o->ts[t].n);
 }
 ORC_API void orc_het_copy_edges(const orc_het_out *o, int r, int64_t *rows, int64_t *cols, int64_t *eidx) {
     size_t nb = sizeof(int64_t) * (size_t)o->rows[r].n;
@@ -380,6 +388,7 @@ static orc_het_out *het_alloc(int32_t T, int32_t R, int32_t H) {
     o->R = R;
     o->H = H;
     o->samples = (vec64 *)calloc((size_t)T, sizeof(vec64));
+    o->ts = (vec64 *)calloc((size_t)T, sizeof(vec64));
     o->rows = (vec64 *)calloc((size_t)R, sizeof(vec64));
     o->cols = (vec64 *)calloc((size_t)R, sizeof(vec64));
     o->eidx = (vec64 *)calloc((size_t)R, sizeof(vec64));
@@ -857,4 +866,237 @@ ORC_API void orc_seed_batches(uint64_t seed, int64_t first_batch, int64_t n_batc
             orc_draw d = orc_philox_draw(ck, (uint64_t)(first_batch + b), (uint32_t)i, (uint32_t)((uint64_t)i >> 32));
             out[b * n_seeds + i] = (int64_t)orc_bounded(d.a, (uint64_t)n_nodes);
         }
+}
+
+
+/* ------------------------------------------------------------------ */
+/* HGT sampling: src/algo/hgt_sampling.rs                              */
+/* ------------------------------------------------------------------ */
+#define ORC_HGT_MAX_NEIGHBORS 50 /* hgt_sampling.rs:10 */
+
+/* NodeBudget (hgt_sampling.rs:13-24) with a canonical iteration order: entries are kept in the order
+ * their key was first inserted (the reference iterates a std HashMap, whose order is not reproducible);
+ * removal leaves a tombstone.  A removed key is never re-inserted: it is in to_local by then (:80). */
+typedef struct {
+    vec64 key, ts, alive;
+    double *score;
+    int64_t score_cap;
+    imap slot; /* key -> entry index */
+    int present; /* budget_dict.entry(type) has been created */
+} orc_budget;
+
+static void budget_add(orc_budget *b, int64_t v, double inv_deg, int64_t ts) { /* :95-97 */
+    int f;
+    int64_t *s = imap_slot(&b->slot, v, &f);
+    if (!f) {
+        *s = b->key.n;
+        if (b->key.n == b->score_cap) {
+            b->score_cap = b->score_cap ? b->score_cap * 2 : 64;
+            b->score = (double *)realloc(b->score, sizeof(double) * (size_t)b->score_cap);
+        }
+        b->score[b->key.n] = 0.0;
+        vpush(&b->key, v);
+        vpush(&b->ts, 0);
+        vpush(&b->alive, 1);
+    }
+    b->score[*s] += inv_deg;
+    b->ts.p[*s] = ts;
+}
+
+typedef struct {
+    int32_t T, R;
+    const int32_t *rel_src, *rel_dst;
+    const int64_t *const *ptrs, *const *indices, *const *rel_ts;
+    int has_timerange;
+    int64_t tr_lo, tr_hi; /* half open, python.rs:450 */
+    imap *to_local;       /* [T] */
+    orc_budget *budget;   /* [T] */
+} orc_hgt_ctx;
+
+/* hgt_sampling.rs:27-102 update_budget for the samples of node type `nt` */
+static void hgt_update_budget(orc_hgt_ctx *h, int nt, const int64_t *samples, const int64_t *samples_ts, int64_t n) {
+    if (n == 0) return; /* :38-40 */
+    for (int r = 0; r < h->R; r++) { /* :47 canonical relation order */
+        if (h->rel_dst[r] != nt) continue; /* :50-52 */
+        int src = h->rel_src[r];
+        imap *to_local_src = &h->to_local[src];
+        orc_budget *sb = &h->budget[src];
+        sb->present = 1; /* :55 entry(src).or_default() */
+        const int64_t *ptrs = h->ptrs[r], *indices = h->indices[r];
+        const int64_t *ets = h->rel_ts ? h->rel_ts[r] : NULL;
+        for (int64_t j = 0; j < n; j++) { /* :58 */
+            int64_t w = samples[j];
+            int64_t b = ptrs[w], e = ptrs[w + 1];
+            if (e <= b) continue; /* :60-62 */
+            int64_t w_ts = samples_ts[j];
+            /* :72 reservoir over 0..min(len,50) into 50 slots never draws: the first min(len,50) neighbours */
+            int64_t cnt = e - b < ORC_HGT_MAX_NEIGHBORS ? e - b : ORC_HGT_MAX_NEIGHBORS;
+            double inv_deg = 1.0 / (double)cnt; /* :73 */
+            for (int64_t i = 0; i < cnt; i++) { /* :76 */
+                int64_t v = indices[b + i];
+                int f;
+                /* :80 contains_key -- probe without inserting */
+                {
+                    uint64_t hh = (uint64_t)v * 0x9E3779B97F4A7C15ULL;
+                    int64_t s = (int64_t)(hh >> 20) & (to_local_src->cap - 1);
+                    while (to_local_src->k[s] != INT64_MIN && to_local_src->k[s] != v) s = (s + 1) & (to_local_src->cap - 1);
+                    f = to_local_src->k[s] == v;
+                }
+                if (f) continue;
+                int64_t v_ts = ets ? ets[b + i] : ORC_NAN_TS; /* :82 */
+                if (v_ts == ORC_NAN_TS) v_ts = w_ts;           /* :83-85 */
+                if (h->has_timerange && v_ts != ORC_NAN_TS && !(h->tr_lo <= v_ts && v_ts < h->tr_hi)) continue; /* :88-92 */
+                budget_add(sb, v, inv_deg, v_ts);
+            }
+        }
+    }
+}
+
+/* hgt_sampling.rs:138-278.  inputs[t] NULL / n_inputs[t] < 0: type absent from `inputs`.
+ * input_ts NULL: no input timestamps at all (:172-178).  num_samples[t*H + layer].
+ * philox addresses: sample_from of (layer, type) uses id = layer*T + type under ORC_TAG_HGT; the edge
+ * reservoir of relation r uses id = dst slot under ORC_TAG_HGT | (r+1) << 8. */
+ORC_API orc_het_out *orc_hgt(int32_t T, int32_t R, const int32_t *rel_src, const int32_t *rel_dst,
+                             const int64_t *const *ptrs, const int64_t *const *indices, const int64_t *const *rel_ts,
+                             const int64_t *const *inputs, const int64_t *n_inputs, const int64_t *const *input_ts,
+                             const int64_t *num_samples, int32_t H, int32_t has_timerange, int64_t tr_lo,
+                             int64_t tr_hi, int32_t edge_reservoir_algo, orc_rng *rng, int32_t *status) {
+    orc_het_out *o = het_alloc(T, R, 0);
+    *status = 0;
+    orc_hgt_ctx h;
+    memset(&h, 0, sizeof(h));
+    h.T = T;
+    h.R = R;
+    h.rel_src = rel_src;
+    h.rel_dst = rel_dst;
+    h.ptrs = ptrs;
+    h.indices = indices;
+    h.rel_ts = rel_ts;
+    h.has_timerange = has_timerange;
+    h.tr_lo = tr_lo;
+    h.tr_hi = tr_hi;
+    h.to_local = (imap *)calloc((size_t)T, sizeof(imap));
+    h.budget = (orc_budget *)calloc((size_t)T, sizeof(orc_budget));
+    int *has_nodes = (int *)calloc((size_t)T, sizeof(int)); /* nodes_dict has an entry for the type */
+    for (int t = 0; t < T; t++) {
+        imap_init(&h.to_local[t], 64);
+        imap_init(&h.budget[t].slot, 64);
+    }
+    /* :167-180 inputs become the first sampled nodes */
+    for (int t = 0; t < T; t++) {
+        if (n_inputs[t] < 0) continue;
+        has_nodes[t] = 1;
+        for (int64_t i = 0; i < n_inputs[t]; i++) {
+            int f;
+            *imap_slot(&h.to_local[t], inputs[t][i], &f) = o->samples[t].n; /* insert overwrites */
+            vpush(&o->samples[t], inputs[t][i]);
+            vpush(&o->ts[t], input_ts ? input_ts[t][i] : ORC_NAN_TS);
+        }
+    }
+    /* :183-196 */
+    for (int t = 0; t < T; t++)
+        if (has_nodes[t]) hgt_update_budget(&h, t, o->samples[t].p, o->ts[t].p, o->samples[t].n);
+
+    orc_ctx c;
+    orc_ctx_init(&c, rng, ORC_TAG_HGT);
+    vec64 *lay_s = (vec64 *)calloc((size_t)T, sizeof(vec64)), *lay_t = (vec64 *)calloc((size_t)T, sizeof(vec64));
+    int *lay_has = (int *)calloc((size_t)T, sizeof(int));
+    for (int32_t layer = 0; layer < H && *status == 0; layer++) { /* :198 */
+        for (int t = 0; t < T; t++) {
+            lay_s[t].n = lay_t[t].n = 0;
+            lay_has[t] = 0;
+        }
+        for (int t = 0; t < T && *status == 0; t++) { /* :201 canonical type order */
+            orc_budget *b = &h.budget[t];
+            if (!b->present) continue;
+            int64_t k = num_samples[t * H + layer];
+            if (k < 0) { /* :202 missing key panics */
+                *status = -1;
+                break;
+            }
+            /* :104-135 sample_from: weighted reservoir over the live entries, weights score^2 */
+            int64_t n = 0;
+            for (int64_t i = 0; i < b->key.n; i++) n += b->alive.p[i];
+            int64_t *live = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+            double *w = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+            int64_t m = 0;
+            for (int64_t i = 0; i < b->key.n; i++)
+                if (b->alive.p[i]) {
+                    live[m] = i;
+                    w[m] = b->score[i] * b->score[i]; /* :110 */
+                    m++;
+                }
+            int64_t *dst = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k ? k : 1));
+            int64_t cnt = 0;
+            if (k > 0) cnt = orc_reservoir_weighted(&c, (uint64_t)(layer * T + t), n, k, w, dst);
+            if (cnt < 0) {
+                *status = -1;
+                cnt = 0;
+            }
+            lay_has[t] = 1; /* :206-208 */
+            has_nodes[t] = 1;
+            for (int64_t s = 0; s < cnt; s++) { /* :216-221 */
+                int64_t e = live[dst[s]];
+                int64_t v = b->key.p[e], vt = b->ts.p[e];
+                vpush(&lay_s[t], v);
+                vpush(&lay_t[t], vt);
+                int f;
+                *imap_slot(&h.to_local[t], v, &f) = o->samples[t].n;
+                vpush(&o->samples[t], v);
+                vpush(&o->ts[t], vt);
+            }
+            for (int64_t s = 0; s < cnt; s++) b->alive.p[live[dst[s]]] = 0; /* :220 remove */
+            free(live);
+            free(w);
+            free(dst);
+        }
+        if (layer < H - 1) /* :224-240 */
+            for (int t = 0; t < T; t++)
+                if (lay_has[t]) hgt_update_budget(&h, t, lay_s[t].p, lay_t[t].p, lay_s[t].n);
+    }
+    /* :244-268 rebuild the edges among the sampled nodes */
+    int64_t res[ORC_HGT_MAX_NEIGHBORS], scratch[2 * ORC_HGT_MAX_NEIGHBORS];
+    for (int r = 0; r < R && *status == 0; r++) {
+        int src = rel_src[r], dst = rel_dst[r];
+        orc_ctx ce;
+        orc_ctx_init(&ce, rng, ORC_TAG_HGT | ((uint32_t)(r + 1) << 8));
+        imap *tl = &h.to_local[src];
+        for (int64_t i = 0; i < o->samples[dst].n; i++) { /* :254 */
+            int64_t w = o->samples[dst].p[i];
+            int64_t b = ptrs[r][w], e = ptrs[r][w + 1];
+            int64_t len = e - b;
+            int64_t k = len < ORC_HGT_MAX_NEIGHBORS ? len : ORC_HGT_MAX_NEIGHBORS; /* :258 */
+            int64_t cnt = orc_reservoir(&ce, (uint64_t)i, 0, len, k, res, scratch,
+                                        edge_reservoir_algo == ORC_RES_AUTO ? ORC_RES_TICKETS : edge_reservoir_algo);
+            for (int64_t s = 0; s < cnt; s++) { /* :261-266 */
+                int64_t ep = b + res[s];
+                int64_t v = indices[r][ep];
+                uint64_t hh = (uint64_t)v * 0x9E3779B97F4A7C15ULL;
+                int64_t sl = (int64_t)(hh >> 20) & (tl->cap - 1);
+                while (tl->k[sl] != INT64_MIN && tl->k[sl] != v) sl = (sl + 1) & (tl->cap - 1);
+                if (tl->k[sl] == v) {
+                    vpush(&o->rows[r], tl->v[sl]);
+                    vpush(&o->cols[r], i);
+                    vpush(&o->eidx[r], ep);
+                }
+            }
+        }
+    }
+    for (int t = 0; t < T; t++) {
+        imap_free(&h.to_local[t]);
+        imap_free(&h.budget[t].slot);
+        vfree(&h.budget[t].key);
+        vfree(&h.budget[t].ts);
+        vfree(&h.budget[t].alive);
+        free(h.budget[t].score);
+        vfree(&lay_s[t]);
+        vfree(&lay_t[t]);
+    }
+    free(h.to_local);
+    free(h.budget);
+    free(has_nodes);
+    free(lay_s);
+    free(lay_t);
+    free(lay_has);
+    return o;
 }

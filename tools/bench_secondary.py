@@ -1,0 +1,40 @@
+"""Secondary configs of BASELINE.json on one MI355X (not the headline bench): cfg3 random_walk
+(node2vec p=q=1, walk_len 80, 1M starts, RMAT-24) and the general-(p,q) variant.  Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tch-geometric_amd"))
+from tch_geometric import _cabi  # noqa: E402
+
+dev = torch.device("cuda:0")
+scale = int(os.environ.get("SCALE", "24"))
+n = 1 << scale
+row, col = _cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
+ptrs, idx, perm = _cabi.coo_to_csx(row, col, n, n, False)      # CSR for walks
+del row, col, perm
+g = _cabi.graph_view(ptrs, idx)
+n_walkers, L = 1 << 20, 80
+start = _cabi.seed_batches(0x57A27, 0, 1, n_walkers, n, dev)[0].contiguous()
+res = {}
+for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)):
+    _cabi.random_walk(g, start, L, p, q, 0, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for r in range(reps):
+        w = _cabi.random_walk(g, start, L, p, q, 0, r + 1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    steps = int((w[:, 1:] >= 0).sum().item())
+    cells = n_walkers * (L + 1)
+    alg = 32 * steps + 8 * n_walkers + 8 * (cells - steps)       # 32 B per executed step, 8 B per -1 cell
+    res[name] = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3,
+                 "algorithmic_GBps": alg / ms / 1e6, "frac_of_8TBps": alg / ms / 1e6 / 8000.0}
+print(json.dumps({"config": "random_walk walk_length=80, %d starts, RMAT-%d CSR" % (n_walkers, scale), **res}))
