@@ -156,6 +156,37 @@ TG_API int tg_neg_workspace_bytes(const tg_neg_problem *problem, int64_t *bytes)
 TG_API int tg_neg_sample(const tg_neg_problem *problem, const tg_rng *rng, const tg_neg_out *out, void *workspace,
                          void *stream);
 
+/* hgt_sampling (src/algo/hgt_sampling.rs:138-278; binding python.rs:399-482).  Host arrays are indexed by node
+ * type (`node_types` order) and relation (`edge_types` order); graphs are CSC, graphs[r].timestamps is the
+ * relation's row_timestamps or NULL.  All state lives in the caller's workspace; nothing synchronises. */
+typedef struct {
+    int32_t n_types, n_rels, n_hops;
+    int32_t has_timerange;          /* timerange = [tr_lo, tr_hi) (python.rs:450) */
+    const int32_t *rel_src;         /* host [n_rels] */
+    const int32_t *rel_dst;         /* host [n_rels] */
+    const tg_graph *graphs;         /* host [n_rels] */
+    const int64_t *const *inputs;   /* host [n_types] device pointers (NULL when absent) */
+    const int64_t *const *input_ts; /* host [n_types] device pointers, or NULL: no input timestamps */
+    const int64_t *n_inputs;        /* host [n_types]; < 0: the type has no entry in `inputs` */
+    const int64_t *num_samples;     /* host [n_types * n_hops]; < 0: the type has no entry in `num_samples` */
+    int64_t tr_lo, tr_hi;
+} tg_hgt_problem;
+
+typedef struct {
+    int64_t *const *samples;    /* host [n_types] device buffers, capacity max(n_inputs,0) + sum of num_samples */
+    int64_t *const *sample_ts;  /* host [n_types], same capacity */
+    int64_t *const *rows;       /* host [n_rels] device buffers, capacity 50 * capacity(samples[dst]) */
+    int64_t *const *cols;       /* host [n_rels] */
+    int64_t *const *edge_index; /* host [n_rels] */
+    int64_t *n_samples;         /* device [n_types] */
+    int64_t *n_edges;           /* device [n_rels] */
+    int32_t *panic;             /* device [1]: 1 where the reference would panic */
+} tg_hgt_out;
+
+TG_API int tg_hgt_workspace_bytes(const tg_hgt_problem *problem, int64_t *bytes);
+TG_API int tg_hgt_sample(const tg_hgt_problem *problem, const tg_rng *rng, const tg_hgt_out *out, void *workspace,
+                         int64_t workspace_bytes, void *stream);
+
 /* ---- synthetic inputs of the measurement harness ---- */
 
 /* R-MAT edge list: n_edges edges over 2^scale vertices, (a,b,c,d) =

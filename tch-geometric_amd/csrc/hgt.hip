@@ -1,0 +1,650 @@
+// hgt_sampling on gfx950 -- replaces src/algo/hgt_sampling.rs:13-278 (reference).
+//
+// The reference is sequential and order-sensitive: budgets are HashMaps whose f64 scores accumulate in
+// visiting order, samples are drawn by a weighted reservoir over the budget in iteration order, and local
+// ids follow insertion order.  This file restates each step as an order-preserving parallel primitive on
+// device-resident state, launched from ONE host function without any synchronisation (sizes the host
+// cannot know are handled with capacity upper bounds + device-side counters):
+//
+//  state per node type  nodes/ts lists, `to_local` hash map (node -> slot), budget = entry arrays
+//                       (key, score f64, ts, alive) in INSERTION order + hash map key -> entry
+//  update_budget        per relation into the sampled type: contributions (sample j, neighbour i < 50,
+//                       hgt_sampling.rs:72 takes a PREFIX of the column) are generated in the reference's
+//                       order; new keys get entries in first-contribution order (min-position hash map +
+//                       prefix sum); scores are summed per entry in contribution order after a stable
+//                       radix sort by entry (rocPRIM) -- same f64 rounding as the reference's `+=` chain
+//  sample_from          live entries compacted in entry order, then the reference's weighted reservoir
+//                       (sampling.rs:28-55) by one wavefront: left-to-right f64 running sum kept exactly,
+//                       one addressed Philox draw per candidate
+//  edges                lane per destination node: <= 50 column positions (reservoir by tickets when the
+//                       column is longer), kept when the source is a sampled node; compaction by prefix sum
+//
+// Canonical order: node types in `node_types` order, relations in `edge_types` order (the reference's
+// HashMap order is not reproducible).  HBM traffic is tiny next to neighbor sampling; this path is
+// launch-bound (~100 small kernels per call).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "tg_device.h"
+#include "tg_host.h"
+#include "tg_map.h"
+
+namespace tg {
+
+constexpr int HGT_MAX_NB = 50; // MAX_NEIGHBORS hgt_sampling.rs:10
+constexpr int64_t HGT_NAN_TS = -1;
+constexpr int64_t SORT_PAD = INT64_MAX;
+
+// device counters of one node type
+struct HgtTypeCtr {
+    int64_t n_nodes;   // length of the nodes list
+    int64_t lay_begin; // nodes[lay_begin, lay_end) = what the next update_budget processes
+    int64_t lay_end;
+    int64_t n_budget; // budget entries ever created
+    int64_t present;  // budget_dict has an entry for the type
+};
+
+struct HgtType {
+    int64_t *nodes, *ts;
+    int64_t *tl_keys, *tl_vals, tl_mask;
+    int64_t *bkey, *bts, *balive;
+    double *bscore;
+    int64_t *bm_keys, *bm_vals, bm_mask;
+    HgtTypeCtr *ctr;
+};
+
+// ---------------------------------------------------------------- generic single-workgroup scan
+// out[i] = sum of in[0..i), total[0] = sum of in[0..n) (+ *add_to if given: total accumulates)
+__global__ void scan_i64_kernel(const int64_t *__restrict__ in, const int64_t *n_ptr, int64_t n_imm, int64_t *out,
+                                int64_t *total) {
+    __shared__ int64_t wave_tot[16];
+    __shared__ int64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int64_t n = n_ptr ? *n_ptr : n_imm;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += blockDim.x) {
+        const int64_t i = base + tid;
+        const int64_t v = (i < n) ? in[i] : 0;
+        const int64_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int64_t off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (i < n) out[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 0) {
+            int64_t s = 0;
+            for (int w = 0; w < n_waves; ++w) s += wave_tot[w];
+            carry_s += s;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) total[0] = carry_s;
+}
+
+// ---------------------------------------------------------------- inputs (hgt_sampling.rs:167-180)
+__global__ void hgt_init_inputs_kernel(HgtType ty, const int64_t *__restrict__ inputs,
+                                       const int64_t *__restrict__ input_ts, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = inputs[i];
+        ty.nodes[i] = v;
+        ty.ts[i] = input_ts ? input_ts[i] : HGT_NAN_TS;
+        const int64_t s = map_slot_insert(ty.tl_keys, ty.tl_mask, v);
+        atomicMax(reinterpret_cast<long long *>(&ty.tl_vals[s]), (long long)i); // insert overwrites: last slot wins
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ty.ctr->n_nodes = n;
+        ty.ctr->lay_begin = 0;
+        ty.ctr->lay_end = n;
+    }
+}
+
+// ---------------------------------------------------------------- update_budget (hgt_sampling.rs:27-102)
+// per sample of the layer: number of contributions = min(deg, 50); also marks the source budget present
+__global__ void hgt_contrib_count_kernel(HgtType dst, HgtTypeCtr *src_ctr, const int64_t *__restrict__ ptrs,
+                                         int64_t *ccnt, int64_t cap) {
+    const int64_t b = dst.ctr->lay_begin, e = dst.ctr->lay_end;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cap; j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = 0;
+        if (b + j < e) {
+            const int64_t w = dst.nodes[b + j];
+            c = min(ptrs[w + 1] - ptrs[w], (int64_t)HGT_MAX_NB);
+        }
+        ccnt[j] = c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && e > b) src_ctr->present = 1; // :38-40, :55
+}
+// one lane per (sample j, neighbour i): key or -1, 1/count, timestamp  (:58-100)
+__global__ void hgt_contrib_gen_kernel(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
+                                       const int64_t *__restrict__ indices, const int64_t *__restrict__ edge_ts,
+                                       int has_timerange, int64_t tr_lo, int64_t tr_hi, const int64_t *ccnt,
+                                       const int64_t *coff, int64_t cap, int64_t *ckey, double *cinv, int64_t *cts) {
+    const int64_t b = dst.ctr->lay_begin, e = dst.ctr->lay_end;
+    const int64_t total = cap * HGT_MAX_NB;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = q / HGT_MAX_NB, i = q - j * HGT_MAX_NB;
+        if (b + j >= e) continue;
+        const int64_t cnt = ccnt[j];
+        if (i >= cnt) continue;
+        const int64_t p = coff[j] + i;
+        const int64_t w = dst.nodes[b + j];
+        const int64_t ep = ptrs[w] + i; // the first min(deg,50) neighbours, :72
+        const int64_t v = indices[ep];
+        int64_t key = v;
+        int64_t v_ts = edge_ts ? edge_ts[ep] : HGT_NAN_TS; // :82
+        if (v_ts == HGT_NAN_TS) v_ts = dst.ts[b + j];      // :83-85
+        if (map_slot_find(src.tl_keys, src.tl_mask, v) >= 0) key = -1; // :80 already sampled
+        if (has_timerange && v_ts != HGT_NAN_TS && !(tr_lo <= v_ts && v_ts < tr_hi)) key = -1; // :88-92
+        ckey[p] = key;
+        cinv[p] = 1.0 / (double)cnt; // :73
+        cts[p] = v_ts;
+    }
+}
+// existing entry -> its index; new key -> remember the smallest contribution position
+__global__ void hgt_contrib_slots_kernel(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
+                                         int64_t *cslot, int64_t *tmp_keys, int64_t *tmp_vals, int64_t tmp_mask) {
+    const int64_t n = *mc;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = ckey[p];
+        if (v < 0) {
+            cslot[p] = -2;
+            continue;
+        }
+        const int64_t s = map_slot_find(src.bm_keys, src.bm_mask, v);
+        if (s >= 0) {
+            cslot[p] = src.bm_vals[s];
+        } else {
+            cslot[p] = -1;
+            const int64_t t = map_slot_insert(tmp_keys, tmp_mask, v);
+            atomicMin(reinterpret_cast<long long *>(&tmp_vals[t]), (long long)p);
+        }
+    }
+}
+__global__ void hgt_first_flags_kernel(const int64_t *mc, const int64_t *__restrict__ ckey,
+                                       const int64_t *__restrict__ cslot, const int64_t *tmp_keys,
+                                       const int64_t *tmp_vals, int64_t tmp_mask, int64_t *flag) {
+    const int64_t n = *mc;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t f = 0;
+        if (cslot[p] == -1) {
+            const int64_t t = map_slot_find(tmp_keys, tmp_mask, ckey[p]);
+            f = (tmp_vals[t] == p);
+        }
+        flag[p] = f;
+    }
+}
+// new keys get entries n_budget + rank(first contribution); the entry order is the reference's insertion order
+__global__ void hgt_new_slots_kernel(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
+                                     int64_t *cslot, const int64_t *tmp_keys, const int64_t *tmp_vals,
+                                     int64_t tmp_mask, const int64_t *__restrict__ rank) {
+    const int64_t n = *mc, nb = src.ctr->n_budget;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (cslot[p] != -1) continue;
+        const int64_t v = ckey[p];
+        const int64_t t = map_slot_find(tmp_keys, tmp_mask, v);
+        const int64_t first = tmp_vals[t];
+        const int64_t entry = nb + rank[first];
+        cslot[p] = entry;
+        if (first == p) { // :95 entry(v).or_default()
+            src.bkey[entry] = v;
+            src.bscore[entry] = 0.0;
+            src.bts[entry] = 0;
+            src.balive[entry] = 1;
+            const int64_t s = map_slot_insert(src.bm_keys, src.bm_mask, v);
+            src.bm_vals[s] = entry;
+        }
+    }
+}
+__global__ void hgt_bump_budget_kernel(HgtTypeCtr *ctr, const int64_t *n_new) { ctr->n_budget += *n_new; }
+// sort input: key = entry (padding sorts last), value = contribution position
+__global__ void hgt_sort_input_kernel(const int64_t *mc, const int64_t *__restrict__ cslot, int64_t cap,
+                                      int64_t *skey, int64_t *sval) {
+    const int64_t n = *mc;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
+        skey[p] = (p < n && cslot[p] >= 0) ? cslot[p] : SORT_PAD;
+        sval[p] = p;
+    }
+}
+// one lane per entry run: score += 1/deg in contribution order (:96), timestamp = the last one (:97)
+__global__ void hgt_accumulate_kernel(HgtType src, const int64_t *__restrict__ skey, const int64_t *__restrict__ sval,
+                                      int64_t cap, const double *__restrict__ cinv, const int64_t *__restrict__ cts) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < cap; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t entry = skey[q];
+        if (entry == SORT_PAD) continue;
+        if (q > 0 && skey[q - 1] == entry) continue; // not the head of its run
+        double score = src.bscore[entry];
+        int64_t ts = src.bts[entry];
+        for (int64_t r = q; r < cap && skey[r] == entry; ++r) {
+            const int64_t p = sval[r];
+            score = score + cinv[p];
+            ts = cts[p];
+        }
+        src.bscore[entry] = score;
+        src.bts[entry] = ts;
+    }
+}
+
+// ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
+__global__ void hgt_live_flags_kernel(HgtType ty, int64_t cap, int64_t *flag) {
+    const int64_t n = ty.ctr->n_budget;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x)
+        flag[i] = (i < n) ? ty.balive[i] : 0;
+}
+__global__ void hgt_live_list_kernel(HgtType ty, const int64_t *__restrict__ flag, const int64_t *__restrict__ rank,
+                                     int64_t *live) {
+    const int64_t n = ty.ctr->n_budget;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (flag[i]) live[rank[i]] = i;
+}
+// one wavefront: the reference's weighted reservoir over the live entries, weights score^2 (:110)
+__global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_ptr, const int64_t *__restrict__ live,
+                                              int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
+                                              int64_t *chosen, int64_t *n_chosen, int *panic) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *slot_pos = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *slot_rank = slot_pos + k;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = *n_live_ptr;
+    if (k < 0) { // num_samples has no entry for this type: the reference panics once the budget exists (:202)
+        if (lane == 0) {
+            if (ty.ctr->present) *panic = 1;
+            *n_chosen = 0;
+        }
+        return;
+    }
+    if (k == 0) {
+        if (lane == 0) *n_chosen = 0;
+        return;
+    }
+    const CallKey ck = call_key(seed, call_id, TAG_HGT);
+    for (int64_t s = lane; s < k; s += 64) slot_rank[s] = 0;
+    wave_lds_handoff();
+    double w_sum = 0.0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t m = base + lane;
+        const bool ok = m < n;
+        double wv = 0.0;
+        if (ok) {
+            const double sc = ty.bscore[live[m]];
+            wv = sc * sc;
+        }
+        double running = w_sum, pref = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) { // left-to-right sum, sampling.rs:40,48
+            running = running + __shfl(wv, l, 64);
+            if (lane == l) pref = running;
+        }
+        w_sum = running;
+        int64_t hit = -1;
+        if (ok && m >= k) {
+            if (!(0.0 < pref)) {
+                *panic = 1;
+            } else {
+                const Draw d = draw(ck, draw_id, (uint32_t)m, D1_WEIGHTED);
+                const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                if (j < wv) hit = (int64_t)bounded64(d.b(), (uint64_t)k);
+            }
+        }
+        if (ok && m < k) slot_pos[m] = (uint32_t)m;
+        if (hit >= 0) atomicMax(&slot_rank[hit], (uint32_t)m);
+        wave_lds_handoff();
+        if (hit >= 0 && slot_rank[hit] == (uint32_t)m) slot_pos[hit] = (uint32_t)m;
+        wave_lds_handoff();
+    }
+    const int64_t cnt = min(n, k);
+    for (int64_t s = lane; s < cnt; s += 64) chosen[s] = (int64_t)slot_pos[s];
+    if (lane == 0) *n_chosen = cnt;
+}
+// :213-221 move the samples to the node list, give them local ids, erase them from the budget
+__global__ void hgt_append_kernel(HgtType ty, const int64_t *__restrict__ live, const int64_t *__restrict__ chosen,
+                                  const int64_t *n_chosen) {
+    const int64_t cnt = *n_chosen, base = ty.ctr->n_nodes;
+    for (int64_t s = threadIdx.x; s < cnt; s += blockDim.x) {
+        const int64_t entry = live[chosen[s]];
+        const int64_t v = ty.bkey[entry];
+        ty.nodes[base + s] = v;
+        ty.ts[base + s] = ty.bts[entry];
+        const int64_t h = map_slot_insert(ty.tl_keys, ty.tl_mask, v);
+        ty.tl_vals[h] = base + s;
+        ty.balive[entry] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ty.ctr->lay_begin = base;
+        ty.ctr->lay_end = base + cnt;
+        ty.ctr->n_nodes = base + cnt;
+    }
+}
+__global__ void hgt_empty_layer_kernel(HgtTypeCtr *ctr) { // a type without a budget contributes no samples
+    ctr->lay_begin = ctr->n_nodes;
+    ctr->lay_end = ctr->n_nodes;
+}
+
+// ---------------------------------------------------------------- edges (hgt_sampling.rs:244-268)
+// one lane per destination node; candidates at a fixed stride of 50, -1 where dropped
+__global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
+                                           const int64_t *__restrict__ indices, int64_t cap_nodes, uint64_t seed,
+                                           uint64_t call_id, uint32_t tag, int64_t *cand_j, int64_t *cand_ep) {
+    __shared__ uint32_t keys[64 * HGT_MAX_NB], vals[64 * HGT_MAX_NB];
+    const int lane = threadIdx.x & 63;
+    uint32_t *K = keys + lane * HGT_MAX_NB, *V = vals + lane * HGT_MAX_NB;
+    const int64_t n_nodes = dst.ctr->n_nodes;
+    const CallKey ck = call_key(seed, call_id, tag);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap_nodes;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t *cj = cand_j + i * HGT_MAX_NB, *ce = cand_ep + i * HGT_MAX_NB;
+        if (i >= n_nodes) {
+            for (int s = 0; s < HGT_MAX_NB; ++s) cj[s] = -1;
+            continue;
+        }
+        const int64_t w = dst.nodes[i];
+        const int64_t b = ptrs[w], len = ptrs[w + 1] - b;
+        const int k = (int)min(len, (int64_t)HGT_MAX_NB); // :258
+        Draw d;
+        for (int s = 0; s < HGT_MAX_NB; ++s) {
+            int64_t j = -1, ep = -1;
+            if (s < k) {
+                int64_t pos = s;
+                if (len > HGT_MAX_NB) { // reservoir by tickets, k = 50
+                    const uint32_t n = (uint32_t)len;
+                    const uint32_t m = (n - 1u) - (uint32_t)s;
+                    if ((s & 1) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 1), 0u);
+                    const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                    uint32_t tr = r, tl = last;
+                    for (int q = 0; q < s; ++q) {
+                        tr = (K[q] == r) ? V[q] : tr;
+                        tl = (K[q] == last) ? V[q] : tl;
+                    }
+                    K[s] = r;
+                    V[s] = tl;
+                    pos = (tr < n - (uint32_t)k) ? (int64_t)k + tr : (int64_t)s;
+                }
+                ep = b + pos;
+                const int64_t v = indices[ep];
+                const int64_t h = map_slot_find(src.tl_keys, src.tl_mask, v); // :263
+                if (h >= 0) j = src.tl_vals[h];
+            }
+            cj[s] = j;
+            ce[s] = ep;
+        }
+    }
+}
+__global__ void hgt_edge_flags_kernel(const int64_t *__restrict__ cand_j, int64_t n, int64_t *flag) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
+        flag[q] = cand_j[q] >= 0;
+}
+__global__ void hgt_edge_emit_kernel(const int64_t *__restrict__ cand_j, const int64_t *__restrict__ cand_ep,
+                                     const int64_t *__restrict__ rank, int64_t n, int64_t *rows, int64_t *cols,
+                                     int64_t *eidx) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        if (cand_j[q] < 0) continue;
+        const int64_t e = rank[q];
+        rows[e] = cand_j[q];        // :264 j
+        cols[e] = q / HGT_MAX_NB;   //      i
+        eidx[e] = cand_ep[q];       //      edge_ptr
+    }
+}
+__global__ void hgt_copy_counts_kernel(const HgtTypeCtr *ctr, int n_types, int64_t *n_samples) {
+    if (threadIdx.x < n_types) n_samples[threadIdx.x] = ctr[threadIdx.x].n_nodes;
+}
+
+// ---------------------------------------------------------------- workspace layout
+struct HgtPlan {
+    int T, R, H;
+    std::vector<int64_t> cap_nodes, cap_budget, tl_cap, bm_cap;
+    int64_t max_layer, mc_cap, tmp_cap, max_budget, max_k, edge_cap, scan_cap;
+    size_t sort_temp_bytes;
+    size_t total_bytes;
+};
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
+    pl.T = pb->n_types;
+    pl.R = pb->n_rels;
+    pl.H = pb->n_hops;
+    pl.cap_nodes.assign(pl.T, 0);
+    pl.cap_budget.assign(pl.T, 0);
+    pl.max_layer = 1;
+    pl.max_k = 1;
+    std::vector<int64_t> upd(pl.T, 0); // nodes of the type that an update_budget ever processes
+    for (int t = 0; t < pl.T; ++t) {
+        const int64_t n_in = pb->n_inputs[t] > 0 ? pb->n_inputs[t] : 0;
+        pl.cap_nodes[t] = n_in;
+        upd[t] = n_in;
+        if (n_in > pl.max_layer) pl.max_layer = n_in;
+        for (int l = 0; l < pl.H; ++l) {
+            const int64_t k = pb->num_samples[(size_t)t * pl.H + l];
+            if (k > 0) {
+                pl.cap_nodes[t] += k;
+                if (l < pl.H - 1) upd[t] += k;
+                if (k > pl.max_layer) pl.max_layer = k;
+                if (k > pl.max_k) pl.max_k = k;
+            }
+        }
+    }
+    for (int r = 0; r < pl.R; ++r) pl.cap_budget[pb->rel_src[r]] += upd[pb->rel_dst[r]] * HGT_MAX_NB;
+    pl.max_budget = 1;
+    int64_t max_nodes = 1;
+    pl.tl_cap.assign(pl.T, 0);
+    pl.bm_cap.assign(pl.T, 0);
+    for (int t = 0; t < pl.T; ++t) {
+        if (pl.cap_budget[t] < 1) pl.cap_budget[t] = 1;
+        // a budget can never hold more live entries than were inserted; samples per layer are capped by both
+        if (pl.cap_budget[t] > pl.max_budget) pl.max_budget = pl.cap_budget[t];
+        if (pl.cap_nodes[t] > max_nodes) max_nodes = pl.cap_nodes[t];
+        pl.tl_cap[t] = pow2_at_least(2 * pl.cap_nodes[t] + 2);
+        pl.bm_cap[t] = pow2_at_least(2 * pl.cap_budget[t] + 2);
+    }
+    pl.mc_cap = pl.max_layer * HGT_MAX_NB;
+    pl.tmp_cap = pow2_at_least(2 * pl.mc_cap + 2);
+    pl.edge_cap = max_nodes * HGT_MAX_NB;
+    pl.scan_cap = std::max(std::max(pl.mc_cap, pl.max_budget), pl.edge_cap);
+    size_t st = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, st, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr,
+                                             (int64_t *)nullptr, (size_t)pl.mc_cap, 0, 64, (hipStream_t)0, false);
+    if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
+    pl.sort_temp_bytes = st;
+    size_t b = 0;
+    b += align16(sizeof(HgtTypeCtr) * pl.T + 64); // counters + misc scalars
+    for (int t = 0; t < pl.T; ++t) {
+        b += align16(8 * (size_t)pl.tl_cap[t]) * 2;
+        b += align16(8 * (size_t)pl.cap_budget[t]) * 4;
+        b += align16(8 * (size_t)pl.bm_cap[t]) * 2;
+    }
+    b += align16(8 * (size_t)pl.max_layer) * 2;  // ccnt, coff
+    b += align16(8 * (size_t)pl.mc_cap) * 8;     // ckey, cinv, cts, cslot, skey, sval, skey2, sval2
+    b += align16(8 * (size_t)pl.tmp_cap) * 2;    // tmp map
+    b += align16(8 * (size_t)pl.scan_cap) * 2;   // flag, rank
+    b += align16(8 * (size_t)pl.max_budget);     // live
+    b += align16(8 * (size_t)pl.max_k);          // chosen
+    b += align16(8 * (size_t)pl.edge_cap) * 2;   // cand_j, cand_ep
+    b += align16(pl.sort_temp_bytes);
+    pl.total_bytes = b + 256;
+    return TG_OK;
+}
+
+} // namespace tg
+
+extern "C" int tg_hgt_workspace_bytes(const tg_hgt_problem *pb, int64_t *bytes) {
+    TG_REQUIRE(pb && bytes, "tg_hgt_workspace_bytes: null argument");
+    TG_REQUIRE(pb->n_types >= 1 && pb->n_types <= 1024 && pb->n_rels >= 0 && pb->n_hops >= 0,
+               "tg_hgt_workspace_bytes: bad sizes");
+    tg::HgtPlan pl;
+    int rc = tg::hgt_make_plan(pb, pl);
+    if (rc != TG_OK) return rc;
+    *bytes = (int64_t)pl.total_bytes;
+    return TG_OK;
+}
+
+extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const tg_hgt_out *out, void *workspace,
+                             int64_t workspace_bytes, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(pb && rng && out && workspace, "tg_hgt_sample: null argument");
+    TG_REQUIRE(pb->n_types >= 1 && pb->n_types <= 1024 && pb->n_rels >= 0 && pb->n_hops >= 0, "tg_hgt_sample: bad sizes");
+    hipStream_t stream = (hipStream_t)stream_;
+    HgtPlan pl;
+    int rc = hgt_make_plan(pb, pl);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE((size_t)workspace_bytes >= pl.total_bytes, "tg_hgt_sample: workspace too small (%lld < %lld)",
+               (long long)workspace_bytes, (long long)pl.total_bytes);
+    const int T = pl.T, R = pl.R, H = pl.H;
+
+    // ---- carve the workspace
+    unsigned char *base = reinterpret_cast<unsigned char *>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *p = base + off;
+        off += align16(bytes);
+        return p;
+    };
+    unsigned char *ctr_block = take(sizeof(HgtTypeCtr) * T + 64);
+    HgtTypeCtr *ctr = reinterpret_cast<HgtTypeCtr *>(ctr_block);
+    int64_t *scal = reinterpret_cast<int64_t *>(ctr_block + sizeof(HgtTypeCtr) * T); // [0] mc [1] n_new [2] n_live
+                                                                                     // [3] n_chosen [4] n_edges tmp
+    int *panic = reinterpret_cast<int *>(scal + 6);
+    TG_HIP(hipMemsetAsync(ctr_block, 0, sizeof(HgtTypeCtr) * T + 64, stream));
+    std::vector<HgtType> ty((size_t)T);
+    for (int t = 0; t < T; ++t) {
+        HgtType &y = ty[t];
+        y.nodes = out->samples[t];
+        y.ts = out->sample_ts[t];
+        y.tl_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tl_cap[t]));
+        y.tl_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tl_cap[t]));
+        y.tl_mask = pl.tl_cap[t] - 1;
+        y.bkey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
+        y.bts = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
+        y.balive = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
+        y.bscore = reinterpret_cast<double *>(take(8 * (size_t)pl.cap_budget[t]));
+        y.bm_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.bm_cap[t]));
+        y.bm_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.bm_cap[t]));
+        y.bm_mask = pl.bm_cap[t] - 1;
+        y.ctr = ctr + t;
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tl_cap[t])), dim3(256), 0, stream, y.tl_keys, pl.tl_cap[t],
+                           MAP_EMPTY);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tl_cap[t])), dim3(256), 0, stream, y.tl_vals, pl.tl_cap[t],
+                           (int64_t)-1);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.bm_cap[t])), dim3(256), 0, stream, y.bm_keys, pl.bm_cap[t],
+                           MAP_EMPTY);
+    }
+    int64_t *ccnt = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
+    int64_t *coff = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
+    int64_t *ckey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    double *cinv = reinterpret_cast<double *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *cts = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *cslot = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *skey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *sval = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *skey2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *sval2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+    int64_t *tmp_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
+    int64_t *tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
+    int64_t *flag = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
+    int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
+    int64_t *live = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_budget));
+    int64_t *chosen = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
+    int64_t *cand_j = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
+    int64_t *cand_ep = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
+    void *sort_temp = take(pl.sort_temp_bytes);
+
+    // ---- update_budget for the current layer of node type nt (:27-102)
+    auto update_budget = [&](int nt) -> int {
+        for (int r = 0; r < R; ++r) { // :47 canonical relation order
+            if (pb->rel_dst[r] != nt) continue;
+            const int st = pb->rel_src[r];
+            const tg_graph &g = pb->graphs[r];
+            hipLaunchKernelGGL(hgt_contrib_count_kernel, dim3(grid_1d(pl.max_layer)), dim3(256), 0, stream, ty[nt],
+                               ctr + st, g.ptrs, ccnt, pl.max_layer);
+            hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, ccnt, (const int64_t *)nullptr,
+                               pl.max_layer, coff, scal + 0);
+            hipLaunchKernelGGL(hgt_contrib_gen_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[nt], ty[st],
+                               g.ptrs, g.indices, g.timestamps, pb->has_timerange, pb->tr_lo, pb->tr_hi, ccnt, coff,
+                               pl.max_layer, ckey, cinv, cts);
+            hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tmp_cap)), dim3(256), 0, stream, tmp_keys, pl.tmp_cap,
+                               MAP_EMPTY);
+            hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tmp_cap)), dim3(256), 0, stream, tmp_vals, pl.tmp_cap,
+                               (int64_t)INT64_MAX);
+            hipLaunchKernelGGL(hgt_contrib_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st],
+                               scal + 0, ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1);
+            hipLaunchKernelGGL(hgt_first_flags_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, ckey,
+                               cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, flag);
+            hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, flag, scal + 0, (int64_t)0, rank,
+                               scal + 1);
+            hipLaunchKernelGGL(hgt_new_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], scal + 0,
+                               ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, rank);
+            hipLaunchKernelGGL(hgt_bump_budget_kernel, dim3(1), dim3(1), 0, stream, ctr + st, scal + 1);
+            hipLaunchKernelGGL(hgt_sort_input_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, cslot,
+                               pl.mc_cap, skey, sval);
+            size_t stb = pl.sort_temp_bytes;
+            TG_HIP(rocprim::radix_sort_pairs(sort_temp, stb, skey, skey2, sval, sval2, (size_t)pl.mc_cap, 0, 64, stream,
+                                             false)); // stable: equal entries keep contribution order
+            hipLaunchKernelGGL(hgt_accumulate_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], skey2,
+                               sval2, pl.mc_cap, cinv, cts);
+            TG_LAUNCH_CHECK();
+        }
+        return TG_OK;
+    };
+
+    // ---- :167-196 inputs, then the first budgets
+    for (int t = 0; t < T; ++t) {
+        const int64_t n_in = pb->n_inputs[t];
+        if (n_in > 0) {
+            TG_REQUIRE(pb->inputs[t], "tg_hgt_sample: node type %d has n_inputs > 0 but no pointer", t);
+            hipLaunchKernelGGL(hgt_init_inputs_kernel, dim3(grid_1d(n_in)), dim3(256), 0, stream, ty[t], pb->inputs[t],
+                               pb->input_ts ? pb->input_ts[t] : (const int64_t *)nullptr, n_in);
+        }
+    }
+    TG_LAUNCH_CHECK();
+    for (int t = 0; t < T; ++t)
+        if (pb->n_inputs[t] >= 0) {
+            rc = update_budget(t);
+            if (rc != TG_OK) return rc;
+        }
+    // ---- :198-242 layers
+    for (int layer = 0; layer < H; ++layer) {
+        for (int t = 0; t < T; ++t) { // :201 every type that owns a budget samples from it
+            const int64_t k = pb->num_samples[(size_t)t * H + layer];
+            hipLaunchKernelGGL(hgt_live_flags_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t],
+                               pl.cap_budget[t], flag);
+            hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, flag, (const int64_t *)nullptr,
+                               pl.cap_budget[t], rank, scal + 2);
+            hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], flag,
+                               rank, live);
+            const size_t lds = (size_t)(k > 0 ? k : 1) * 8;
+            TG_REQUIRE(lds <= 64 * 1024, "tg_hgt_sample: num_samples %lld exceeds 8192 per layer", (long long)k);
+            hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(64), lds, stream, ty[t], scal + 2, live, k,
+                               rng->seed, rng->call_id, (uint64_t)((int64_t)layer * T + t), chosen, scal + 3, panic);
+            hipLaunchKernelGGL(hgt_append_kernel, dim3(1), dim3(256), 0, stream, ty[t], live, chosen, scal + 3);
+            TG_LAUNCH_CHECK();
+        }
+        if (layer < H - 1)
+            for (int t = 0; t < T; ++t) { // :227 (types without samples return at :38-40)
+                rc = update_budget(t);
+                if (rc != TG_OK) return rc;
+            }
+    }
+    // ---- :244-268 edges among the sampled nodes
+    for (int r = 0; r < R; ++r) {
+        const int st = pb->rel_src[r], dt = pb->rel_dst[r];
+        const tg_graph &g = pb->graphs[r];
+        const int64_t cap_n = pl.cap_nodes[dt] > 0 ? pl.cap_nodes[dt] : 1;
+        const int64_t nq = cap_n * HGT_MAX_NB;
+        hipLaunchKernelGGL(hgt_edge_candidates_kernel, dim3((unsigned)((cap_n + 63) / 64)), dim3(64), 0, stream, ty[dt],
+                           ty[st], g.ptrs, g.indices, cap_n, rng->seed, rng->call_id,
+                           TAG_HGT | ((uint32_t)(r + 1) << 8), cand_j, cand_ep);
+        hipLaunchKernelGGL(hgt_edge_flags_kernel, dim3(grid_1d(nq)), dim3(256), 0, stream, cand_j, nq, flag);
+        hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, flag, (const int64_t *)nullptr, nq, rank,
+                           out->n_edges + r);
+        hipLaunchKernelGGL(hgt_edge_emit_kernel, dim3(grid_1d(nq)), dim3(256), 0, stream, cand_j, cand_ep, rank, nq,
+                           out->rows[r], out->cols[r], out->edge_index[r]);
+        TG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(hgt_copy_counts_kernel, dim3(1), dim3(1024), 0, stream, ctr, T, out->n_samples);
+    TG_HIP(hipMemcpyAsync(out->panic, panic, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}

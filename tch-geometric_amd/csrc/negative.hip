@@ -21,11 +21,11 @@
 
 #include "tg_device.h"
 #include "tg_host.h"
+#include "tg_map.h"
 
 namespace tg {
 
 constexpr int NEG_MAX_RELS = 32;
-constexpr int64_t MAP_EMPTY = -1; // node ids are >= 0
 
 struct NegRel {
     const int64_t *ptrs;
@@ -98,34 +98,6 @@ __global__ void neg_candidates_kernel(NegRelTable tab, NegSrcRels src, const int
     }
 }
 
-__device__ __forceinline__ uint64_t map_hash(int64_t key) {
-    uint64_t x = (uint64_t)key * 0x9E3779B97F4A7C15ull;
-    return x ^ (x >> 29);
-}
-// claims (or finds) the slot of `key`
-__device__ __forceinline__ int64_t map_slot_insert(int64_t *keys, int64_t mask, int64_t key) {
-    int64_t s = (int64_t)(map_hash(key) & (uint64_t)mask);
-    for (;;) {
-        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&keys[s]),
-                                                  (unsigned long long)MAP_EMPTY, (unsigned long long)key);
-        if ((int64_t)prev == MAP_EMPTY || (int64_t)prev == key) return s;
-        s = (s + 1) & mask;
-    }
-}
-__device__ __forceinline__ int64_t map_slot_find(const int64_t *keys, int64_t mask, int64_t key) {
-    int64_t s = (int64_t)(map_hash(key) & (uint64_t)mask);
-    for (;;) {
-        const int64_t k = keys[s];
-        if (k == key) return s;
-        if (k == MAP_EMPTY) return -1;
-        s = (s + 1) & mask;
-    }
-}
-
-__global__ void fill_i64_kernel(int64_t *p, int64_t n, int64_t v) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = v;
-}
 // inputs of the dst type: value -> LAST slot holding it; also copies them to the head of `samples`
 __global__ void neg_insert_inputs_kernel(const int64_t *__restrict__ inputs, int64_t n, int64_t *keys, int64_t *vals,
                                          int64_t mask, int64_t *samples) {
@@ -229,18 +201,6 @@ __global__ void neg_emit_edges_kernel(int rel, const int64_t *__restrict__ cand,
     }
 }
 
-static inline unsigned neg_grid(int64_t n) {
-    int64_t g = (n + 255) / 256;
-    if (g < 1) g = 1;
-    if (g > 8192) g = 8192;
-    return (unsigned)g;
-}
-static inline int64_t pow2_at_least(int64_t n) {
-    int64_t c = 64;
-    while (c < n) c <<= 1;
-    return c;
-}
-
 } // namespace tg
 
 extern "C" int tg_neg_workspace_bytes(const tg_neg_problem *pb, int64_t *bytes) {
@@ -299,7 +259,7 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
             if (pb->rel_src[r] == t) src.rel[src.n++] = r; // :65-71
         TG_REQUIRE(src.n > 0, "tg_neg_sample: node type %d has inputs but no outgoing relation (the reference panics)", t);
         const uint32_t tag = pb->homogeneous ? TAG_NEG_HOMO : (TAG_NEG_HETERO | ((uint32_t)t << 8));
-        hipLaunchKernelGGL(neg_candidates_kernel, dim3(neg_grid(n * pb->num_neg)), dim3(256), 0, stream, tab, src,
+        hipLaunchKernelGGL(neg_candidates_kernel, dim3(grid_1d(n * pb->num_neg)), dim3(256), 0, stream, tab, src,
                            pb->inputs[t], n, pb->num_neg, pb->try_count, pb->inbound, pb->homogeneous ? 0 : 1,
                            rng->seed, rng->call_id, tag, item_begin[t], cand, rel_of, panic);
         TG_LAUNCH_CHECK();
@@ -307,20 +267,20 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
     // ---- 2. local ids per destination type
     for (int dt = 0; dt < pb->n_types; ++dt) {
         const int64_t n_in = pb->n_inputs[dt] > 0 ? pb->n_inputs[dt] : 0;
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(neg_grid(in_cap)), dim3(256), 0, stream, in_keys, in_cap, MAP_EMPTY);
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(neg_grid(in_cap)), dim3(256), 0, stream, in_vals, in_cap, (int64_t)-1);
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(neg_grid(new_cap)), dim3(256), 0, stream, new_keys, new_cap, MAP_EMPTY);
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(neg_grid(new_cap)), dim3(256), 0, stream, new_vals, new_cap,
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(in_cap)), dim3(256), 0, stream, in_keys, in_cap, MAP_EMPTY);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(in_cap)), dim3(256), 0, stream, in_vals, in_cap, (int64_t)-1);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(new_cap)), dim3(256), 0, stream, new_keys, new_cap, MAP_EMPTY);
+        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(new_cap)), dim3(256), 0, stream, new_vals, new_cap,
                            (int64_t)INT64_MAX);
         if (n_in > 0)
-            hipLaunchKernelGGL(neg_insert_inputs_kernel, dim3(neg_grid(n_in)), dim3(256), 0, stream, pb->inputs[dt],
+            hipLaunchKernelGGL(neg_insert_inputs_kernel, dim3(grid_1d(n_in)), dim3(256), 0, stream, pb->inputs[dt],
                                n_in, in_keys, in_vals, in_cap - 1, out->samples[dt]);
         if (m > 0) {
-            hipLaunchKernelGGL(neg_insert_items_kernel, dim3(neg_grid(m)), dim3(256), 0, stream, tab, dt, cand, rel_of,
+            hipLaunchKernelGGL(neg_insert_items_kernel, dim3(grid_1d(m)), dim3(256), 0, stream, tab, dt, cand, rel_of,
                                m, in_keys, in_vals, in_cap - 1, new_keys, new_vals, new_cap - 1, ids);
             hipLaunchKernelGGL(neg_scan_kernel, dim3(1), dim3(1024), 0, stream, tab, 0, dt, cand, rel_of, ids,
                                (int64_t)0, m, new_keys, new_vals, new_cap - 1, rank, totals, n_in);
-            hipLaunchKernelGGL(neg_assign_ids_kernel, dim3(neg_grid(m)), dim3(256), 0, stream, tab, dt, cand, rel_of, m,
+            hipLaunchKernelGGL(neg_assign_ids_kernel, dim3(grid_1d(m)), dim3(256), 0, stream, tab, dt, cand, rel_of, m,
                                n_in, new_keys, new_vals, new_cap - 1, rank, ids, out->samples[dt]);
         } else {
             hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, stream, totals, (int64_t)1, n_in);
@@ -336,7 +296,7 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
         if (e > b) {
             hipLaunchKernelGGL(neg_scan_kernel, dim3(1), dim3(1024), 0, stream, tab, 1, r, cand, rel_of, ids, b, e,
                                new_keys, new_vals, new_cap - 1, erank, totals + 1, (int64_t)0);
-            hipLaunchKernelGGL(neg_emit_edges_kernel, dim3(neg_grid(e - b)), dim3(256), 0, stream, r, cand, rel_of, ids,
+            hipLaunchKernelGGL(neg_emit_edges_kernel, dim3(grid_1d(e - b)), dim3(256), 0, stream, r, cand, rel_of, ids,
                                erank, b, e, pb->num_neg, out->rows[r], out->cols[r]);
         } else {
             TG_HIP(hipMemsetAsync(totals + 1, 0, sizeof(int64_t), stream));

@@ -19,7 +19,7 @@ FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
-           "tg_neg_workspace_bytes", "tg_neg_sample"]
+           "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample"]
 
 
 class TgGraph(C.Structure):

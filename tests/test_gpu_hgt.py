@@ -1,0 +1,84 @@
+"""GPU parity: hgt_sampling through the operator surface == oracle philox-mode (canonical orders)."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from helpers import has_edge, load_fake_hetero, rel_key
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import tch_geometric
+    return tch_geometric
+
+
+@pytest.fixture(scope="module")
+def graph():
+    counts, edges = load_fake_hetero()
+    node_types, edge_types = sorted(counts), sorted(edges)
+    P, I = {}, {}
+    for et in edge_types:
+        P[rel_key(et)], I[rel_key(et)], _ = orc.to_csc(edges[et], (counts[et[0]], counts[et[2]]))
+    return node_types, edge_types, P, I
+
+
+def _cuda(d):
+    return {k: torch.from_numpy(np.asarray(v, dtype=np.int64)).cuda() for k, v in d.items()} if d is not None else None
+
+
+def _compare(tg, graph, inputs, in_ts, ns, hops, seed, rts=None, timerange=None):
+    node_types, edge_types, P, I = graph
+    tg.seed(seed)
+    s, t, r, c, e = tg.hgt_sampling(node_types, edge_types, _cuda(P), _cuda(I), _cuda(rts), _cuda(inputs),
+                                    _cuda(in_ts), ns, hops, timerange)
+    o = orc.hgt(node_types, edge_types, P, I, rts, inputs, in_ts, ns, hops, orc.rng_philox(seed, 0),
+                timerange=timerange)
+    for nt in node_types:
+        assert np.array_equal(s[nt].cpu().numpy(), o[0][nt]), nt
+        assert np.array_equal(t[nt].cpu().numpy(), o[1][nt]), nt
+    for et in edge_types:
+        k = rel_key(et)
+        assert np.array_equal(r[k].cpu().numpy(), o[2][k]), k
+        assert np.array_equal(c[k].cpu().numpy(), o[3][k]), k
+        assert np.array_equal(e[k].cpu().numpy(), o[4][k]), k
+    return o
+
+
+def test_hgt_reference_config(tg, graph):
+    """hgt_sampling.rs:356-429: inputs [0,1,4,5] per type, [20,15] per type, 2 hops."""
+    node_types, edge_types, P, I = graph
+    o = _compare(tg, graph, {t: [0, 1, 4, 5] for t in node_types}, None, {t: [20, 15] for t in node_types}, 2, 11)
+    for et in edge_types:
+        k = rel_key(et)
+        for j, i in zip(o[2][k], o[3][k]):                                  # :300-305
+            assert has_edge(P[k], I[k], o[0][et[2]][i], o[0][et[0]][j])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hgt_larger_quotas_three_hops(tg, graph, seed):
+    node_types = graph[0]
+    _compare(tg, graph, {"v0": list(range(0, 120, 3)), "v2": [5, 5, 9]},      # a duplicate input
+             None, {t: [64, 48, 32] for t in node_types}, 3, seed)
+
+
+def test_hgt_timestamps_and_timerange(tg, graph):
+    node_types, edge_types, P, I = graph
+    g = np.random.default_rng(5)
+    rts = {k: g.integers(-1, 30, len(I[k])) for k in I}
+    _compare(tg, graph, {"v0": [0, 1, 4, 5], "v2": [7, 8]}, {"v0": [3, 10, -1, 20], "v2": [5, 25]},
+             {t: [10, 6] for t in node_types}, 2, 9, rts=rts, timerange=(5, 20))
+    some = {k: v for k, v in list(rts.items())[:3]}                            # timestamps on some relations only
+    _compare(tg, graph, {"v1": [2, 3]}, {"v1": [7, 8]}, {t: [30, 30] for t in node_types}, 2, 10, rts=some)
+
+
+def test_hgt_quota_above_budget_and_edge_cases(tg, graph):
+    node_types = graph[0]
+    _compare(tg, graph, {"v1": [3]}, None, {t: [1000, 1000] for t in node_types}, 2, 4)     # take whole budgets
+    _compare(tg, graph, {t: list(range(60)) for t in node_types}, None, {t: [] for t in node_types}, 0, 5)
+    _compare(tg, graph, {"v0": []}, None, {t: [5] for t in node_types}, 1, 6)               # empty input list
+    with pytest.raises(RuntimeError, match="reference panics"):                             # :202
+        tg.hgt_sampling(graph[0], graph[1], _cuda(graph[2]), _cuda(graph[3]), None, _cuda({"v1": [3]}), None,
+                        {"v1": [5, 5]}, 2)
