@@ -22,6 +22,8 @@
 //           fully coalesced.
 // Algorithmic HBM bytes per hop (F frontier slots, S sampled edges):
 //   reads 8F (frontier id) + 16F (ptrs pair) + 8S (gather), writes 32S.
+#include <stdlib.h>
+
 #include "tg_device.h"
 #include "tg_host.h"
 
@@ -42,6 +44,7 @@ struct NsHomoParams {
     uint64_t seed, call_id;
     uint32_t tag;
     int64_t id_base;
+    int32_t flags; // bit 0: streaming (non-temporal) gather loads
 };
 
 __host__ __device__ inline size_t ns_wave_lds_bytes(int kmax) {
@@ -83,7 +86,7 @@ __device__ __forceinline__ void sample_tickets(CallKey ck, uint64_t id, uint32_t
     }
 }
 
-template <int KMAX, bool REPLACE>
+template <int KMAX, bool REPLACE, bool NT>
 __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
@@ -184,12 +187,18 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 for (uint32_t q = lane; q < total; q += 64) {
                     const int l = slane[q];
                     const int64_t ep = ebase[l] + (int64_t)spos[q];
-                    const int64_t v = p.indices[ep]; // :211
+                    const int64_t v = (p.flags & 1) ? __builtin_nontemporal_load(&p.indices[ep]) : p.indices[ep]; // :211
                     const int64_t e = e_chunk + q;
-                    samples[n_seeds + e] = v;   // :215
-                    rows[e] = n_seeds + e;      // :217 j
-                    cols[e] = i0 + l;           // :217 i
-                    eidx[e] = ep;               // :217 edge_ptr
+                    samples[n_seeds + e] = v; // :215 (re-read as the next hop's frontier: keep it cacheable)
+                    if (NT) { // write-once outputs: stream them past L2 so gathers keep the cache
+                        __builtin_nontemporal_store(n_seeds + e, &rows[e]); // :217 j
+                        __builtin_nontemporal_store(i0 + l, &cols[e]);      // :217 i
+                        __builtin_nontemporal_store(ep, &eidx[e]);          // :217 edge_ptr
+                    } else {
+                        rows[e] = n_seeds + e;
+                        cols[e] = i0 + l;
+                        eidx[e] = ep;
+                    }
                 }
                 wave_lds_handoff();
             }
@@ -207,16 +216,28 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
     }
 }
 
-template <int KMAX, bool REPLACE>
-static int launch_uniform(const NsHomoParams &p, int64_t n_batches, hipStream_t stream) {
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int KMAX, bool REPLACE, bool NT>
+static int launch_uniform_nt(const NsHomoParams &p, int64_t n_batches, hipStream_t stream) {
     // few batches: wide workgroups for latency; many batches: narrow ones for occupancy
-    int threads = (n_batches < 512) ? 1024 : 256;
+    int threads = (n_batches < 512) ? 1024 : 512;
+    const int forced = env_int("TG_NS_THREADS", 0); // tuning knob
+    if (forced >= 64 && forced <= 1024 && forced % 64 == 0) threads = forced;
     while (threads > 64 && ns_block_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads >>= 1; // default LDS limit
     const size_t lds = ns_block_lds_bytes(p.kmax, threads / 64);
-    hipLaunchKernelGGL((ns_homo_uniform_kernel<KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads), lds, stream,
-                       p);
+    hipLaunchKernelGGL((ns_homo_uniform_kernel<KMAX, REPLACE, NT>), dim3((unsigned)n_batches), dim3(threads), lds,
+                       stream, p);
     TG_LAUNCH_CHECK();
     return TG_OK;
+}
+template <int KMAX, bool REPLACE>
+static int launch_uniform(const NsHomoParams &p, int64_t n_batches, hipStream_t stream) {
+    return env_int("TG_NS_NT", 1) ? launch_uniform_nt<KMAX, REPLACE, true>(p, n_batches, stream)
+                                  : launch_uniform_nt<KMAX, REPLACE, false>(p, n_batches, stream);
 }
 
 } // namespace tg
@@ -298,6 +319,7 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     p.call_id = rng->call_id;
     p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
     p.id_base = cfg ? cfg->id_base : 0;
+    p.flags = tg::env_int("TG_NS_NTLOAD", 1) ? 1 : 0; // each gathered line is used once: stream it
     hipStream_t s = (hipStream_t)stream;
     const bool repl = sampler == TG_SAMPLER_UNIFORM_REPL;
     if (p.kmax <= 16)
