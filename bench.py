@@ -32,6 +32,8 @@ def parse_args():
     ap.add_argument("--batches-per-launch", type=int, default=1024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")
+    ap.add_argument("--ptr32", type=int, default=1, help="also keep a u32 shadow of `ptrs`")
     return ap.parse_args()
 
 
@@ -68,7 +70,9 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     t_build = time.time() - t_build
-    graph = _cabi.graph_view(ptrs, indices)
+    idx32 = indices.to(torch.int32) if args.idx32 else None  # bit pattern of u32 for ids < 2^31
+    ptr32 = ptrs.to(torch.int32) if args.ptr32 else None    # offsets < 2^31 at scale 24 (2^28 edges)
+    graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32)
 
     # ---- this rank's batches: global batch ids [rank*(W+K), (rank+1)*(W+K))
     first, _ = sharding.rank_batch_range(rank, world, W + K)
@@ -122,7 +126,8 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))  # PMC passes of an identical launch (profiles/r01/pmc_summary.json)
-            if tj.get("batches_per_launch") == G and args.scale == 24 and B == 1024 and fanout == [15, 10]:
+            if (tj.get("batches_per_launch") == G and args.scale == 24 and B == 1024 and fanout == [15, 10]
+                    and tj.get("idx32") == args.idx32 and tj.get("ptr32") == args.ptr32):
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -145,6 +150,8 @@ def main():
                         "batch %d, default sampler (uniform w/o replacement), no filter" %
                         (args.scale, n_nodes, n_edges, fanout, B),
             "batches_per_launch": G,
+            "hbm_layout": "CSC int64 ptrs/indices%s%s" % (" + u32 shadow of indices for the gathers" if args.idx32 else "",
+                                                          " + u32 shadow of ptrs" if args.ptr32 else ""),
             "rng": "philox4x32-10 counter-addressed, seed 0, call_id = global batch id",
             "parallelism": "replicated CSC, %d x independent seed batches" % world,
             "sampled_edges_per_step": edges_all / (K * world),

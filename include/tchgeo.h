@@ -50,6 +50,10 @@ typedef struct {
     const int64_t *timestamps; /* [n_edges] or NULL  (TemporalFilter, neighbor_sampling.rs:36-77) */
     int64_t n_major;
     int64_t n_edges;
+    const uint32_t *indices32; /* optional u32 shadow of `indices` (all ids < 2^32): same values, half the bytes per
+                                  gathered line; NULL = not provided.  Outputs stay int64 either way. */
+    const uint32_t *ptrs32;    /* optional u32 shadow of `ptrs` (n_edges < 2^32): 4 B per offset, so the whole
+                                  offset table of RMAT-24 (67 MB) stays in the Infinity Cache; NULL = not provided */
 } tg_graph;
 
 typedef struct {

@@ -34,6 +34,8 @@ constexpr int NS_CHUNKS_PER_ROUND = 1024; // 64-vertex chunks whose totals fit t
 struct NsHomoParams {
     const int64_t *ptrs;
     const int64_t *indices;
+    const uint32_t *indices32;
+    const uint32_t *ptrs32;
     const int64_t *seeds;
     int64_t n_seeds;
     int32_t n_hops;
@@ -129,7 +131,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 uint32_t cnt = 0;
                 if (i < round_end) {
                     const int64_t w = samples[i];
-                    const int64_t deg = p.ptrs[w + 1] - p.ptrs[w];
+                    const int64_t deg = p.ptrs32 ? (int64_t)(p.ptrs32[w + 1] - p.ptrs32[w]) : p.ptrs[w + 1] - p.ptrs[w];
                     cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
                 }
                 const uint32_t tot = wave_sum(cnt);
@@ -155,8 +157,13 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 int64_t e0 = 0, deg = 0;
                 if (i < round_end) {
                     const int64_t w = samples[i];
-                    e0 = p.ptrs[w];
-                    deg = p.ptrs[w + 1] - e0;
+                    if (p.ptrs32) {
+                        e0 = (int64_t)p.ptrs32[w];
+                        deg = (int64_t)p.ptrs32[w + 1] - e0;
+                    } else {
+                        e0 = p.ptrs[w];
+                        deg = p.ptrs[w + 1] - e0;
+                    }
                 }
                 const uint32_t cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
                 const uint32_t incl = wave_inclusive_scan(cnt);
@@ -187,7 +194,11 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 for (uint32_t q = lane; q < total; q += 64) {
                     const int l = slane[q];
                     const int64_t ep = ebase[l] + (int64_t)spos[q];
-                    const int64_t v = (p.flags & 1) ? __builtin_nontemporal_load(&p.indices[ep]) : p.indices[ep]; // :211
+                    int64_t v; // :211
+                    if (p.indices32)
+                        v = (int64_t)((p.flags & 1) ? __builtin_nontemporal_load(&p.indices32[ep]) : p.indices32[ep]);
+                    else
+                        v = (p.flags & 1) ? __builtin_nontemporal_load(&p.indices[ep]) : p.indices[ep];
                     const int64_t e = e_chunk + q;
                     samples[n_seeds + e] = v; // :215 (re-read as the next hop's frontier: keep it cacheable)
                     if (NT) { // write-once outputs: stream them past L2 so gathers keep the cache
@@ -296,6 +307,8 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     tg::NsHomoParams p;
     p.ptrs = csc->ptrs;
     p.indices = csc->indices;
+    p.indices32 = csc->indices32;
+    p.ptrs32 = csc->ptrs32;
     p.seeds = seeds;
     p.n_seeds = n_seeds;
     p.n_hops = n_hops;

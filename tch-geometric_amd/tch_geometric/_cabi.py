@@ -24,7 +24,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
 
 class TgGraph(C.Structure):
     _fields_ = [("ptrs", C.c_void_p), ("indices", C.c_void_p), ("weights", C.c_void_p), ("timestamps", C.c_void_p),
-                ("n_major", C.c_int64), ("n_edges", C.c_int64)]
+                ("n_major", C.c_int64), ("n_edges", C.c_int64), ("indices32", C.c_void_p), ("ptrs32", C.c_void_p)]
 
 
 class TgRng(C.Structure):
@@ -67,13 +67,15 @@ def stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def graph_view(ptrs, indices, weights=None, timestamps=None):
+def graph_view(ptrs, indices, weights=None, timestamps=None, indices32=None, ptrs32=None):
     g = TgGraph()
     g.ptrs, g.indices = ptrs.data_ptr(), indices.data_ptr()
     g.weights = weights.data_ptr() if weights is not None else None
     g.timestamps = timestamps.data_ptr() if timestamps is not None else None
     g.n_major, g.n_edges = ptrs.numel() - 1, indices.numel()
-    g._keep = (ptrs, indices, weights, timestamps)  # the struct only borrows the device memory
+    g.indices32 = indices32.data_ptr() if indices32 is not None else None
+    g.ptrs32 = ptrs32.data_ptr() if ptrs32 is not None else None
+    g._keep = (ptrs, indices, weights, timestamps, indices32, ptrs32)  # the struct only borrows the device memory
     return g
 
 
