@@ -36,7 +36,8 @@ extern "C" {
 #define TG_ERR_UNSUPPORTED 3 /* valid request this build does not implement */
 
 #define TG_MAX_HOPS 8
-#define TG_MAX_FANOUT 32 /* per-hop fan-out handled by the register-resident sampler */
+#define TG_MAX_FANOUT 32 /* per-hop fan-out handled by the register-resident sampler; larger fan-outs (<= 255 while
+                            the LDS holds them) take a slower LDS-resident form with identical results */
 
 /* Adjacency resident in HBM, borrowed for the call: replaces
  * SparseGraph{ptrs,indices} (src/data/graph.rs:34-38) and EdgeAttr

@@ -49,12 +49,15 @@ struct NsHomoParams {
     int32_t flags; // bit 0: streaming (non-temporal) gather loads
 };
 
-__host__ __device__ inline size_t ns_wave_lds_bytes(int kmax) {
-    return 64 * sizeof(int64_t) + (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
+// per wave: edge base [64] i64 | staged positions [64*k] u32 | staged lanes [64*k] u8 | (big fan-outs only) the
+// ticket strips [64 * 2k] u32
+__host__ __device__ inline size_t ns_wave_lds_bytes(int kmax, bool strips) {
+    return 64 * sizeof(int64_t) + (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15) +
+           (strips ? (size_t)64 * 2 * kmax * sizeof(uint32_t) : 0);
 }
-__host__ __device__ inline size_t ns_block_lds_bytes(int kmax, int n_waves) {
+__host__ __device__ inline size_t ns_block_lds_bytes(int kmax, int n_waves, bool strips) {
     return (((size_t)(NS_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) +
-           (size_t)n_waves * ns_wave_lds_bytes(kmax);
+           (size_t)n_waves * ns_wave_lds_bytes(kmax, strips);
 }
 
 // Reservoir by tickets for one vertex with n > k candidates: slot s receives
@@ -64,7 +67,7 @@ __host__ __device__ inline size_t ns_block_lds_bytes(int kmax, int n_waves) {
 template <int KMAX>
 __device__ __forceinline__ void sample_tickets(CallKey ck, uint64_t id, uint32_t n, int k, uint32_t *spos,
                                                uint8_t *slane, uint32_t out_base, int lane) {
-    uint32_t keys[KMAX], vals[KMAX];
+    uint32_t keys[KMAX > 0 ? KMAX : 1], vals[KMAX > 0 ? KMAX : 1];
     Draw d;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
@@ -88,6 +91,28 @@ __device__ __forceinline__ void sample_tickets(CallKey ck, uint64_t id, uint32_t
     }
 }
 
+// Same law for any fan-out (KMAX == 0 instantiation): the shuffle's displaced entries live in LDS, one
+// 2k-word strip per lane.  Slower than the register form; used above TG_MAX_FANOUT.
+__device__ __forceinline__ void sample_tickets_lds(CallKey ck, uint64_t id, uint32_t n, int k, uint32_t *spos,
+                                                   uint8_t *slane, uint32_t out_base, int lane, uint32_t *strip) {
+    uint32_t *keys = strip + (size_t)lane * 2 * k, *vals = keys + k;
+    Draw d;
+    for (int s = 0; s < k; ++s) {
+        const uint32_t m = (n - 1u) - (uint32_t)s;
+        if ((s & 1) == 0) d = draw(ck, id, (uint32_t)(s >> 1), 0u);
+        const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+        uint32_t tr = r, tl = last;
+        for (int j = 0; j < s; ++j) {
+            tr = (keys[j] == r) ? vals[j] : tr;
+            tl = (keys[j] == last) ? vals[j] : tl;
+        }
+        keys[s] = r;
+        vals[s] = tl;
+        spos[out_base + s] = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+        slane[out_base + s] = (uint8_t)lane;
+    }
+}
+
 template <int KMAX, bool REPLACE, bool NT>
 __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -96,10 +121,13 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
 
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
     unsigned char *wbase = smem + ((((size_t)(NS_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15) +
-                           (size_t)wave * ns_wave_lds_bytes(p.kmax);
+                           (size_t)wave * ns_wave_lds_bytes(p.kmax, KMAX == 0);
     int64_t *ebase = reinterpret_cast<int64_t *>(wbase);
     uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 64 * sizeof(int64_t));
     uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 64 * sizeof(int64_t) + (size_t)64 * p.kmax * sizeof(uint32_t));
+    uint32_t *strip = reinterpret_cast<uint32_t *>(wbase + 64 * sizeof(int64_t) + (size_t)64 * p.kmax * sizeof(uint32_t) +
+                                                   (((size_t)64 * p.kmax + 15) & ~(size_t)15));
+    (void)strip;
 
     int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges;
@@ -184,6 +212,8 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                             spos[excl + s] = s;
                             slane[excl + s] = (uint8_t)lane;
                         }
+                    } else if constexpr (KMAX == 0) {
+                        sample_tickets_lds(ck, (uint64_t)(p.id_base + i), n, k, spos, slane, excl, lane, strip);
                     } else {
                         sample_tickets<KMAX>(ck, (uint64_t)(p.id_base + i), n, k, spos, slane, excl, lane);
                     }
@@ -238,8 +268,13 @@ static int launch_uniform_nt(const NsHomoParams &p, int64_t n_batches, hipStream
     int threads = (n_batches < 512) ? 1024 : 512;
     const int forced = env_int("TG_NS_THREADS", 0); // tuning knob
     if (forced >= 64 && forced <= 1024 && forced % 64 == 0) threads = forced;
-    while (threads > 64 && ns_block_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads >>= 1; // default LDS limit
-    const size_t lds = ns_block_lds_bytes(p.kmax, threads / 64);
+    while (threads > 64 && ns_block_lds_bytes(p.kmax, threads / 64, KMAX == 0) > 64 * 1024) threads >>= 1; // LDS limit
+    const size_t lds = ns_block_lds_bytes(p.kmax, threads / 64, KMAX == 0);
+    if (lds > 160 * 1024)
+        return fail(TG_ERR_UNSUPPORTED, "tg_ns_homo_batched: fan-out %d needs %zu B of LDS per wavefront", p.kmax, lds);
+    if (lds > 64 * 1024) // one wavefront per workgroup with a large fan-out: opt in to the full 160 KB of a CU
+        TG_HIP(hipFuncSetAttribute((const void *)ns_homo_uniform_kernel<KMAX, REPLACE, NT>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((ns_homo_uniform_kernel<KMAX, REPLACE, NT>), dim3((unsigned)n_batches), dim3(threads), lds,
                        stream, p);
     TG_LAUNCH_CHECK();
@@ -315,8 +350,7 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     p.kmax = 1;
     for (int h = 0; h < TG_MAX_HOPS; ++h) p.fanout[h] = 0;
     for (int h = 0; h < n_hops; ++h) {
-        TG_REQUIRE(fanout[h] <= TG_MAX_FANOUT, "tg_ns_homo_batched: fanout[%d] = %lld exceeds TG_MAX_FANOUT = %d", h,
-                   (long long)fanout[h], TG_MAX_FANOUT);
+        TG_REQUIRE(fanout[h] <= 255, "tg_ns_homo_batched: fanout[%d] = %lld exceeds 255", h, (long long)fanout[h]);
         p.fanout[h] = (int32_t)fanout[h];
         if (p.fanout[h] > p.kmax) p.kmax = p.fanout[h];
     }
@@ -337,5 +371,8 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     const bool repl = sampler == TG_SAMPLER_UNIFORM_REPL;
     if (p.kmax <= 16)
         return repl ? tg::launch_uniform<16, true>(p, n_batches, s) : tg::launch_uniform<16, false>(p, n_batches, s);
-    return repl ? tg::launch_uniform<32, true>(p, n_batches, s) : tg::launch_uniform<32, false>(p, n_batches, s);
+    if (p.kmax <= TG_MAX_FANOUT)
+        return repl ? tg::launch_uniform<32, true>(p, n_batches, s) : tg::launch_uniform<32, false>(p, n_batches, s);
+    // above the register-resident sampler: ticket strips in LDS (any fan-out the LDS can hold)
+    return repl ? tg::launch_uniform<0, true>(p, n_batches, s) : tg::launch_uniform<0, false>(p, n_batches, s);
 }

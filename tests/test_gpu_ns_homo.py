@@ -117,6 +117,17 @@ def test_rmat16_bench_shape_and_narrow_workgroups(cabi, dev):
     _check_batches(cabi, dev, ptrs, idx, seeds, [17, 2], sampler=1)
 
 
+def test_fanout_above_the_register_sampler(cabi, dev):
+    """fan-outs > TG_MAX_FANOUT take the LDS-resident ticket form: same results"""
+    n = 1 << 13
+    orow, ocol = orc.rmat_edges(13, n * 16, 17)
+    ptrs, idx, _ = orc.to_csc(np.stack([orow, ocol]), n)
+    seeds = orc.seed_batches(3, 0, 3, 40, n)
+    _check_batches(cabi, dev, ptrs, idx, seeds, [40, 3])
+    _check_batches(cabi, dev, ptrs, idx, seeds, [100])
+    _check_batches(cabi, dev, ptrs, idx, seeds, [33, 2], sampler=1)
+
+
 def test_edge_cases(cabi, dev):
     ptrs = np.array([0, 0, 2, 2, 5], dtype=np.int64)   # 0,2 isolated; 1 <- {0,2}; 3 <- {0,1,3}
     idx = np.array([0, 2, 0, 1, 3], dtype=np.int64)
@@ -142,6 +153,6 @@ def test_errors_are_reported(cabi, dev):
     g = cabi.graph_view(ptrs, idx)
     out = cabi.NsBatchedOut(1, 1, [2], dev)
     with pytest.raises(cabi.TchGeoError):
-        cabi.ns_homo_batched(g, torch.tensor([[0]], device=dev), [40], 0, 0, out)     # above TG_MAX_FANOUT
+        cabi.ns_homo_batched(g, torch.tensor([[0]], device=dev), [300], 0, 0, out)    # above any supported fan-out
     with pytest.raises(cabi.TchGeoError):
         cabi.ns_homo_batched(g, torch.tensor([[0]], device=dev), [3, 3], 0, 0, out)   # slabs too small
