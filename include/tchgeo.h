@@ -81,6 +81,11 @@ typedef struct {
     int64_t win_lo, win_hi;       /* inclusive window (python.rs:150) */
     const int64_t *seeds_state;   /* [n_batches * n_seeds] initial filter state, or NULL */
     int64_t id_base;              /* draw id of slot i is id_base + i (slot of the vertex in its sample list) */
+    /* Remote-frontier mode (range-partitioned graphs, n_hops == 1 only): seed i of batch b is some OTHER sampler's
+     * frontier vertex; it is sampled with that sampler's draws: id = seed_ids[b*n_seeds+i], call id =
+     * seed_call_ids[b*n_seeds+i] (instead of id_base + i and rng.call_id + b).  Both NULL = off. */
+    const int64_t *seed_ids;
+    const int64_t *seed_call_ids;
 } tg_ns_config;
 
 #define TG_TAG_NS_HOMO 1u

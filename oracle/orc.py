@@ -27,7 +27,7 @@ class Rng(C.Structure):
 class NsCfg(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("filter_mode", C.c_int32), ("forward", C.c_int32),
                 ("reservoir_algo", C.c_int32), ("win_lo", C.c_int64), ("win_hi", C.c_int64),
-                ("weights", C.c_void_p), ("timestamps", C.c_void_p)]
+                ("weights", C.c_void_p), ("timestamps", C.c_void_p), ("id_base", C.c_int64)]
 
 
 def build(force=False):
@@ -184,12 +184,13 @@ def ns_capacity(B, fanout):
 
 
 def ns_homo(ptrs, indices, inputs, fanout, rng, sampler=SAMPLER_UNIFORM, weights=None, filter_mode=FILTER_NONE,
-            forward=False, window=None, timestamps=None, inputs_state=None, reservoir_algo=RES_AUTO):
+            forward=False, window=None, timestamps=None, inputs_state=None, reservoir_algo=RES_AUTO, id_base=0):
     """neighbor_sampling_homogenous -> (samples, rows, cols, edge_index, layer_offsets)."""
     ptrs, indices, inputs = _i64(ptrs), _i64(indices), _i64(inputs)
     fan = _i64(fanout)
     keep = []
     cfg = _mk_cfg(sampler, weights, filter_mode, forward, window, timestamps, reservoir_algo, keep)
+    cfg.id_base = id_base
     B, H = inputs.size, fan.size
     cap = ns_capacity(B, fanout)
     samples = np.empty(cap, dtype=np.int64)

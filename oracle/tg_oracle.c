@@ -181,6 +181,7 @@ typedef struct {
     int64_t win_lo, win_hi;    /* inclusive window, python.rs:150 */
     const double *weights;     /* per edge ptr (f64, python.rs:214) */
     const int64_t *timestamps; /* per edge ptr (i64, python.rs:149) */
+    int64_t id_base;           /* philox mode: draw id of slot i is id_base + i */
 } orc_ns_cfg;
 
 /* neighbor_sampling.rs:55-67 TemporalFilter::filter */
@@ -300,7 +301,7 @@ ORC_API int orc_ns_homo(const int64_t *ptrs, const int64_t *indices, const int64
         for (int64_t i = begin; i < end; i++) { /* :195 */
             int64_t w = samples[i];
             int64_t w_state = has_state ? states[i] : 0;
-            int64_t cnt = orc_sample_vertex(&c, cfg, &st, ptrs, w, w_state, (uint64_t)i, eptr);
+            int64_t cnt = orc_sample_vertex(&c, cfg, &st, ptrs, w, w_state, (uint64_t)(cfg->id_base + i), eptr);
             if (cnt < 0) {
                 rc = -1;
                 break;

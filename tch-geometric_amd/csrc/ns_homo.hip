@@ -47,6 +47,7 @@ struct NsHomoParams {
     uint32_t tag;
     int64_t id_base;
     int32_t flags; // bit 0: streaming (non-temporal) gather loads
+    const int64_t *seed_ids, *seed_call_ids; // remote-frontier mode (n_hops == 1)
 };
 
 // per wave: edge base [64] i64 | staged positions [64*k] u32 | staged lanes [64*k] u8 | (big fan-outs only) the
@@ -194,6 +195,12 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                     }
                 }
                 const uint32_t cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+                uint64_t did = (uint64_t)(p.id_base + i); // address of this vertex's draws
+                CallKey ckl = ck;
+                if (p.seed_ids && i < round_end) { // remote-frontier mode: the origin sampler's (call id, slot)
+                    did = (uint64_t)p.seed_ids[b * n_seeds + i];
+                    ckl = call_key(p.seed, (uint64_t)p.seed_call_ids[b * n_seeds + i], p.tag);
+                }
                 const uint32_t incl = wave_inclusive_scan(cnt);
                 const uint32_t excl = incl - cnt;
                 const uint32_t total = __shfl(incl, 63, 64);
@@ -203,7 +210,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                     if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
                         Draw d;
                         for (int s = 0; s < k; ++s) {
-                            if ((s & 1) == 0) d = draw(ck, (uint64_t)(p.id_base + i), (uint32_t)(s >> 1), D1_REPLACE);
+                            if ((s & 1) == 0) d = draw(ckl, did, (uint32_t)(s >> 1), D1_REPLACE);
                             spos[excl + s] = bounded32(d.half(s & 1), n);
                             slane[excl + s] = (uint8_t)lane;
                         }
@@ -213,9 +220,9 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                             slane[excl + s] = (uint8_t)lane;
                         }
                     } else if constexpr (KMAX == 0) {
-                        sample_tickets_lds(ck, (uint64_t)(p.id_base + i), n, k, spos, slane, excl, lane, strip);
+                        sample_tickets_lds(ckl, did, n, k, spos, slane, excl, lane, strip);
                     } else {
-                        sample_tickets<KMAX>(ck, (uint64_t)(p.id_base + i), n, k, spos, slane, excl, lane);
+                        sample_tickets<KMAX>(ckl, did, n, k, spos, slane, excl, lane);
                     }
                 }
                 wave_lds_handoff();
@@ -367,6 +374,11 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
     p.id_base = cfg ? cfg->id_base : 0;
     p.flags = tg::env_int("TG_NS_NTLOAD", 1) ? 1 : 0; // each gathered line is used once: stream it
+    p.seed_ids = cfg ? cfg->seed_ids : nullptr;
+    p.seed_call_ids = cfg ? cfg->seed_call_ids : nullptr;
+    TG_REQUIRE((p.seed_ids == nullptr) == (p.seed_call_ids == nullptr),
+               "tg_ns_homo_batched: seed_ids and seed_call_ids come together");
+    TG_REQUIRE(!p.seed_ids || n_hops == 1, "tg_ns_homo_batched: remote-frontier mode needs n_hops == 1");
     hipStream_t s = (hipStream_t)stream;
     const bool repl = sampler == TG_SAMPLER_UNIFORM_REPL;
     if (p.kmax <= 16)

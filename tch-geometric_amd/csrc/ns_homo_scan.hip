@@ -293,6 +293,8 @@ int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_
     p.forward = cfg->forward;
     p.win_lo = cfg->win_lo;
     p.win_hi = cfg->win_hi;
+    TG_REQUIRE(!cfg->seed_ids && !cfg->seed_call_ids,
+               "tg_ns_homo_batched: remote-frontier mode is not available with filters / weights yet");
     TG_REQUIRE(p.sampler != TG_SAMPLER_WEIGHTED || csc->weights, "tg_ns_homo_batched: weighted sampler without weights");
     if (p.filter_mode != TG_FILTER_NONE) {
         TG_REQUIRE(csc->timestamps, "tg_ns_homo_batched: temporal filter without edge timestamps");

@@ -33,7 +33,8 @@ class TgRng(C.Structure):
 
 class TgNsConfig(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("filter_mode", C.c_int32), ("forward", C.c_int32), ("rng_tag", C.c_uint32),
-                ("win_lo", C.c_int64), ("win_hi", C.c_int64), ("seeds_state", C.c_void_p), ("id_base", C.c_int64)]
+                ("win_lo", C.c_int64), ("win_hi", C.c_int64), ("seeds_state", C.c_void_p), ("id_base", C.c_int64),
+                ("seed_ids", C.c_void_p), ("seed_call_ids", C.c_void_p)]
 
 
 class TgNsOut(C.Structure):
@@ -119,7 +120,8 @@ class NsBatchedOut:
 
 
 def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UNIFORM, filter_mode=FILTER_NONE,
-                    forward=False, window=(0, 0), seeds_state=None, rng_tag=0, id_base=0):
+                    forward=False, window=(0, 0), seeds_state=None, rng_tag=0, id_base=0, seed_ids=None,
+                    seed_call_ids=None):
     """seeds: [n_batches, n_seeds] int64 on the graph's device; `out` an NsBatchedOut."""
     assert seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.dim() == 2
     cfg = TgNsConfig()
@@ -127,6 +129,8 @@ def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UN
     cfg.win_lo, cfg.win_hi = window
     cfg.seeds_state = seeds_state.data_ptr() if seeds_state is not None else None
     cfg.rng_tag, cfg.id_base = rng_tag, id_base
+    cfg.seed_ids = seed_ids.data_ptr() if seed_ids is not None else None
+    cfg.seed_call_ids = seed_call_ids.data_ptr() if seed_call_ids is not None else None
     rng = TgRng(seed, call_id)
     fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
     so = out.struct()

@@ -1,0 +1,177 @@
+"""neighbor_sampling_homogenous over a RANGE-PARTITIONED CSC (mode 2; BASELINE cfg5).
+
+For graphs that do not fit one GPU's HBM: rank r owns the columns of the contiguous vertex range
+[r*S, (r+1)*S) (`ptrs` rebased to 0, `indices` holding global ids) and the seed batches it was given.  Per
+hop, every rank
+  1. buckets its frontier by owning rank (stable, so each bucket stays in frontier order),
+  2. exchanges bucket sizes, then the requests (vertex, call id, slot) -- two all-to-alls,
+  3. samples the requests it received with the SAME draws the requester would have used (the kernel's
+     remote-frontier mode: draw id = requester's slot, call id = requester's batch), so results equal the
+     replicated-graph sampler bit for bit,
+  4. returns per-request counts and (neighbour id, global edge pointer) pairs -- two more all-to-alls,
+  5. reassembles them in slot order, which is the reference's output order
+     (src/algo/neighbor_sampling.rs:195-218).
+xGMI is point-to-point and these messages are small (<= 16 B per request, 16 B per sample), so the exchange is
+latency-bound: all batches of a call travel in ONE set of collectives per hop.  With the "nccl" backend (RCCL)
+device tensors go straight into all_to_all_single; with "gloo" (tests) they are staged through the host.
+
+Only the unweighted, unfiltered samplers are partitioned in this round.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _cabi
+
+SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL = _cabi.SAMPLER_UNIFORM, _cabi.SAMPLER_UNIFORM_REPL
+
+
+class CscShard:
+    """Columns [v_lo, v_hi) of a CSC: ptrs rebased to 0, indices = global row ids, e_lo = global edge offset."""
+
+    def __init__(self, ptrs, indices, v_lo, v_hi, e_lo, n_nodes, shard_size):
+        self.ptrs, self.indices = ptrs, indices
+        self.v_lo, self.v_hi, self.e_lo = int(v_lo), int(v_hi), int(e_lo)
+        self.n_nodes, self.shard_size = int(n_nodes), int(shard_size)
+
+    @staticmethod
+    def shard_size_for(n_nodes, world):
+        return (n_nodes + world - 1) // world
+
+    @classmethod
+    def from_full(cls, ptrs, indices, rank, world):
+        """Cut rank's shard out of a replicated CSC (tests / benchmarks; a real loader reads only its shard)."""
+        n = ptrs.numel() - 1
+        size = cls.shard_size_for(n, world)
+        lo, hi = min(rank * size, n), min((rank + 1) * size, n)
+        e_lo, e_hi = int(ptrs[lo]), int(ptrs[hi])
+        return cls((ptrs[lo:hi + 1] - e_lo).contiguous(), indices[e_lo:e_hi].contiguous(), lo, hi, e_lo, n, size)
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _all_to_all_rows(send, send_counts, recv_counts, group):
+    """all_to_all_v over dim 0 of `send` ([M] or [M, C] int64); counts are python lists of rows per peer."""
+    world, _ = _world(group)
+    tail = tuple(send.shape[1:])
+    n_recv = int(sum(recv_counts))
+    if world == 1:
+        return send.clone()
+    if dist.get_backend(group) == "gloo":  # host staging (CPU tests); RCCL takes the device tensors directly
+        s = send.cpu().contiguous()
+        r = torch.empty((n_recv,) + tail, dtype=send.dtype)
+        dist.all_to_all_single(r, s, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts),
+                               group=group)
+        return r.to(send.device)
+    r = torch.empty((n_recv,) + tail, dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(r, send.contiguous(), output_split_sizes=list(recv_counts),
+                           input_split_sizes=list(send_counts), group=group)
+    return r
+
+
+def _exchange_counts(counts, group):
+    world, _ = _world(group)
+    c = torch.as_tensor(counts, dtype=torch.int64)
+    return [int(x) for x in _all_to_all_rows(c.reshape(world, 1), [1] * world, [1] * world, group).reshape(-1)] \
+        if world > 1 else list(counts)
+
+
+def _hip_hop(shard, local_vertices, call_ids, slot_ids, k, seed, sampler):
+    """Owner side of one hop on the GPU: -> (cnt per request, neighbour ids, LOCAL edge pointers), request order."""
+    m = local_vertices.numel()
+    dev = local_vertices.device
+    if m == 0:
+        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        return z, z, z
+    out = _cabi.NsBatchedOut(1, m, [k], dev)
+    _cabi.ns_homo_batched(_cabi.graph_view(shard.ptrs, shard.indices), local_vertices.reshape(1, m).contiguous(), [k],
+                          seed, 0, out, sampler=sampler, seed_ids=slot_ids.contiguous(),
+                          seed_call_ids=call_ids.contiguous())
+    ne = int(out.counts[0, 1])  # size read-back
+    cnt = torch.bincount(out.cols[0, :ne], minlength=m)
+    return cnt, out.samples[0, m:m + ne], out.edge_index[0, :ne]
+
+
+def _ragged_gather_index(src_start, cnt):
+    """index of every element of ragged rows given each row's start in the source and its length"""
+    total = int(cnt.sum())
+    if total == 0:
+        return torch.zeros(0, dtype=torch.int64, device=cnt.device)
+    row = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device), cnt)
+    dst_start = torch.cumsum(cnt, 0) - cnt
+    return src_start[row] + (torch.arange(total, device=cnt.device) - dst_start[row])
+
+
+def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
+                        _hop_fn=None):
+    """seeds: [n_batches, B] int64 on the shard's device; batch j of this rank has call id first_call_id + j.
+
+    Returns a list of per-batch (samples, rows, cols, edge_index, layer_offsets), equal to what the
+    replicated-graph sampler returns for the same (seed, call id)."""
+    hop_fn = _hop_fn or _hip_hop
+    world, rank = _world(group)
+    dev = seeds.device
+    nb, B = seeds.shape
+    # frontier, batch-major: vertex, batch, slot (= index in the batch's sample list = draw id)
+    f_vertex = seeds.reshape(-1)
+    f_batch = torch.repeat_interleave(torch.arange(nb, device=dev), B)
+    f_slot = torch.arange(B, device=dev).repeat(nb)
+    samples = [[seeds[j]] for j in range(nb)]
+    cols, eidx = [[] for _ in range(nb)], [[] for _ in range(nb)]
+    n_edges = torch.zeros(nb, dtype=torch.int64, device=dev)
+    layer_offsets = [[] for _ in range(nb)]
+    for k in fanout:
+        ne_host = n_edges.tolist()
+        for j in range(nb):
+            layer_offsets[j].append((B + ne_host[j], ne_host[j], B + ne_host[j]))  # neighbor_sampling.rs:193
+        # ---- 1. bucket by owner (stable: buckets keep frontier order)
+        owner = torch.clamp(f_vertex // shard.shard_size, max=world - 1)
+        perm = torch.argsort(owner, stable=True)
+        send_counts = torch.bincount(owner, minlength=world).tolist()
+        req = torch.stack([f_vertex[perm], first_call_id + f_batch[perm], f_slot[perm]], dim=1)
+        # ---- 2. sizes, then requests
+        recv_counts = _exchange_counts(send_counts, group)
+        got = _all_to_all_rows(req, send_counts, recv_counts, group)
+        # ---- 3. sample what this rank owns, with the requester's draws
+        cnt_r, nbr_r, ep_r = hop_fn(shard, got[:, 0] - shard.v_lo, got[:, 1], got[:, 2], int(k), seed, sampler)
+        ep_r = ep_r + shard.e_lo
+        # ---- 4. replies: per-request counts, then (neighbour, global edge pointer) rows
+        cnt_sorted = _all_to_all_rows(cnt_r, recv_counts, send_counts, group)
+        peer_of_req = torch.repeat_interleave(torch.arange(world, device=dev), torch.as_tensor(recv_counts, device=dev))
+        rep_send = torch.zeros(world, dtype=torch.int64, device=dev).index_add_(0, peer_of_req, cnt_r).tolist()
+        rep_recv = _exchange_counts(rep_send, group)
+        data_sorted = _all_to_all_rows(torch.stack([nbr_r, ep_r], dim=1), rep_send, rep_recv, group)
+        # ---- 5. back to frontier (slot) order
+        cnt_f = torch.empty_like(cnt_sorted)
+        cnt_f[perm] = cnt_sorted
+        start_sorted = torch.cumsum(cnt_sorted, 0) - cnt_sorted
+        start_f = torch.empty_like(start_sorted)
+        start_f[perm] = start_sorted
+        gidx = _ragged_gather_index(start_f, cnt_f)
+        new_nbr, new_ep = data_sorted[gidx, 0], data_sorted[gidx, 1]
+        parent_slot = torch.repeat_interleave(f_slot, cnt_f)
+        new_batch = torch.repeat_interleave(f_batch, cnt_f)
+        per_batch = torch.zeros(nb, dtype=torch.int64, device=dev).index_add_(0, f_batch, cnt_f)
+        # new samples of batch j occupy slots B + n_edges[j] ... in emission order
+        first_new = torch.cumsum(per_batch, 0) - per_batch
+        new_slot = B + n_edges[new_batch] + (torch.arange(new_batch.numel(), device=dev) - first_new[new_batch])
+        sizes = per_batch.tolist()
+        for j, (a, b_, c, d) in enumerate(zip(torch.split(new_nbr, sizes), torch.split(parent_slot, sizes),
+                                              torch.split(new_ep, sizes), sizes)):
+            if d:
+                samples[j].append(a)
+                cols[j].append(b_)
+                eidx[j].append(c)
+        n_edges = n_edges + per_batch
+        f_vertex, f_batch, f_slot = new_nbr, new_batch, new_slot
+    out = []
+    ne_host = n_edges.tolist()
+    empty = torch.zeros(0, dtype=torch.int64, device=dev)
+    for j in range(nb):
+        out.append((torch.cat(samples[j]), torch.arange(B, B + ne_host[j], device=dev),
+                    torch.cat(cols[j]) if cols[j] else empty, torch.cat(eidx[j]) if eidx[j] else empty,
+                    layer_offsets[j]))
+    return out

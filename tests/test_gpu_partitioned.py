@@ -1,0 +1,98 @@
+"""Range-partitioned neighbor sampling with the real HIP kernels: (a) one rank (the remote-frontier kernel mode
++ reassembly), (b) two ranks sharing the one GPU over gloo (host-staged exchange).  Both must equal the
+replicated-graph launch (tg_ns_homo_batched) bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED, FANOUT, B = 0xD157, [15, 10], 128
+
+
+def _graph(dev):
+    from tch_geometric import _cabi
+    n = 1 << 14
+    row, col = _cabi.rmat_edges(14, n * 16, 0xAA, dev)
+    ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, True)
+    return ptrs, idx, n
+
+
+def _replicated(ptrs, idx, seeds, first_call, sampler):
+    from tch_geometric import _cabi
+    out = _cabi.NsBatchedOut(seeds.shape[0], seeds.shape[1], FANOUT, seeds.device)
+    _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, FANOUT, SEED, first_call, out, sampler=sampler)
+    torch.cuda.synchronize()
+    return [out.batch(b) for b in range(seeds.shape[0])]
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_single_rank_partitioned_equals_batched(sampler):
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n = _graph(dev)
+    seeds = _cabi.seed_batches(9, 40, 5, B, n, dev)
+    shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
+    res = partitioned.ns_homo_partitioned(shard, seeds, FANOUT, SEED, 40, sampler=sampler)
+    ref = _replicated(ptrs, idx, seeds, 40, sampler)
+    for (s, r, c, e, lo), (rs, rr, rc, re_, rlo) in zip(res, ref):
+        assert lo == rlo
+        assert torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_)
+    # and against the oracle for one batch
+    o = orc.ns_homo(ptrs.cpu().numpy(), idx.cpu().numpy(), seeds[2].cpu().numpy(), FANOUT, orc.rng_philox(SEED, 42),
+                    sampler=sampler)
+    assert np.array_equal(res[2][0].cpu().numpy(), o[0]) and np.array_equal(res[2][3].cpu().numpy(), o[3])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tch-geometric_amd")):
+        sys.path.insert(0, p)
+    from tch_geometric import _cabi, partitioned
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")          # both ranks share the box's one GPU; a real node gives each its own
+    ptrs, idx, n = _graph(dev)
+    shard = partitioned.CscShard.from_full(ptrs, idx, rank, world)
+    first = 100 + rank * 4
+    seeds = _cabi.seed_batches(9, first, 4, B, n, dev)
+    res = partitioned.ns_homo_partitioned(shard, seeds, FANOUT, SEED, first)
+    ref = _replicated(ptrs, idx, seeds, first, 0)
+    ok = all(lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_)
+             for (s, r, c, e, lo), (rs, rr, rc, re_, rlo) in zip(res, ref))
+    remote = sum(int(((s[B:] // shard.shard_size).clamp(max=world - 1) != rank).sum()) for s, *_ in res)
+    q.put((rank, ok, remote, sum(int(r.numel()) for _, r, *_ in res)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, remote, edges in got:
+        assert ok, "rank %d: partitioned result differs from the replicated launch" % rank
+        assert edges > 0 and remote > 0        # the test really crossed the partition boundary

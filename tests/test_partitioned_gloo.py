@@ -1,0 +1,106 @@
+"""Range-partitioned neighbor sampling (SURVEY 8(e) mode 2) on CPU: two gloo ranks each own half of the
+columns and half of the seed batches; the owner-side sampler stand-in is the oracle's philox-mode addressed
+with the REQUESTER's (call id, slot).  The union must equal the replicated-graph oracle batch for batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED, FANOUT, B, PER_RANK = 0xD157, [6, 4], 16, 3
+
+
+def _paths():
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tch-geometric_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _graph():
+    _paths()
+    import orc
+    n = 1 << 9
+    row, col = orc.rmat_edges(9, n * 12, 33)
+    ptrs, idx, _ = orc.to_csc(np.stack([row, col]), n)
+    return ptrs, idx, n
+
+
+def _oracle_hop(shard, local_v, call_ids, slot_ids, k, seed, sampler):
+    import orc
+    ptrs, idx = shard.ptrs.numpy(), shard.indices.numpy()
+    cnt, nbr, ep = [], [], []
+    for v, c, s in zip(local_v.tolist(), call_ids.tolist(), slot_ids.tolist()):
+        r = orc.ns_homo(ptrs, idx, [v], [k], orc.rng_philox(seed, c), sampler=sampler, id_base=s)
+        cnt.append(len(r[1]))
+        nbr.append(r[0][1:])
+        ep.append(r[3])
+    t = lambda parts: torch.from_numpy(np.concatenate(parts).astype(np.int64)) if parts else torch.zeros(0, dtype=torch.int64)
+    return torch.tensor(cnt, dtype=torch.int64), t(nbr), t(ep)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sampler, q):
+    _paths()
+    import orc
+    from tch_geometric import partitioned
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ptrs, idx, n = _graph()
+    shard = partitioned.CscShard.from_full(torch.from_numpy(ptrs), torch.from_numpy(idx), rank, world)
+    first = rank * PER_RANK
+    seeds = torch.from_numpy(orc.seed_batches(5, first, PER_RANK, B, n))
+    res = partitioned.ns_homo_partitioned(shard, seeds, FANOUT, SEED, first, sampler=sampler, _hop_fn=_oracle_hop)
+    q.put((rank, [(s.tolist(), r.tolist(), c.tolist(), e.tolist(), lo) for s, r, c, e, lo in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_two_rank_partitioned_equals_replicated(sampler):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sampler, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import orc
+    ptrs, idx, n = _graph()
+    for rank in range(world):
+        seeds = orc.seed_batches(5, rank * PER_RANK, PER_RANK, B, n)
+        for j in range(PER_RANK):
+            o = orc.ns_homo(ptrs, idx, seeds[j], FANOUT, orc.rng_philox(SEED, rank * PER_RANK + j), sampler=sampler)
+            s, r, c, e, lo = got[rank][j]
+            assert lo == o[4]
+            assert s == o[0].tolist() and r == o[1].tolist() and c == o[2].tolist() and e == o[3].tolist()
+
+
+def test_shards_tile_the_graph():
+    _paths()
+    from tch_geometric import partitioned
+    ptrs, idx, n = _graph()
+    P, I = torch.from_numpy(ptrs), torch.from_numpy(idx)
+    for world in (1, 2, 3, 8):
+        shards = [partitioned.CscShard.from_full(P, I, r, world) for r in range(world)]
+        assert shards[0].v_lo == 0 and shards[-1].v_hi == n
+        assert all(a.v_hi == b.v_lo for a, b in zip(shards, shards[1:]))
+        assert sum(s.indices.numel() for s in shards) == len(idx)
+        for s in shards:
+            assert int(s.ptrs[0]) == 0 and int(s.ptrs[-1]) == s.indices.numel()
+            assert torch.equal(s.indices, I[s.e_lo:s.e_lo + s.indices.numel()])
