@@ -125,6 +125,36 @@ TG_API int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t
                        const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                        const tg_ns_out *out, void *stream);
 
+/* One hop of the unweighted, unfiltered sampler over a flat frontier, spread over the whole device (the
+ * per-vertex work of neighbor_sampling.rs:195-218 without the per-batch bookkeeping).  Used where the frontier
+ * is not "one seed batch": the owner side of the range-partitioned sampler, relation-hops of the heterogeneous
+ * sampler.  Vertex i of the frontier is sampled with draw id ids[i] (or id_base + i) and call id call_ids[i]
+ * (or rng.call_id); vertices < 0 are empty slots.  Outputs are sized for the worst case m * fanout;
+ * offsets[m] is the number of samples.  No synchronisation. */
+typedef struct {
+    const int64_t *vertices; /* [m] */
+    const int64_t *ids;      /* [m] or NULL */
+    const int64_t *call_ids; /* [m] or NULL */
+    int64_t m;
+    int64_t id_base;
+    int32_t fanout;
+    int32_t sampler;  /* TG_SAMPLER_UNIFORM or TG_SAMPLER_UNIFORM_REPL */
+    uint32_t rng_tag; /* 0 = TG_TAG_NS_HOMO */
+    uint32_t _reserved;
+} tg_hop_in;
+
+typedef struct {
+    int64_t *cnt;       /* [m] samples per frontier vertex */
+    int64_t *offsets;   /* [m + 1] exclusive prefix of cnt */
+    int64_t *neighbors; /* [m * fanout] indices[edge_ptr], grouped by frontier vertex in reservoir-slot order */
+    int64_t *edge_ptrs; /* [m * fanout] */
+    int64_t *parents;   /* [m * fanout] index of the frontier vertex */
+} tg_hop_out;
+
+TG_API int tg_ns_hop_workspace_bytes(int64_t m, int64_t *bytes);
+TG_API int tg_ns_hop(const tg_graph *csc, const tg_hop_in *in, const tg_rng *rng, const tg_hop_out *out,
+                     void *workspace, int64_t workspace_bytes, void *stream);
+
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */
 TG_API int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,

@@ -19,7 +19,7 @@ FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
-           "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample"]
+           "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop"]
 
 
 class TgGraph(C.Structure):
@@ -49,6 +49,17 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 lib.tg_version.restype = C.c_char_p
 lib.tg_last_error.restype = C.c_char_p
+
+
+class TgHopIn(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("ids", C.c_void_p), ("call_ids", C.c_void_p), ("m", C.c_int64),
+                ("id_base", C.c_int64), ("fanout", C.c_int32), ("sampler", C.c_int32), ("rng_tag", C.c_uint32),
+                ("_reserved", C.c_uint32)]
+
+
+class TgHopOut(C.Structure):
+    _fields_ = [("cnt", C.c_void_p), ("offsets", C.c_void_p), ("neighbors", C.c_void_p), ("edge_ptrs", C.c_void_p),
+                ("parents", C.c_void_p)]
 
 
 class TchGeoError(RuntimeError):
@@ -197,3 +208,27 @@ def probe_random_gather(table, n_threads, per_thread, seed=1):
     check(lib.tg_probe_random_gather(ptr(table), C.c_int64(table.numel()), C.c_int64(n_threads),
                                      C.c_int64(per_thread), C.c_uint64(seed), ptr(sink), stream_ptr(table.device)))
     return sink
+
+
+def ns_hop(graph, vertices, fanout, seed, call_id=0, sampler=SAMPLER_UNIFORM, ids=None, call_ids=None, id_base=0,
+           rng_tag=0):
+    """One flat hop (tg_ns_hop).  -> (cnt[m], offsets[m+1], neighbors, edge_ptrs, parents), the last three sized
+    m*fanout with offsets[m] valid entries; no host synchronisation."""
+    m, dev = vertices.numel(), vertices.device
+    o = dict(dtype=torch.int64, device=dev)
+    cnt, offsets = torch.empty(max(m, 1), **o), torch.empty(m + 1, **o)
+    nbr, ep, par = (torch.empty(max(m * fanout, 1), **o) for _ in range(3))
+    hin, hout = TgHopIn(), TgHopOut()
+    hin.vertices = vertices.data_ptr() if m else None
+    hin.ids = ids.data_ptr() if ids is not None else None
+    hin.call_ids = call_ids.data_ptr() if call_ids is not None else None
+    hin.m, hin.id_base, hin.fanout, hin.sampler, hin.rng_tag = m, id_base, fanout, sampler, rng_tag
+    hout.cnt, hout.offsets = cnt.data_ptr(), offsets.data_ptr()
+    hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+    nbytes = C.c_int64(0)
+    check(lib.tg_ns_hop_workspace_bytes(C.c_int64(m), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, **o)
+    rng = TgRng(seed, call_id)
+    check(lib.tg_ns_hop(C.byref(graph), C.byref(hin), C.byref(rng), C.byref(hout), ptr(ws), C.c_int64(nbytes.value),
+                        stream_ptr(dev)))
+    return cnt[:m], offsets, nbr, ep, par

@@ -32,6 +32,12 @@ class CscShard:
         self.ptrs, self.indices = ptrs, indices
         self.v_lo, self.v_hi, self.e_lo = int(v_lo), int(v_hi), int(e_lo)
         self.n_nodes, self.shard_size = int(n_nodes), int(shard_size)
+        self._view = None
+
+    def graph_view(self):
+        if self._view is None:
+            self._view = _cabi.graph_view(self.ptrs, self.indices)
+        return self._view
 
     @staticmethod
     def shard_size_for(n_nodes, world):
@@ -80,19 +86,16 @@ def _exchange_counts(counts, group):
 
 
 def _hip_hop(shard, local_vertices, call_ids, slot_ids, k, seed, sampler):
-    """Owner side of one hop on the GPU: -> (cnt per request, neighbour ids, LOCAL edge pointers), request order."""
+    """Owner side of one hop on the GPU (tg_ns_hop, whole-device flat hop):
+    -> (cnt per request, neighbour ids, LOCAL edge pointers), in request order."""
     m = local_vertices.numel()
-    dev = local_vertices.device
     if m == 0:
-        z = torch.zeros(0, dtype=torch.int64, device=dev)
+        z = torch.zeros(0, dtype=torch.int64, device=local_vertices.device)
         return z, z, z
-    out = _cabi.NsBatchedOut(1, m, [k], dev)
-    _cabi.ns_homo_batched(_cabi.graph_view(shard.ptrs, shard.indices), local_vertices.reshape(1, m).contiguous(), [k],
-                          seed, 0, out, sampler=sampler, seed_ids=slot_ids.contiguous(),
-                          seed_call_ids=call_ids.contiguous())
-    ne = int(out.counts[0, 1])  # size read-back
-    cnt = torch.bincount(out.cols[0, :ne], minlength=m)
-    return cnt, out.samples[0, m:m + ne], out.edge_index[0, :ne]
+    cnt, offsets, nbr, ep, _ = _cabi.ns_hop(shard.graph_view(), local_vertices.contiguous(), k, seed, sampler=sampler,
+                                            ids=slot_ids.contiguous(), call_ids=call_ids.contiguous())
+    total = int(offsets[m])  # size read-back
+    return cnt, nbr[:total], ep[:total]
 
 
 def _ragged_gather_index(src_start, cnt):
@@ -110,68 +113,84 @@ def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPL
     """seeds: [n_batches, B] int64 on the shard's device; batch j of this rank has call id first_call_id + j.
 
     Returns a list of per-batch (samples, rows, cols, edge_index, layer_offsets), equal to what the
-    replicated-graph sampler returns for the same (seed, call id)."""
+    replicated-graph sampler returns for the same (seed, call id).  Everything stays flat (batch-major) on the
+    device until one final scatter; per hop the host only learns the all-to-all split sizes."""
     hop_fn = _hop_fn or _hip_hop
     world, rank = _world(group)
     dev = seeds.device
     nb, B = seeds.shape
+    i64 = dict(dtype=torch.int64, device=dev)
     # frontier, batch-major: vertex, batch, slot (= index in the batch's sample list = draw id)
     f_vertex = seeds.reshape(-1)
-    f_batch = torch.repeat_interleave(torch.arange(nb, device=dev), B)
-    f_slot = torch.arange(B, device=dev).repeat(nb)
-    samples = [[seeds[j]] for j in range(nb)]
-    cols, eidx = [[] for _ in range(nb)], [[] for _ in range(nb)]
-    n_edges = torch.zeros(nb, dtype=torch.int64, device=dev)
-    layer_offsets = [[] for _ in range(nb)]
+    f_batch = torch.repeat_interleave(torch.arange(nb, **i64), B)
+    f_slot = torch.arange(B, **i64).repeat(nb)
+    n_edges = torch.zeros(nb, **i64)
+    ne_at_hop, hops = [], []          # per hop: edges before it (per batch); (batch, slot, neighbour, parent slot, edge ptr)
     for k in fanout:
-        ne_host = n_edges.tolist()
-        for j in range(nb):
-            layer_offsets[j].append((B + ne_host[j], ne_host[j], B + ne_host[j]))  # neighbor_sampling.rs:193
-        # ---- 1. bucket by owner (stable: buckets keep frontier order)
-        owner = torch.clamp(f_vertex // shard.shard_size, max=world - 1)
-        perm = torch.argsort(owner, stable=True)
-        send_counts = torch.bincount(owner, minlength=world).tolist()
-        req = torch.stack([f_vertex[perm], first_call_id + f_batch[perm], f_slot[perm]], dim=1)
-        # ---- 2. sizes, then requests
-        recv_counts = _exchange_counts(send_counts, group)
-        got = _all_to_all_rows(req, send_counts, recv_counts, group)
+        ne_at_hop.append(n_edges)
+        m = f_vertex.numel()
+        if world > 1:
+            # ---- 1. bucket by owner (stable: buckets keep frontier order)
+            owner = torch.clamp(f_vertex // shard.shard_size, max=world - 1)
+            perm = torch.argsort(owner, stable=True)
+            send_counts = torch.bincount(owner, minlength=world).tolist()
+            req = torch.stack([f_vertex[perm], first_call_id + f_batch[perm], f_slot[perm]], dim=1)
+            # ---- 2. sizes, then requests
+            recv_counts = _exchange_counts(send_counts, group)
+            got = _all_to_all_rows(req, send_counts, recv_counts, group)
+            r_vertex, r_call, r_slot = got[:, 0], got[:, 1], got[:, 2]
+        else:
+            r_vertex, r_call, r_slot = f_vertex, first_call_id + f_batch, f_slot
         # ---- 3. sample what this rank owns, with the requester's draws
-        cnt_r, nbr_r, ep_r = hop_fn(shard, got[:, 0] - shard.v_lo, got[:, 1], got[:, 2], int(k), seed, sampler)
+        cnt_r, nbr_r, ep_r = hop_fn(shard, r_vertex - shard.v_lo, r_call, r_slot, int(k), seed, sampler)
         ep_r = ep_r + shard.e_lo
-        # ---- 4. replies: per-request counts, then (neighbour, global edge pointer) rows
-        cnt_sorted = _all_to_all_rows(cnt_r, recv_counts, send_counts, group)
-        peer_of_req = torch.repeat_interleave(torch.arange(world, device=dev), torch.as_tensor(recv_counts, device=dev))
-        rep_send = torch.zeros(world, dtype=torch.int64, device=dev).index_add_(0, peer_of_req, cnt_r).tolist()
-        rep_recv = _exchange_counts(rep_send, group)
-        data_sorted = _all_to_all_rows(torch.stack([nbr_r, ep_r], dim=1), rep_send, rep_recv, group)
-        # ---- 5. back to frontier (slot) order
-        cnt_f = torch.empty_like(cnt_sorted)
-        cnt_f[perm] = cnt_sorted
-        start_sorted = torch.cumsum(cnt_sorted, 0) - cnt_sorted
-        start_f = torch.empty_like(start_sorted)
-        start_f[perm] = start_sorted
-        gidx = _ragged_gather_index(start_f, cnt_f)
-        new_nbr, new_ep = data_sorted[gidx, 0], data_sorted[gidx, 1]
-        parent_slot = torch.repeat_interleave(f_slot, cnt_f)
-        new_batch = torch.repeat_interleave(f_batch, cnt_f)
-        per_batch = torch.zeros(nb, dtype=torch.int64, device=dev).index_add_(0, f_batch, cnt_f)
-        # new samples of batch j occupy slots B + n_edges[j] ... in emission order
+        if world > 1:
+            # ---- 4. replies: per-request counts, then (neighbour, global edge pointer) rows
+            cnt_sorted = _all_to_all_rows(cnt_r, recv_counts, send_counts, group)
+            peer_of_req = torch.repeat_interleave(torch.arange(world, **i64), torch.as_tensor(recv_counts, **i64))
+            rep_send = torch.zeros(world, **i64).index_add_(0, peer_of_req, cnt_r).tolist()
+            rep_recv = _exchange_counts(rep_send, group)
+            data_sorted = _all_to_all_rows(torch.stack([nbr_r, ep_r], dim=1), rep_send, rep_recv, group)
+            # ---- 5. back to frontier (slot) order
+            cnt_f = torch.empty_like(cnt_sorted)
+            cnt_f[perm] = cnt_sorted
+            start_sorted = torch.cumsum(cnt_sorted, 0) - cnt_sorted
+            start_f = torch.empty_like(start_sorted)
+            start_f[perm] = start_sorted
+            gidx = _ragged_gather_index(start_f, cnt_f)
+            new_nbr, new_ep = data_sorted[gidx, 0], data_sorted[gidx, 1]
+        else:
+            cnt_f, new_nbr, new_ep = cnt_r, nbr_r, ep_r
+        parent_slot = torch.repeat_interleave(f_slot, cnt_f, output_size=new_nbr.numel())
+        new_batch = torch.repeat_interleave(f_batch, cnt_f, output_size=new_nbr.numel())
+        per_batch = torch.zeros(nb, **i64).index_add_(0, f_batch, cnt_f)
+        # new samples of batch j occupy slots B + n_edges[j] ... in emission order (batches are contiguous blocks)
         first_new = torch.cumsum(per_batch, 0) - per_batch
-        new_slot = B + n_edges[new_batch] + (torch.arange(new_batch.numel(), device=dev) - first_new[new_batch])
-        sizes = per_batch.tolist()
-        for j, (a, b_, c, d) in enumerate(zip(torch.split(new_nbr, sizes), torch.split(parent_slot, sizes),
-                                              torch.split(new_ep, sizes), sizes)):
-            if d:
-                samples[j].append(a)
-                cols[j].append(b_)
-                eidx[j].append(c)
+        new_slot = B + n_edges[new_batch] + (torch.arange(new_batch.numel(), **i64) - first_new[new_batch])
+        hops.append((new_batch, new_slot, new_nbr, parent_slot, new_ep))
         n_edges = n_edges + per_batch
         f_vertex, f_batch, f_slot = new_nbr, new_batch, new_slot
+        del m
+    # ---- one scatter into flat, batch-major outputs
+    node_base = torch.cumsum(B + n_edges, 0) - (B + n_edges)
+    edge_base = torch.cumsum(n_edges, 0) - n_edges
+    total_nodes, total_edges = int((B + n_edges).sum()), int(n_edges.sum())
+    samples = torch.empty(total_nodes, **i64)
+    cols, eidx = torch.empty(total_edges, **i64), torch.empty(total_edges, **i64)
+    rows = torch.empty(total_edges, **i64)
+    samples[(node_base[:, None] + torch.arange(B, **i64)[None, :]).reshape(-1)] = seeds.reshape(-1)
+    for new_batch, new_slot, new_nbr, parent_slot, new_ep in hops:
+        samples[node_base[new_batch] + new_slot] = new_nbr
+        e = edge_base[new_batch] + (new_slot - B)
+        rows[e] = new_slot                                  # rows[e] = n_seeds + e (neighbor_sampling.rs:212-217)
+        cols[e] = parent_slot
+        eidx[e] = new_ep
+    ns_host, ne_host = (B + n_edges).tolist(), n_edges.tolist()
+    hop_host = torch.stack(ne_at_hop).tolist() if ne_at_hop else []
+    s_parts, r_parts = torch.split(samples, ns_host), torch.split(rows, ne_host)
+    c_parts, e_parts = torch.split(cols, ne_host), torch.split(eidx, ne_host)
     out = []
-    ne_host = n_edges.tolist()
-    empty = torch.zeros(0, dtype=torch.int64, device=dev)
     for j in range(nb):
-        out.append((torch.cat(samples[j]), torch.arange(B, B + ne_host[j], device=dev),
-                    torch.cat(cols[j]) if cols[j] else empty, torch.cat(eidx[j]) if eidx[j] else empty,
-                    layer_offsets[j]))
+        lo = [(B + h[j], h[j], B + h[j]) for h in hop_host]           # neighbor_sampling.rs:193
+        out.append((s_parts[j], r_parts[j], c_parts[j], e_parts[j], lo))
     return out
