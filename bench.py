@@ -110,7 +110,7 @@ def main():
     dt = time.perf_counter() - t0
 
     dt_max, tot = sharding.reduce_measurement(dt, acc)
-    edges_all, frontier_all, launches_all = (int(x) for x in tot.tolist())
+    edges_all = int(tot.tolist()[0])
 
     # ---- roofline of the dominant kernel (this rank): algorithmic bytes / HIP-event kernel time
     kernel_ms = [a.elapsed_time(b) for a, b in events]

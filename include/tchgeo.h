@@ -233,10 +233,21 @@ TG_API int tg_hgt_sample(const tg_hgt_problem *problem, const tg_rng *rng, const
  * (0.57,0.19,0.19,0.05), one Philox word per bit; duplicates and self loops
  * kept.  row, col: [n_edges] device int64. */
 TG_API int tg_rmat_edges(int32_t scale, int64_t n_edges, uint64_t seed, int64_t *row, int64_t *col, void *stream);
+/* rectangular form for bipartite relations: 2^row_scale x 2^col_scale, row / column bits drawn to their own depths */
+TG_API int tg_rmat_edges_rect(int32_t row_scale, int32_t col_scale, int64_t n_edges, uint64_t seed, int64_t *row,
+                              int64_t *col, void *stream);
 
 /* Seed batches: out[b*n_seeds + i] = Philox(seed; first_batch + b, i) mod n_nodes. */
 TG_API int tg_seed_batches(uint64_t seed, int64_t first_batch, int64_t n_batches, int64_t n_seeds, int64_t n_nodes,
                     int64_t *out, void *stream);
+
+/* to_csc / to_csr (src/data/storage.rs:103-126; bindings python.rs:27-53): COO (row, col) of a size0 x size1 graph
+ * -> ptrs [size1 + 1 | size0 + 1], indices [nnz], perm [nnz] (stable sort by the reference's key
+ * col*size0+row | row*size1+col).  Negative ids are not checked. */
+TG_API int tg_coo_to_csx_workspace_bytes(int64_t nnz, int64_t size0, int64_t size1, int64_t *bytes);
+TG_API int tg_coo_to_csx(const int64_t *row, const int64_t *col, int64_t nnz, int64_t size0, int64_t size1, int32_t csc,
+                         int64_t *ptrs, int64_t *indices, int64_t *perm, void *workspace, int64_t workspace_bytes,
+                         void *stream);
 
 /* ind2ptr (src/data/storage.rs:67-101) on the device: sorted `ind` [numel] -> out [m+1]. */
 TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out, void *stream);

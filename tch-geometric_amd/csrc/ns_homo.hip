@@ -98,7 +98,6 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
             lo[1] = ne;
             lo[2] = n_seeds + ne;
         }
-        const int64_t hop_edge_base = ne;
         for (int64_t round_begin = begin; round_begin < end; round_begin += (int64_t)NS_CHUNKS_PER_ROUND * 64) {
             const int64_t round_end = min(end, round_begin + (int64_t)NS_CHUNKS_PER_ROUND * 64);
             const int nc = (int)((round_end - round_begin + 63) >> 6);
@@ -202,7 +201,6 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
             ne += chunk_off[nc];
             __syncthreads(); // chunk_off is rewritten by the next round
         }
-        (void)hop_edge_base;
         begin = end; // :221-222
         end = n_seeds + ne;
     }

@@ -10,8 +10,12 @@ constexpr uint32_t RMAT_T_A = 2448131358u;   // floor(0.57 * 2^32)
 constexpr uint32_t RMAT_T_AB = 3264175144u;  // floor(0.76 * 2^32)
 constexpr uint32_t RMAT_T_ABC = 4080218931u; // floor(0.95 * 2^32)
 
-__global__ void rmat_edges_kernel(int scale, int64_t n_edges, uint64_t seed, int64_t *row, int64_t *col) {
+// rectangular form: row bits and column bits are drawn to their own depths (level `bit` contributes a row bit
+// while bit < row_scale and a column bit while bit < col_scale); square when both scales are equal
+__global__ void rmat_edges_kernel(int row_scale, int col_scale, int64_t n_edges, uint64_t seed, int64_t *row,
+                                  int64_t *col) {
     const CallKey ck = call_key(seed, 0, TAG_RMAT);
+    const int scale = max(row_scale, col_scale);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges;
          e += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = 0, c = 0;
@@ -21,8 +25,8 @@ __global__ void rmat_edges_kernel(int scale, int64_t n_edges, uint64_t seed, int
             const uint32_t u = d.w[bit & 3];
             const int rb = u >= RMAT_T_AB;                       // quadrants c, d
             const int cb = (u >= RMAT_T_A && u < RMAT_T_AB) || u >= RMAT_T_ABC; // quadrants b, d
-            r = (r << 1) | rb;
-            c = (c << 1) | cb;
+            if (bit < row_scale) r = (r << 1) | rb;
+            if (bit < col_scale) c = (c << 1) | cb;
         }
         row[e] = r;
         col[e] = c;
@@ -69,7 +73,18 @@ extern "C" int tg_rmat_edges(int32_t scale, int64_t n_edges, uint64_t seed, int6
     TG_REQUIRE(n_edges >= 0 && (n_edges == 0 || (row && col)), "tg_rmat_edges: bad buffers");
     if (n_edges == 0) return TG_OK;
     hipLaunchKernelGGL(tg::rmat_edges_kernel, dim3(tg::grid_for(n_edges, 256)), dim3(256), 0, (hipStream_t)stream,
-                       scale, n_edges, seed, row, col);
+                       scale, scale, n_edges, seed, row, col);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_rmat_edges_rect(int32_t row_scale, int32_t col_scale, int64_t n_edges, uint64_t seed, int64_t *row,
+                                  int64_t *col, void *stream) {
+    TG_REQUIRE(row_scale >= 1 && row_scale <= 40 && col_scale >= 1 && col_scale <= 40, "tg_rmat_edges_rect: bad scales");
+    TG_REQUIRE(n_edges >= 0 && (n_edges == 0 || (row && col)), "tg_rmat_edges_rect: bad buffers");
+    if (n_edges == 0) return TG_OK;
+    hipLaunchKernelGGL(tg::rmat_edges_kernel, dim3(tg::grid_for(n_edges, 256)), dim3(256), 0, (hipStream_t)stream,
+                       row_scale, col_scale, n_edges, seed, row, col);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -164,16 +164,18 @@ std::tuple<Tensor, Tensor, Tensor> to_csx(const Tensor &row_col, const py::objec
     const c10::Device dev = compute_device({&row_col});
     DeviceGuard guard(dev);
     Tensor rc = on(row_col, dev, at::kLong);
-    Tensor row = rc.select(0, 0), col = rc.select(0, 1);
+    if (rc.dim() != 2 || rc.size(0) != 2) throw py::value_error("row_col must have shape [2, E]");
+    Tensor row = rc.select(0, 0).contiguous(), col = rc.select(0, 1).contiguous();
+    const int64_t nnz = row.numel(), m = csc ? size1 : size0;
+    if (size0 < 1 || size1 < 1) throw py::value_error("graph size must be positive");
+    Tensor ptrs = at::empty({m + 1}, i64(dev)), indices = at::empty({nnz}, i64(dev)), perm = at::empty({nnz}, i64(dev));
+    int64_t ws_bytes = 0;
+    check_rc(tg_coo_to_csx_workspace_bytes(nnz, size0, size1, &ws_bytes));
+    Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
     // storage.rs:112,119: perm = argsort(major * size_minor + minor); stable, so duplicate edges keep input order
-    Tensor key = csc ? col * size0 + row : row * size1 + col;
-    Tensor perm = std::get<1>(at::sort(key, /*stable=*/true, /*dim=*/0, /*descending=*/false));
-    Tensor major = (csc ? col : row).index_select(0, perm).contiguous();
-    Tensor indices = (csc ? row : col).index_select(0, perm).contiguous();
-    const int64_t m = csc ? size1 : size0;
-    Tensor ptrs = at::empty({m + 1}, i64(dev));
-    check_rc(tg_ind2ptr(major.numel() ? major.data_ptr<int64_t>() : nullptr, major.numel(), m,
-                        ptrs.data_ptr<int64_t>(), stream_of(dev)));
+    check_rc(tg_coo_to_csx(nnz ? row.data_ptr<int64_t>() : nullptr, nnz ? col.data_ptr<int64_t>() : nullptr, nnz, size0,
+                           size1, csc ? 1 : 0, ptrs.data_ptr<int64_t>(), nnz ? indices.data_ptr<int64_t>() : nullptr,
+                           nnz ? perm.data_ptr<int64_t>() : nullptr, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
     const c10::Device out_dev = row_col.device();
     return {back(ptrs, out_dev), back(indices, out_dev), back(perm, out_dev)};
 }

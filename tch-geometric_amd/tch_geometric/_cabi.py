@@ -19,7 +19,8 @@ FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
-           "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop"]
+           "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
+           "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx"]
 
 
 class TgGraph(C.Structure):
@@ -178,6 +179,14 @@ def rmat_edges(scale, n_edges, seed, device):
     return row, col
 
 
+def rmat_edges_rect(row_scale, col_scale, n_edges, seed, device):
+    row = torch.empty(n_edges, dtype=torch.int64, device=device)
+    col = torch.empty(n_edges, dtype=torch.int64, device=device)
+    check(lib.tg_rmat_edges_rect(C.c_int32(row_scale), C.c_int32(col_scale), C.c_int64(n_edges), C.c_uint64(seed),
+                                 ptr(row), ptr(col), stream_ptr(device)))
+    return row, col
+
+
 def seed_batches(seed, first_batch, n_batches, n_seeds, n_nodes, device):
     out = torch.empty((n_batches, n_seeds), dtype=torch.int64, device=device)
     check(lib.tg_seed_batches(C.c_uint64(seed), C.c_int64(first_batch), C.c_int64(n_batches), C.c_int64(n_seeds),
@@ -192,14 +201,19 @@ def ind2ptr(ind, m):
 
 
 def coo_to_csx(row, col, size0, size1, csc):
-    """Device ingest with the reference's sort key (storage.rs:112,119): stable sort by
-    major*size + minor, then ind2ptr.  Returns (ptrs, indices, perm)."""
-    key = (col * size0 + row) if csc else (row * size1 + col)
-    _, perm = torch.sort(key, stable=True)
-    del key
-    major = (col if csc else row)[perm]
-    indices = (row if csc else col)[perm].contiguous()
-    ptrs = ind2ptr(major.contiguous(), size1 if csc else size0)
+    """Device ingest (tg_coo_to_csx): stable radix sort by the reference's key (storage.rs:112,119), then
+    ptrs / indices.  Returns (ptrs, indices, perm)."""
+    nnz, dev = row.numel(), row.device
+    o = dict(dtype=torch.int64, device=dev)
+    m = size1 if csc else size0
+    ptrs, indices, perm = torch.empty(m + 1, **o), torch.empty(nnz, **o), torch.empty(nnz, **o)
+    nbytes = C.c_int64(0)
+    check(lib.tg_coo_to_csx_workspace_bytes(C.c_int64(nnz), C.c_int64(size0), C.c_int64(size1), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, **o)
+    row, col = row.contiguous(), col.contiguous()
+    check(lib.tg_coo_to_csx(ptr(row) if nnz else None, ptr(col) if nnz else None, C.c_int64(nnz), C.c_int64(size0),
+                            C.c_int64(size1), C.c_int32(int(csc)), ptr(ptrs), ptr(indices), ptr(perm), ptr(ws),
+                            C.c_int64(nbytes.value), stream_ptr(dev)))
     return ptrs, indices, perm
 
 

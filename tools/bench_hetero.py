@@ -1,0 +1,63 @@
+"""BASELINE cfg4: neighbor_sampling_heterogenous and hgt_sampling through the operator surface on a synthetic
+3-node-type / 5-edge-type graph (A = 2^23, B = 2^22, C = 2^22 nodes; 20 M rectangular R-MAT edges per relation),
+1024 seeds of type A, 2 hops.  Per-call latency (the surface is one call per mini-batch).  Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tch-geometric_amd"))
+import tch_geometric as tg  # noqa: E402
+from tch_geometric import _cabi  # noqa: E402
+
+dev = torch.device("cuda:0")
+scales = {"A": 23, "B": 22, "C": 22}
+edge_types = [("A", "e0", "A"), ("A", "e1", "B"), ("B", "e2", "A"), ("B", "e3", "C"), ("C", "e4", "A")]
+E = int(os.environ.get("EDGES", 20_000_000))
+P, I = {}, {}
+for r, (s, _, d) in enumerate(edge_types):
+    row, col = _cabi.rmat_edges_rect(scales[s], scales[d], E, 0xC0F4 + r, dev)
+    key = "%s__%s__%s" % (s, edge_types[r][1], d)
+    P[key], I[key], _ = _cabi.coo_to_csx(row, col, 1 << scales[s], 1 << scales[d], True)
+node_types = ["A", "B", "C"]
+res = {"config": "3 ntypes (2^23, 2^22, 2^22), 5 etypes x %d edges, 1024 seeds of type A, 2 hops" % E}
+
+
+def timeit(fn, reps=20):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, out
+
+
+tg.seed(1)
+calls = [0]
+
+
+def seeds():
+    calls[0] += 1
+    return _cabi.seed_batches(0xBA7C4, calls[0], 1, 1024, 1 << 23, dev)[0].contiguous()
+
+
+nn = {k: [15, 10] for k in P}
+dt, out = timeit(lambda: tg.neighbor_sampling_heterogenous(node_types, edge_types, P, I, {"A": seeds()}, nn, 2))
+edges = sum(int(v.numel()) for v in out[1].values())
+res["neighbor_sampling_heterogenous"] = {"ms_per_call": dt * 1e3, "sampled_edges_per_call": edges,
+                                         "edges_per_s": edges / dt}
+ns = {t: [512, 512] for t in node_types}
+dt, out = timeit(lambda: tg.hgt_sampling(node_types, edge_types, P, I, None, {"A": seeds()}, None, ns, 2))
+nodes = sum(int(v.numel()) for v in out[0].values())
+edges = sum(int(v.numel()) for v in out[2].values())
+res["hgt_sampling"] = {"ms_per_call": dt * 1e3, "nodes_per_call": nodes, "edges_per_call": edges,
+                       "nodes_plus_edges_per_s": (nodes + edges) / dt}
+dt, out = timeit(lambda: tg.neighbor_sampling_homogenous(P["A__e0__A"], I["A__e0__A"], seeds(), [15, 10]))
+res["neighbor_sampling_homogenous_single_call"] = {"ms_per_call": dt * 1e3, "sampled_edges_per_call": int(out[1].numel()),
+                                                   "edges_per_s": int(out[1].numel()) / dt}
+print(json.dumps(res))
