@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -85,6 +86,12 @@ __global__ void scan_i64_kernel(const int64_t *__restrict__ in, const int64_t *n
         __syncthreads();
     }
     if (tid == 0) total[0] = carry_s;
+}
+
+// total of a flag array after its exclusive scan
+__global__ void scan_total_kernel(const int64_t *__restrict__ in, const int64_t *__restrict__ excl, int64_t n,
+                                  int64_t *total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) total[0] = n > 0 ? excl[n - 1] + in[n - 1] : 0;
 }
 
 // ---------------------------------------------------------------- inputs (hgt_sampling.rs:167-180)
@@ -167,11 +174,11 @@ __global__ void hgt_contrib_slots_kernel(HgtType src, const int64_t *mc, const i
 }
 __global__ void hgt_first_flags_kernel(const int64_t *mc, const int64_t *__restrict__ ckey,
                                        const int64_t *__restrict__ cslot, const int64_t *tmp_keys,
-                                       const int64_t *tmp_vals, int64_t tmp_mask, int64_t *flag) {
+                                       const int64_t *tmp_vals, int64_t tmp_mask, int64_t cap, int64_t *flag) {
     const int64_t n = *mc;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
         int64_t f = 0;
-        if (cslot[p] == -1) {
+        if (p < n && cslot[p] == -1) {
             const int64_t t = map_slot_find(tmp_keys, tmp_mask, ckey[p]);
             f = (tmp_vals[t] == p);
         }
@@ -326,51 +333,56 @@ __global__ void hgt_empty_layer_kernel(HgtTypeCtr *ctr) { // a type without a bu
 }
 
 // ---------------------------------------------------------------- edges (hgt_sampling.rs:244-268)
-// one lane per destination node; candidates at a fixed stride of 50, -1 where dropped
+// one WAVEFRONT per destination node; candidates at a fixed stride of 50, -1 where dropped.  Lane s owns
+// reservoir slot s: the ticket chain (k = 50 sequential bounded draws over a shrinking urn) is resolved with
+// ballots over the lanes' displaced entries, then all slots gather and look up `to_local` in parallel.
 __global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
                                            const int64_t *__restrict__ indices, int64_t cap_nodes, uint64_t seed,
                                            uint64_t call_id, uint32_t tag, int64_t *cand_j, int64_t *cand_ep) {
-    __shared__ uint32_t keys[64 * HGT_MAX_NB], vals[64 * HGT_MAX_NB];
-    const int lane = threadIdx.x & 63;
-    uint32_t *K = keys + lane * HGT_MAX_NB, *V = vals + lane * HGT_MAX_NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int64_t n_nodes = dst.ctr->n_nodes;
     const CallKey ck = call_key(seed, call_id, tag);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap_nodes;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * n_waves + wave; i < cap_nodes; i += (int64_t)gridDim.x * n_waves) {
         int64_t *cj = cand_j + i * HGT_MAX_NB, *ce = cand_ep + i * HGT_MAX_NB;
         if (i >= n_nodes) {
-            for (int s = 0; s < HGT_MAX_NB; ++s) cj[s] = -1;
+            if (lane < HGT_MAX_NB) cj[lane] = -1;
             continue;
         }
         const int64_t w = dst.nodes[i];
         const int64_t b = ptrs[w], len = ptrs[w + 1] - b;
         const int k = (int)min(len, (int64_t)HGT_MAX_NB); // :258
-        Draw d;
-        for (int s = 0; s < HGT_MAX_NB; ++s) {
-            int64_t j = -1, ep = -1;
-            if (s < k) {
-                int64_t pos = s;
-                if (len > HGT_MAX_NB) { // reservoir by tickets, k = 50
-                    const uint32_t n = (uint32_t)len;
-                    const uint32_t m = (n - 1u) - (uint32_t)s;
-                    if ((s & 1) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 1), 0u);
-                    const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
-                    uint32_t tr = r, tl = last;
-                    for (int q = 0; q < s; ++q) {
-                        tr = (K[q] == r) ? V[q] : tr;
-                        tl = (K[q] == last) ? V[q] : tl;
-                    }
-                    K[s] = r;
-                    V[s] = tl;
-                    pos = (tr < n - (uint32_t)k) ? (int64_t)k + tr : (int64_t)s;
+        int64_t pos = lane;
+        if (len > HGT_MAX_NB) { // reservoir by tickets, k = 50
+            const uint32_t n = (uint32_t)len;
+            uint32_t myK = 0xffffffffu, myV = 0, mypos = 0;
+            Draw d;
+            for (int s = 0; s < HGT_MAX_NB; ++s) {
+                const uint32_t m = (n - 1u) - (uint32_t)s;
+                if ((s & 1) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 1), 0u);
+                const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                const uint64_t mr = __ballot(lane < s && myK == r);     // the latest displaced entry wins
+                const uint64_t ml = __ballot(lane < s && myK == last);
+                const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);
+                const uint32_t vl = __shfl(myV, ml ? 63 - __clzll((long long)ml) : 0, 64);
+                const uint32_t tr = mr ? vr : r, tl = ml ? vl : last;
+                if (lane == s) {
+                    myK = r;
+                    myV = tl;
+                    mypos = (tr < n - (uint32_t)HGT_MAX_NB) ? (uint32_t)HGT_MAX_NB + tr : (uint32_t)s;
                 }
+            }
+            pos = mypos;
+        }
+        if (lane < HGT_MAX_NB) {
+            int64_t j = -1, ep = -1;
+            if (lane < k) {
                 ep = b + pos;
                 const int64_t v = indices[ep];
                 const int64_t h = map_slot_find(src.tl_keys, src.tl_mask, v); // :263
                 if (h >= 0) j = src.tl_vals[h];
             }
-            cj[s] = j;
-            ce[s] = ep;
+            cj[lane] = j;
+            ce[lane] = ep;
         }
     }
 }
@@ -398,7 +410,7 @@ struct HgtPlan {
     int T, R, H;
     std::vector<int64_t> cap_nodes, cap_budget, tl_cap, bm_cap;
     int64_t max_layer, mc_cap, tmp_cap, max_budget, max_k, edge_cap, scan_cap;
-    size_t sort_temp_bytes;
+    size_t sort_temp_bytes, scan_temp_bytes;
     size_t total_bytes;
 };
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -449,6 +461,11 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
                                              (int64_t *)nullptr, (size_t)pl.mc_cap, 0, 64, (hipStream_t)0, false);
     if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
     pl.sort_temp_bytes = st;
+    size_t sc = 0;
+    e = rocprim::exclusive_scan(nullptr, sc, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)pl.scan_cap,
+                                rocprim::plus<int64_t>(), (hipStream_t)0, false);
+    if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::exclusive_scan size query failed: %s", hipGetErrorString(e));
+    pl.scan_temp_bytes = sc;
     size_t b = 0;
     b += align16(sizeof(HgtTypeCtr) * pl.T + 64); // counters + misc scalars
     for (int t = 0; t < pl.T; ++t) {
@@ -464,6 +481,7 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     b += align16(8 * (size_t)pl.max_k);          // chosen
     b += align16(8 * (size_t)pl.edge_cap) * 2;   // cand_j, cand_ep
     b += align16(pl.sort_temp_bytes);
+    b += align16(pl.scan_temp_bytes);
     pl.total_bytes = b + 256;
     return TG_OK;
 }
@@ -550,6 +568,15 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     int64_t *cand_j = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
     int64_t *cand_ep = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
     void *sort_temp = take(pl.sort_temp_bytes);
+    void *scan_temp = take(pl.scan_temp_bytes);
+    // exclusive scan of flag[0..n) into rank[], total into *total (device-wide, rocPRIM)
+    auto device_scan = [&](int64_t n, int64_t *total) -> int {
+        size_t stb = pl.scan_temp_bytes;
+        TG_HIP(rocprim::exclusive_scan(scan_temp, stb, flag, rank, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), stream,
+                                       false));
+        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, flag, rank, n, total);
+        return TG_OK;
+    };
 
     // ---- update_budget for the current layer of node type nt (:27-102)
     auto update_budget = [&](int nt) -> int {
@@ -571,9 +598,8 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             hipLaunchKernelGGL(hgt_contrib_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st],
                                scal + 0, ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1);
             hipLaunchKernelGGL(hgt_first_flags_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, ckey,
-                               cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, flag);
-            hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, flag, scal + 0, (int64_t)0, rank,
-                               scal + 1);
+                               cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, pl.mc_cap, flag);
+            if (int rcs = device_scan(pl.mc_cap, scal + 1)) return rcs;
             hipLaunchKernelGGL(hgt_new_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], scal + 0,
                                ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, rank);
             hipLaunchKernelGGL(hgt_bump_budget_kernel, dim3(1), dim3(1), 0, stream, ctr + st, scal + 1);
@@ -610,8 +636,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             const int64_t k = pb->num_samples[(size_t)t * H + layer];
             hipLaunchKernelGGL(hgt_live_flags_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t],
                                pl.cap_budget[t], flag);
-            hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, flag, (const int64_t *)nullptr,
-                               pl.cap_budget[t], rank, scal + 2);
+            if (int rcs = device_scan(pl.cap_budget[t], scal + 2)) return rcs;
             hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], flag,
                                rank, live);
             const size_t lds = (size_t)(k > 0 ? k : 1) * 8;
@@ -633,12 +658,11 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         const tg_graph &g = pb->graphs[r];
         const int64_t cap_n = pl.cap_nodes[dt] > 0 ? pl.cap_nodes[dt] : 1;
         const int64_t nq = cap_n * HGT_MAX_NB;
-        hipLaunchKernelGGL(hgt_edge_candidates_kernel, dim3((unsigned)((cap_n + 63) / 64)), dim3(64), 0, stream, ty[dt],
-                           ty[st], g.ptrs, g.indices, cap_n, rng->seed, rng->call_id,
-                           TAG_HGT | ((uint32_t)(r + 1) << 8), cand_j, cand_ep);
+        hipLaunchKernelGGL(hgt_edge_candidates_kernel, dim3(grid_1d(cap_n * 64)), dim3(256), 0, stream, ty[dt], ty[st],
+                           g.ptrs, g.indices, cap_n, rng->seed, rng->call_id, TAG_HGT | ((uint32_t)(r + 1) << 8), cand_j,
+                           cand_ep);
         hipLaunchKernelGGL(hgt_edge_flags_kernel, dim3(grid_1d(nq)), dim3(256), 0, stream, cand_j, nq, flag);
-        hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, flag, (const int64_t *)nullptr, nq, rank,
-                           out->n_edges + r);
+        if (int rcs = device_scan(nq, out->n_edges + r)) return rcs;
         hipLaunchKernelGGL(hgt_edge_emit_kernel, dim3(grid_1d(nq)), dim3(256), 0, stream, cand_j, cand_ep, rank, nq,
                            out->rows[r], out->cols[r], out->edge_index[r]);
         TG_LAUNCH_CHECK();
