@@ -227,6 +227,30 @@ TG_API int tg_hgt_workspace_bytes(const tg_hgt_problem *problem, int64_t *bytes)
 TG_API int tg_hgt_sample(const tg_hgt_problem *problem, const tg_rng *rng, const tg_hgt_out *out, void *workspace,
                          int64_t workspace_bytes, void *stream);
 
+/* budget_sampling (src/algo/budget_sampling.rs:63-265; binding python.rs:486-581), one (layer, node type) at a
+ * time: Budget::update + Budget::sample for every frontier node of the type (SURVEY.md 8(f) "next" row).  The host
+ * appends the selected candidates in (node, slot) order.  Selected slot (j, s) lives at [j * fanout + s];
+ * sel_rel < 0 marks an empty slot. */
+typedef struct {
+    const tg_graph *graphs;  /* host [n_rels]: CSC of the relations INTO the node type (timestamps optional) */
+    const int32_t *rel_ids;  /* host [n_rels]: their index in the caller's relation list */
+    int32_t n_rels;
+    int32_t node_type;       /* index of the type being expanded (rng tag) */
+    int32_t fanout;          /* num_neighbors[type][layer], <= 64 */
+    int32_t filter_on, forward, relative;
+    int64_t win_lo, win_hi;  /* half-open window */
+    const int64_t *nodes;    /* [n_front] frontier nodes of the type */
+    const int64_t *nodes_ts; /* [n_front] */
+    int64_t n_front;
+    int64_t id_base;         /* slot of nodes[0] in the type's sample list (draw id = id_base + j) */
+} tg_budget_layer_in;
+
+typedef struct {
+    int64_t *sel_v, *sel_ts, *sel_rel, *sel_i; /* each [n_front * fanout] */
+} tg_budget_layer_out;
+
+TG_API int tg_budget_layer(const tg_budget_layer_in *in, const tg_rng *rng, const tg_budget_layer_out *out, void *stream);
+
 /* ---- synthetic inputs of the measurement harness ---- */
 
 /* R-MAT edge list: n_edges edges over 2^scale vertices, (a,b,c,d) =

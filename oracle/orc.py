@@ -405,3 +405,54 @@ def hgt(node_types, edge_types, col_ptrs, row_indices, row_timestamps, inputs, i
         return samples, ts, rows, cols, eidx
     finally:
         L.orc_het_free(C.c_void_p(h))
+
+
+# ---------------------------------------------------------------- budget sampling
+class BudgetFilter(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("forward", C.c_int32), ("relative", C.c_int32), ("_pad", C.c_int32),
+                ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
+def budget(node_types, edge_types, col_ptrs, row_indices, row_timestamps, inputs, input_timestamps, num_neighbors,
+           num_hops, rng, window=None, forward=False, relative=False):
+    """budget_sampling -> (samples, sample_ts, rows, cols, edge_index) dicts (canonical relation order)."""
+    L = lib()
+    L.orc_budget_sampling.restype = C.c_void_p
+    L.orc_het_copy_sample_ts.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    T, R, H = len(node_types), len(edge_types), num_hops
+    tix = {t: i for i, t in enumerate(node_types)}
+    rels = [_rel_key(e) for e in edge_types]
+    rel_src = (C.c_int32 * R)(*[tix[e[0]] for e in edge_types])
+    rel_dst = (C.c_int32 * R)(*[tix[e[2]] for e in edge_types])
+    P = [_i64(col_ptrs[r]) for r in rels]
+    I = [_i64(row_indices[r]) for r in rels]
+    TS = None
+    if row_timestamps is not None:
+        TS = [_i64(row_timestamps[r]) if r in row_timestamps else None for r in rels]
+    IN = [_i64(inputs[t]) if t in inputs else None for t in node_types]
+    n_in = _i64([a.size if a is not None else -1 for a in IN])
+    ITS = None
+    if input_timestamps is not None:
+        ITS = [_i64(input_timestamps[t]) if t in input_timestamps else None for t in node_types]
+    nn = _i64([[num_neighbors[t][h] if t in num_neighbors else -1 for h in range(H)] for t in node_types]).reshape(-1)
+    flt = BudgetFilter()
+    if window is not None:
+        flt.enabled, flt.forward, flt.relative = 1, int(bool(forward)), int(bool(relative))
+        flt.lo, flt.hi = window
+    status = C.c_int32(0)
+    h = L.orc_budget_sampling(C.c_int32(T), C.c_int32(R), rel_src, rel_dst, _ptr_array(P), _ptr_array(I),
+                     _ptr_array(TS) if TS is not None else C.c_void_p(0), _ptr_array(IN), _p(n_in),
+                     _ptr_array(ITS) if ITS is not None else C.c_void_p(0), _p(nn), C.c_int32(H), C.byref(flt),
+                     C.byref(rng), C.byref(status))
+    try:
+        if status.value != 0:
+            raise RuntimeError("oracle budget: the reference would panic")
+        samples, rows, cols, eidx, _ = _unpack_het(h, node_types, rels, 0)
+        ts = {}
+        for t, name in enumerate(node_types):
+            a = np.empty(len(samples[name]), dtype=np.int64)
+            L.orc_het_copy_sample_ts(C.c_void_p(h), t, _p(a))
+            ts[name] = a
+        return samples, ts, rows, cols, eidx
+    finally:
+        L.orc_het_free(C.c_void_p(h))

@@ -44,6 +44,7 @@
 #define ORC_TAG_HGT 7u
 #define ORC_TAG_RMAT 8u
 #define ORC_TAG_SEEDS 9u
+#define ORC_TAG_BUDGET 10u /* | node-type index << 8 */
 
 typedef struct {
     int32_t mode;

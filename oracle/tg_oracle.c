@@ -1101,3 +1101,99 @@ ORC_API orc_het_out *orc_hgt(int32_t T, int32_t R, const int32_t *rel_src, const
     free(lay_has);
     return o;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* Budget sampling: src/algo/budget_sampling.rs (SURVEY 8(f) "next")   */
+/* ------------------------------------------------------------------ */
+/* budget_sampling.rs:19-38 TemporalFilter (half-open window, python.rs:541-548) */
+typedef struct {
+    int32_t enabled, forward, relative, _pad;
+    int64_t lo, hi;
+} orc_budget_filter;
+static inline int budget_filter_pass(const orc_budget_filter *f, int64_t state, int64_t t) { /* :20-29 */
+    if (state == ORC_NAN_TS || t == ORC_NAN_TS) return 1;
+    int64_t x = f->forward ? (t - state) : -(t - state);
+    return f->lo <= x && x < f->hi;
+}
+
+/* budget_sampling.rs:155-265 budget_neighbor_sampling_heterogenous.  Canonical order: the budget of a node
+ * lists relations in `edge_types` order (:81 iterates a HashMap).  num_neighbors[t*H + layer] (< 0: missing key
+ * -> the reference panics at :226).  NOTE the reference stores the neighbour's index INSIDE the column as the
+ * edge's `edge_index` (:116 `*i as EdgePtr`), not the CSC edge pointer; kept.  layer_offsets stay empty (:199-201).
+ * philox address of a node's reservoir (:138): tag ORC_TAG_BUDGET | type << 8, id = slot of the node. */
+ORC_API orc_het_out *orc_budget_sampling(int32_t T, int32_t R, const int32_t *rel_src, const int32_t *rel_dst,
+                                const int64_t *const *ptrs, const int64_t *const *indices, const int64_t *const *rel_ts,
+                                const int64_t *const *inputs, const int64_t *n_inputs, const int64_t *const *input_ts,
+                                const int64_t *num_neighbors, int32_t H, const orc_budget_filter *filter, orc_rng *rng,
+                                int32_t *status) {
+    orc_het_out *o = het_alloc(T, R, 0);
+    *status = 0;
+    for (int t = 0; t < T; t++) /* :181-197 */
+        for (int64_t i = 0; i < (n_inputs[t] > 0 ? n_inputs[t] : 0); i++) {
+            vpush(&o->samples[t], inputs[t][i]);
+            vpush(&o->ts[t], (input_ts && input_ts[t]) ? input_ts[t][i] : ORC_NAN_TS);
+        }
+    int64_t *begin = (int64_t *)calloc((size_t)T, sizeof(int64_t)), *end = (int64_t *)calloc((size_t)T, sizeof(int64_t));
+    for (int t = 0; t < T; t++) end[t] = o->samples[t].n; /* :207-209 */
+    /* a candidate: (relation, index in column, node, timestamp) */
+    typedef struct {
+        int32_t rel;
+        int64_t i, v, ts;
+    } cand_t;
+    cand_t *cand = (cand_t *)malloc(sizeof(cand_t) * (size_t)(50 * (R > 0 ? R : 1)));
+    for (int32_t layer = 0; layer < H && *status == 0; layer++) { /* :223 */
+        for (int t = 0; t < T && *status == 0; t++) { /* :225 node_types order (a Vec in the reference) */
+            int64_t k = num_neighbors[t * H + layer];
+            if (k < 0) {
+                *status = -1;
+                break;
+            }
+            orc_ctx c;
+            orc_ctx_init(&c, rng, ORC_TAG_BUDGET | ((uint32_t)t << 8));
+            int64_t *dst = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? k : 1));
+            int64_t *scratch = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k > 0 ? 2 * k : 2));
+            for (int64_t j = begin[t]; j < end[t]; j++) { /* :230 */
+                /* Budget::update for node j (:81-122): relations into type t, first min(deg,50) neighbours each */
+                int64_t w = o->samples[t].p[j], w_t = o->ts[t].p[j], n = 0;
+                for (int r = 0; r < R; r++) {
+                    if (rel_dst[r] != t) continue;
+                    int64_t b = ptrs[r][w], len = ptrs[r][w + 1] - b;
+                    int64_t cnt = len < 50 ? len : 50; /* :100 no draws: a column prefix */
+                    for (int64_t i = 0; i < cnt; i++) {
+                        int64_t v_t = (rel_ts && rel_ts[r]) ? rel_ts[r][b + i] : ORC_NAN_TS; /* :103 */
+                        if (v_t == ORC_NAN_TS) v_t = w_t;                                    /* :104-106 */
+                        if (filter->enabled && !budget_filter_pass(filter, w_t, v_t)) continue; /* :108-112 */
+                        cand[n].rel = r;
+                        cand[n].i = i;
+                        cand[n].v = indices[r][b + i];
+                        cand[n].ts = filter->enabled ? (filter->relative ? w_t : v_t) : v_t; /* :117-119 */
+                        n++;
+                    }
+                }
+                /* Budget::sample (:137-151) */
+                int64_t cnt = (k > 0) ? orc_reservoir(&c, (uint64_t)j, 0, n, k, dst, scratch, ORC_RES_TICKETS) : 0;
+                for (int64_t s = 0; s < cnt; s++) {
+                    const cand_t *q = &cand[dst[s]];
+                    int st = rel_src[q->rel];
+                    int64_t i_new = o->samples[st].n; /* :147 */
+                    vpush(&o->samples[st], q->v);
+                    vpush(&o->ts[st], q->ts);
+                    vpush(&o->rows[q->rel], i_new); /* :150 push_edge(i, j, edge_ptr) */
+                    vpush(&o->cols[q->rel], j);
+                    vpush(&o->eidx[q->rel], q->i);
+                }
+            }
+            free(dst);
+            free(scratch);
+        }
+        for (int t = 0; t < T; t++) { /* :240-243 */
+            begin[t] = end[t];
+            end[t] = o->samples[t].n;
+        }
+    }
+    free(cand);
+    free(begin);
+    free(end);
+    return o;
+}

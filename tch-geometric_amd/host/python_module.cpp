@@ -428,7 +428,6 @@ PYBIND11_MODULE(tch_geometric, m) {
     m.def("tempo_random_walk", &tempo_random_walk, py::arg("row_ptrs"), py::arg("col_indices"),
           py::arg("node_timestamps"), py::arg("edge_timestamps"), py::arg("start"), py::arg("start_timestamps"),
           py::arg("walk_length"), py::arg("window"));
-    m.def("budget_sampling", [](py::args, py::kwargs) { out_of_scope("budget_sampling"); });
     m.def("biased_tempo_random_walk", [](py::args, py::kwargs) { out_of_scope("biased_tempo_random_walk"); });
     register_more(m);
 }

@@ -161,7 +161,8 @@ py::tuple negative_sample_neighbors_heterogenous(const std::vector<std::string> 
 
 } // namespace
 
-void register_hgt(py::module_ &m); // python_module_hgt.cpp
+void register_hgt(py::module_ &m);    // python_module_hgt.cpp
+void register_budget(py::module_ &m); // python_module_budget.cpp
 
 void register_more(py::module_ &m) {
     m.def("negative_sample_neighbors_homogenous", &negative_sample_neighbors_homogenous, py::arg("row_ptrs"),
@@ -170,4 +171,5 @@ void register_more(py::module_ &m) {
           py::arg("edge_types"), py::arg("row_ptrs"), py::arg("col_indices"), py::arg("sizes"), py::arg("inputs"),
           py::arg("num_neg"), py::arg("try_count"), py::arg("inbound"));
     register_hgt(m);
+    register_budget(m);
 }

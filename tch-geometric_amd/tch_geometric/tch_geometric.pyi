@@ -62,6 +62,14 @@ def negative_sample_neighbors_heterogenous(
     num_neg: int, try_count: int, inbound: bool,
 ) -> Tuple[Dict[NodeType, Tensor], Dict[RelType, Tensor], Dict[RelType, Tensor], Dict[NodeType, int]]: ...
 
-# outside this backend's scope; the names exist and raise RuntimeError
-def budget_sampling(*args, **kwargs): ...
+def budget_sampling(
+    node_types: List[NodeType], edge_types: List[EdgeType], col_ptrs: Dict[RelType, Tensor],
+    row_indices: Dict[RelType, Tensor], row_timestamps: Optional[Dict[RelType, Tensor]],
+    inputs: Dict[NodeType, Tensor], input_timestamps: Optional[Dict[NodeType, Tensor]],
+    num_neighbors: Dict[NodeType, List[int]], num_hops: int, window: Optional[Tuple[int, int]], forward: bool,
+    relative: bool,
+) -> Tuple[Dict[NodeType, Tensor], Dict[NodeType, Tensor], Dict[RelType, Tensor], Dict[RelType, Tensor],
+           Dict[RelType, Tensor]]: ...
+
+# outside this backend's scope; the name exists and raises RuntimeError
 def biased_tempo_random_walk(*args, **kwargs): ...

@@ -99,7 +99,7 @@ def test_error_behaviour(tg):
     with pytest.raises(ValueError):
         tg.neighbor_sampling_homogenous(P, I, torch.tensor([0]).cuda(), [0])
     with pytest.raises(RuntimeError, match="outside this backend's scope"):
-        tg.budget_sampling()
+        tg.biased_tempo_random_walk()
     with pytest.raises(RuntimeError):                                           # sampling.rs:49 panic
         tg.neighbor_sampling_homogenous(torch.tensor([0, 2, 2]).cuda(), torch.tensor([0, 1]).cuda(),
                                         torch.tensor([0]).cuda(), [1],      # 2 candidates, 1 slot: one float draw
