@@ -273,6 +273,11 @@ TG_API int tg_coo_to_csx(const int64_t *row, const int64_t *col, int64_t nnz, in
                          int64_t *ptrs, int64_t *indices, int64_t *perm, void *workspace, int64_t workspace_bytes,
                          void *stream);
 
+/* Input validation for hosts: sets flag[0] |= 1 (device int32, zeroed by the caller) when any of values[0..n) lies
+ * outside [lo, hi).  The samplers index `ptrs` with their inputs and do NOT check them (the reference panics on an
+ * out-of-range node id; a device kernel would fault). */
+TG_API int tg_check_range(const int64_t *values, int64_t n, int64_t lo, int64_t hi, int32_t *flag, void *stream);
+
 /* ind2ptr (src/data/storage.rs:67-101) on the device: sorted `ind` [numel] -> out [m+1]. */
 TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out, void *stream);
 

@@ -59,6 +59,14 @@ __global__ void ind2ptr_kernel(const int64_t *ind, int64_t numel, int64_t m, int
     }
 }
 
+// flag[0] |= 1 when any value lies outside [lo, hi)
+__global__ void check_range_kernel(const int64_t *__restrict__ v, int64_t n, int64_t lo, int64_t hi, int32_t *flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bad |= (v[i] < lo) | (v[i] >= hi);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 static inline unsigned grid_for(int64_t n, int threads) {
     int64_t g = (n + threads - 1) / threads;
     if (g < 1) g = 1;
@@ -104,6 +112,15 @@ extern "C" int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t 
     TG_REQUIRE(numel >= 0 && m >= 0 && out && (ind || numel == 0), "tg_ind2ptr: bad arguments");
     hipLaunchKernelGGL(tg::ind2ptr_kernel, dim3(tg::grid_for(m + 1, 256)), dim3(256), 0, (hipStream_t)stream, ind,
                        numel, m, out);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_check_range(const int64_t *values, int64_t n, int64_t lo, int64_t hi, int32_t *flag, void *stream) {
+    TG_REQUIRE(n >= 0 && flag && (values || n == 0), "tg_check_range: bad arguments");
+    if (n == 0) return TG_OK;
+    hipLaunchKernelGGL(tg::check_range_kernel, dim3(tg::grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, values, n,
+                       lo, hi, flag);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -93,6 +93,24 @@ inline Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
 inline Tensor back(const Tensor &t, const c10::Device &out_dev) { return t.device() == out_dev ? t : t.to(out_dev); }
 inline at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions().dtype(at::kLong).device(dev); }
 
+// Collects range checks of node-id inputs on the device; `verify()` reads the flag (one tiny copy) and raises.
+// The reference panics (index out of bounds) on such inputs; a device kernel would fault instead.
+struct RangeCheck {
+    Tensor flag;
+    c10::Device dev;
+    explicit RangeCheck(const c10::Device &d) : flag(at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(d))), dev(d) {}
+    void add(const Tensor &values, int64_t hi) { // values on `dev`, contiguous int64; valid ids are [0, hi)
+        if (values.numel() == 0) return;
+        check_rc(tg_check_range(values.data_ptr<int64_t>(), values.numel(), 0, hi, flag.data_ptr<int32_t>(),
+                                stream_of(dev)));
+    }
+    void verify(const char *what) const {
+        if (flag.item<int32_t>() != 0)
+            throw py::index_error(std::string(what) + ": a node id is outside the graph (the reference panics with an "
+                                                      "index out of bounds here)");
+    }
+};
+
 inline std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257
     return std::get<0>(e) + "__" + std::get<1>(e) + "__" + std::get<2>(e);
 }

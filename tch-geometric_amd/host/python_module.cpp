@@ -198,6 +198,9 @@ py::tuple neighbor_sampling_homogenous(const Tensor &col_ptrs, const Tensor &row
         st = on(as_homogeneous(f.state), dev, at::kLong).reshape({-1});
         if (st.numel() != seeds.numel()) throw py::value_error("filter state must have one entry per input");
     }
+    RangeCheck rc(dev);
+    rc.add(seeds, ptrs.numel() - 1);
+    rc.verify("neighbor_sampling_homogenous inputs");
     NsResult r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0);
     const c10::Device out_dev = inputs.device();
     return py::make_tuple(back(r.samples.narrow(0, 0, r.n_samples), out_dev),
@@ -284,6 +287,11 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         if (has_state) st_chunks[t].push_back(frontier_st[t]);
         len[t] = frontier[t].numel();
     }
+    {
+        RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
+        for (const Rel &r : rels) rc.add(frontier[r.dst], r.ptrs.numel() - 1);
+        rc.verify("neighbor_sampling_heterogenous inputs");
+    }
 
     for (int64_t ell = 0; ell < num_hops; ++ell) { // :292
         for (size_t t = 0; t < T; ++t) {
@@ -342,6 +350,9 @@ Tensor random_walk(const Tensor &row_ptrs, const Tensor &col_indices, const Tens
     Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
     Tensor st = on(start, dev, at::kLong).reshape({-1});
     if (walk_length < 0) throw py::value_error("walk_length must be >= 0");
+    RangeCheck rc(dev);
+    rc.add(st, ptrs.numel() - 1);
+    rc.verify("random_walk start");
     Tensor walks = at::empty({st.numel(), walk_length + 1}, i64(dev));
     tg_graph g{};
     g.ptrs = ptrs.data_ptr<int64_t>();
@@ -366,6 +377,11 @@ std::tuple<Tensor, Tensor> tempo_random_walk(const Tensor &row_ptrs, const Tenso
     Tensor st = on(start, dev, at::kLong).reshape({-1}), sts = on(start_timestamps, dev, at::kLong).reshape({-1});
     if (walk_length < 0) throw py::value_error("walk_length must be >= 0");
     if (sts.numel() != st.numel()) throw py::value_error("start_timestamps must have one entry per start node");
+    if (nts.numel() < ptrs.numel() - 1) throw py::value_error("node_timestamps must have one entry per node");
+    if (ets.numel() != idx.numel()) throw py::value_error("edge_timestamps must have one entry per edge");
+    RangeCheck rc(dev);
+    rc.add(st, ptrs.numel() - 1);
+    rc.verify("tempo_random_walk start");
     Tensor walks = at::full({st.numel(), walk_length}, -1, i64(dev));
     Tensor wts = at::full({st.numel(), walk_length}, -1, i64(dev));
     tg_graph g{};

@@ -79,6 +79,11 @@ py::tuple budget_sampling(const std::vector<std::string> &node_types,
         ts_chunks[(size_t)t].push_back(frontier_ts[(size_t)t]);
         len[(size_t)t] = n;
     }
+    {
+        RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
+        for (const Rel &r : rels) rc.add(frontier[(size_t)r.dst], r.ptrs.numel() - 1);
+        rc.verify("budget_sampling inputs");
+    }
     tg_budget_layer_in in{};
     if (!window.is_none()) { // python.rs:541-548
         auto w = window.cast<std::pair<int64_t, int64_t>>();

@@ -85,6 +85,12 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
             }
         }
     }
+    {
+        RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
+        for (int r = 0; r < R; ++r)
+            if (n_in[(size_t)rel_dst[(size_t)r]] > 0) rc.add(in[(size_t)rel_dst[(size_t)r]], ptrs[(size_t)r].numel() - 1);
+        rc.verify("hgt_sampling inputs");
+    }
     tg_hgt_problem pb{};
     pb.n_types = T;
     pb.n_rels = R;

@@ -92,6 +92,9 @@ py::tuple negative_sample_neighbors_homogenous(const Tensor &row_ptrs, const Ten
     Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
     Tensor in = on(inputs, dev, at::kLong).reshape({-1});
     if (graph_size.second < 1) throw py::value_error("graph_size[1] must be >= 1 (the reference panics on an empty range)");
+    RangeCheck rc(dev);
+    rc.add(in, ptrs.numel() - 1);
+    rc.verify("negative_sample_neighbors_homogenous inputs");
     NegRun r = run_neg(dev, 1, {0}, {0}, {ptrs}, {idx}, {graph_size.second}, {in}, {in.numel()}, num_neg, try_count,
                        false, true);
     const c10::Device out_dev = inputs.device();
@@ -145,6 +148,12 @@ py::tuple negative_sample_neighbors_heterogenous(const std::vector<std::string> 
         }
         in[(size_t)t] = on(x, dev, at::kLong).reshape({-1});
         n_in[(size_t)t] = in[(size_t)t].numel();
+    }
+    {
+        RangeCheck rc(dev); // an input of type t indexes the rows of every relation whose src is t
+        for (size_t k = 0; k < keys.size(); ++k)
+            if (n_in[(size_t)rel_src[k]] > 0) rc.add(in[(size_t)rel_src[k]], ptrs[k].numel() - 1);
+        rc.verify("negative_sample_neighbors_heterogenous inputs");
     }
     NegRun r = run_neg(dev, T, rel_src, rel_dst, ptrs, idx, node_count, in, n_in, num_neg, try_count, inbound, false);
     py::dict samples, rows, cols, counts;

@@ -163,3 +163,30 @@ def test_walks_through_the_surface(tg):
                                 torch.tensor([0, 1, 2, 3]).cuda(), torch.tensor([0, -1, 2, 3]).cuda(), 10, (0, 2))
     oa, ob = orc.tempo_random_walk(ptrs, idx, nts, ets, [0, 1, 2, 3], [0, -1, 2, 3], 10, (0, 2), orc.rng_philox(5, 2))
     assert a.shape == (4, 10) and np.array_equal(_np(a), oa) and np.array_equal(_np(b), ob)
+
+
+def test_out_of_range_node_ids_raise_instead_of_faulting(tg):
+    """the reference panics (index out of bounds) on a node id outside the graph; here: IndexError, no device fault"""
+    P, I = torch.tensor([0, 1, 2]).cuda(), torch.tensor([1, 0]).cuda()       # 2 nodes
+    bad = torch.tensor([0, 2]).cuda()
+    with pytest.raises(IndexError, match="outside the graph"):
+        tg.neighbor_sampling_homogenous(P, I, bad, [2])
+    with pytest.raises(IndexError):
+        tg.neighbor_sampling_homogenous(P, I, torch.tensor([-1]).cuda(), [2])
+    with pytest.raises(IndexError):
+        tg.random_walk(P, I, bad, 3, 1.0, 1.0)
+    with pytest.raises(IndexError):
+        tg.tempo_random_walk(P, I, torch.zeros(2, dtype=torch.int64).cuda(), torch.zeros(2, dtype=torch.int64).cuda(),
+                             bad, torch.zeros(2, dtype=torch.int64).cuda(), 3, (0, 1))
+    with pytest.raises(IndexError):
+        tg.negative_sample_neighbors_homogenous(P, I, (2, 2), bad, 2, 2)
+    et = ("a", "to", "a")
+    k = "a__to__a"
+    with pytest.raises(IndexError):
+        tg.neighbor_sampling_heterogenous(["a"], [et], {k: P}, {k: I}, {"a": bad}, {k: [2]}, 1)
+    with pytest.raises(IndexError):
+        tg.hgt_sampling(["a"], [et], {k: P}, {k: I}, None, {"a": bad}, None, {"a": [2]}, 1)
+    with pytest.raises(IndexError):
+        tg.budget_sampling(["a"], [et], {k: P}, {k: I}, None, {"a": bad}, None, {"a": [2]}, 1, None, False, False)
+    # and valid calls still work afterwards
+    assert tg.neighbor_sampling_homogenous(P, I, torch.tensor([0, 1]).cuda(), [2])[0].numel() == 4
