@@ -22,7 +22,7 @@
 
 #define ORC_RES_TICKETS 0
 #define ORC_RES_LITERAL 1
-#define ORC_RES_AUTO (-1) /* tickets when the candidate set is a whole column, literal under a filter */
+#define ORC_RES_AUTO (-1) /* what the device uses: tickets for neighbor sampling, literal for the temporal walk */
 
 typedef struct {
     orc_rng *rng;

@@ -259,10 +259,10 @@ static int64_t orc_sample_vertex(orc_ctx *c, const orc_ns_cfg *cfg, orc_sampler_
         if (cnt < 0) return -1;
         break;
     default: {
-        /* philox-mode spec: a filter forces a scan of the column anyway, so the per-item form is used
-         * there (one pass); without a filter the k-draw ticket form (same law) */
+        /* philox-mode spec: the k-draw ticket form, with or without a filter (under a filter the device counts
+         * the admissible edges first, then fetches the drawn ranks) */
         int algo = cfg->reservoir_algo;
-        if (algo == ORC_RES_AUTO) algo = (cfg->filter_mode != ORC_FILTER_NONE) ? ORC_RES_LITERAL : ORC_RES_TICKETS;
+        if (algo == ORC_RES_AUTO) algo = ORC_RES_TICKETS;
         cnt = orc_reservoir(c, id, 0, n, k, st->dst, st->scratch, algo);
     }
     }

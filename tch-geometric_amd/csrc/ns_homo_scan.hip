@@ -22,6 +22,8 @@
 namespace tg {
 
 constexpr int NSS_CHUNKS_PER_ROUND = 1024;
+constexpr int NSS_PREFETCH = 8; // 64-edge chunks whose loads are in flight together per wavefront
+constexpr int NSS_GROUPS = 512;  // running-count slots per wavefront (group = 512 << shift edges)
 
 struct NsScanParams {
     const int64_t *ptrs;
@@ -43,9 +45,9 @@ struct NsScanParams {
 };
 
 __host__ __device__ inline size_t nss_wave_lds_bytes(int kmax) {
-    // slot_ptr[k] i64 | tgt[k] i64 | slot_rank[k] u32 (padded) | ebuf[64*k] i64 | elane[64*k] u8 (padded)
-    return (size_t)kmax * 8 * 2 + (((size_t)kmax * 4 + 15) & ~(size_t)15) + (size_t)64 * kmax * 8 +
-           (((size_t)64 * kmax + 15) & ~(size_t)15);
+    // slot_ptr[k] i64 | tgt[k] i64 | slot_rank[k] u32 (padded) | eslot[64*k] u8 | elane[64*k] u8 (padded) | gpref
+    return (size_t)kmax * 8 * 2 + (((size_t)kmax * 4 + 15) & ~(size_t)15) + 2 * (((size_t)64 * kmax + 15) & ~(size_t)15) +
+           (size_t)NSS_GROUPS * 4;
 }
 __host__ __device__ inline size_t nss_block_lds_bytes(int kmax, int n_waves) {
     return (((size_t)(NSS_CHUNKS_PER_ROUND + 1) * 4 + 15) & ~(size_t)15) + (size_t)n_waves * nss_wave_lds_bytes(kmax);
@@ -63,6 +65,12 @@ __device__ __forceinline__ bool filter_pass(const NsScanParams &p, int64_t state
     return p.win_lo <= x && x <= p.win_hi;
 }
 
+__device__ __forceinline__ bool filter_value_pass(const NsScanParams &p, int64_t state, int64_t t) {
+    if (p.filter_mode == TG_FILTER_NONE) return true;
+    const int64_t x = (p.filter_mode == TG_FILTER_STATIC) ? t : (p.forward ? (t - state) : -(t - state));
+    return p.win_lo <= x && x <= p.win_hi;
+}
+
 // serial (left-to-right) inclusive prefix of one f64 per lane, starting from `carry`:
 // keeps the reference's summation order of sampling.rs:40,48 bit for bit
 __device__ __forceinline__ double wave_serial_prefix(double v, double carry, double *total) {
@@ -77,6 +85,7 @@ __device__ __forceinline__ double wave_serial_prefix(double v, double carry, dou
     return mine;
 }
 
+template <bool WEIGHTED>
 __global__ void ns_homo_scan_kernel(const NsScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
@@ -89,8 +98,10 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
     int64_t *slot_ptr = reinterpret_cast<int64_t *>(wbase);
     int64_t *tgt = slot_ptr + p.kmax;
     uint32_t *slot_rank = reinterpret_cast<uint32_t *>(tgt + p.kmax);
-    int64_t *ebuf = reinterpret_cast<int64_t *>(wbase + (size_t)p.kmax * 16 + (((size_t)p.kmax * 4 + 15) & ~(size_t)15));
-    uint8_t *elane = reinterpret_cast<uint8_t *>(ebuf + (size_t)64 * p.kmax);
+    uint8_t *eslot = reinterpret_cast<uint8_t *>(wbase + (size_t)p.kmax * 16 + (((size_t)p.kmax * 4 + 15) & ~(size_t)15));
+    uint8_t *elane = eslot + (((size_t)64 * p.kmax + 15) & ~(size_t)15);
+    uint32_t *gpref = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(elane) +
+                                                   (((size_t)64 * p.kmax + 15) & ~(size_t)15));
 
     int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges;
@@ -129,65 +140,152 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
             uint32_t n = 0; // admissible candidates seen so far
             if (lane < k) slot_rank[lane] = 0;
             wave_lds_handoff();
-            if (p.sampler == TG_SAMPLER_UNIFORM_REPL) {
-                // sampling.rs:57-69 needs the candidate count first, then k draws, then a second pass to
-                // turn candidate ranks into edge pointers
-                for (int64_t base = e0; base < e1; base += 64) {
-                    const int64_t e = base + lane;
-                    n += (uint32_t)__popcll(__ballot(e < e1 && filter_pass(p, st, e)));
-                }
-                if (n > 0) {
-                    if (lane < k) {
-                        const Draw d = draw(ck, (uint64_t)(p.id_base + i), (uint32_t)(lane >> 1), D1_REPLACE);
-                        tgt[lane] = (int64_t)bounded64(d.half(lane & 1), (uint64_t)n);
-                    }
-                    wave_lds_handoff();
-                    uint32_t seen = 0;
-                    for (int64_t base = e0; base < e1; base += 64) {
-                        const int64_t e = base + lane;
-                        const bool ok = e < e1 && filter_pass(p, st, e);
-                        const uint64_t mask = __ballot(ok);
-                        if (ok) {
-                            const int64_t rank = seen + (uint32_t)__popcll(mask & lt_mask);
-                            for (int s = 0; s < k; ++s)
-                                if (tgt[s] == rank) slot_ptr[s] = e;
+            if constexpr (!WEIGHTED) {
+                // ---- uniform samplers under a filter: count, draw ranks, fetch only the groups that hold them.
+                // pass 1 streams the column once (8 chunks in flight per lane) and keeps the running count of
+                // admissible edges at the end of every group of 512 << shift edges in LDS;
+                const int64_t deg = e1 - e0;
+                int shift = 0;
+                while (((deg + 511) >> (9 + shift)) > NSS_GROUPS) ++shift;
+                const int64_t gsize = (int64_t)512 << shift;
+                int g = 0;
+                for (int64_t gb = e0; gb < e1; gb += gsize, ++g) {
+                    const int64_t ge = min(gb + gsize, e1);
+                    for (int64_t cb = gb; cb < ge; cb += 64 * NSS_PREFETCH) {
+                        int64_t tsv[NSS_PREFETCH];
+#pragma unroll
+                        for (int u = 0; u < NSS_PREFETCH; ++u) {
+                            const int64_t e = cb + u * 64 + lane;
+                            tsv[u] = (e < ge) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
                         }
-                        seen += (uint32_t)__popcll(mask);
+#pragma unroll
+                        for (int u = 0; u < NSS_PREFETCH; ++u) {
+                            const int64_t e = cb + u * 64 + lane;
+                            n += (uint32_t)__popcll(__ballot(e < ge && filter_value_pass(p, st, tsv[u])));
+                        }
+                    }
+                    if (lane == 0) gpref[g] = n;
+                }
+                const int n_groups = g;
+                wave_lds_handoff();
+                // the ranks to fetch: every candidate when there are few, k draws of U[0,n) with replacement
+                // (sampling.rs:57-69), else the reservoir's ticket chain (lane s owns slot s)
+                const uint32_t cnt_sel = (p.sampler == TG_SAMPLER_UNIFORM_REPL) ? (n > 0 ? (uint32_t)k : 0u)
+                                                                               : min(n, (uint32_t)k);
+                uint32_t myrank = (uint32_t)lane;
+                const uint64_t did = (uint64_t)(p.id_base + i);
+                if (p.sampler == TG_SAMPLER_UNIFORM_REPL) {
+                    if (n > 0 && lane < k) {
+                        const Draw d = draw(ck, did, (uint32_t)(lane >> 1), D1_REPLACE);
+                        myrank = bounded32(d.half(lane & 1), n);
+                    }
+                } else if (n > (uint32_t)k) {
+                    uint32_t myK = 0xffffffffu, myV = 0;
+                    Draw d;
+                    for (int s = 0; s < k; ++s) {
+                        const uint32_t m = (n - 1u) - (uint32_t)s;
+                        if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
+                        const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                        const uint64_t mr = __ballot(lane < s && myK == r);
+                        const uint64_t ml = __ballot(lane < s && myK == last);
+                        const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);
+                        const uint32_t vl = __shfl(myV, ml ? 63 - __clzll((long long)ml) : 0, 64);
+                        const uint32_t tr = mr ? vr : r, tl = ml ? vl : last;
+                        if (lane == s) {
+                            myK = r;
+                            myV = tl;
+                            myrank = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+                        }
+                    }
+                }
+                // pass 2: slot by slot, re-read only the group that contains the rank
+                for (uint32_t s = 0; s < cnt_sel; ++s) {
+                    const uint32_t r = __shfl(myrank, (int)s, 64);
+                    int lo_g = 0, hi_g = n_groups - 1; // first group whose running count exceeds r
+                    while (lo_g < hi_g) {
+                        const int mid = (lo_g + hi_g) >> 1;
+                        if (gpref[mid] > r)
+                            hi_g = mid;
+                        else
+                            lo_g = mid + 1;
+                    }
+                    uint32_t seen = lo_g > 0 ? gpref[lo_g - 1] : 0u;
+                    const int64_t gb = e0 + (int64_t)lo_g * gsize, ge = min(gb + gsize, e1);
+                    bool found = false;
+                    for (int64_t cb = gb; cb < ge && !found; cb += 64 * NSS_PREFETCH) {
+                        int64_t tsv[NSS_PREFETCH];
+#pragma unroll
+                        for (int u = 0; u < NSS_PREFETCH; ++u) {
+                            const int64_t e = cb + u * 64 + lane;
+                            tsv[u] = (e < ge) ? p.timestamps[e] : 0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < NSS_PREFETCH; ++u) {
+                            if (found) break;
+                            const int64_t e = cb + u * 64 + lane;
+                            const bool ok = e < ge && filter_value_pass(p, st, tsv[u]);
+                            const uint64_t mask = __ballot(ok);
+                            const uint32_t c = (uint32_t)__popcll(mask);
+                            if (r - seen < c) {
+                                if (ok && seen + (uint32_t)__popcll(mask & lt_mask) == r) slot_ptr[s] = e;
+                                found = true;
+                            }
+                            seen += c;
+                        }
                     }
                 }
             } else {
+                // The column is streamed NSS_PREFETCH chunks at a time: all loads of a group are issued before any
+                // of them is consumed, so a wavefront keeps several HBM requests in flight instead of one.
                 double w_sum = 0.0;
-                for (int64_t base = e0; base < e1; base += 64) {
-                    const int64_t e = base + lane;
-                    const bool ok = e < e1 && filter_pass(p, st, e);
-                    const uint64_t mask = __ballot(ok);
-                    const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
-                    uint32_t hit_slot = 0xffffffffu;
-                    if (p.sampler == TG_SAMPLER_WEIGHTED) { // sampling.rs:28-55
-                        const double wv = ok ? p.weights[e] : 0.0;
-                        double tot;
-                        const double pref = wave_serial_prefix(wv, w_sum, &tot);
-                        w_sum = tot;
-                        if (ok && rank >= (uint32_t)k) {
-                            if (!(0.0 < pref)) {
-                                panic_flag = 1;
-                            } else {
-                                const Draw d = draw(ck, (uint64_t)(p.id_base + i), rank, D1_WEIGHTED);
-                                const double j = u64_to_f64_01(d.a()) * pref + 0.0;
-                                if (j < wv) hit_slot = (uint32_t)bounded64(d.b(), (uint64_t)k);
-                            }
-                        }
-                    } else if (ok && rank >= (uint32_t)k) { // sampling.rs:17-24, one addressed draw per item
-                        const Draw d = draw(ck, (uint64_t)(p.id_base + i), rank, D1_LITERAL);
-                        const uint64_t j = bounded64(d.a(), (uint64_t)rank);
-                        if (j < (uint64_t)k) hit_slot = (uint32_t)j;
+                constexpr bool weighted = WEIGHTED;
+                for (int64_t gbase = e0; gbase < e1; gbase += 64 * NSS_PREFETCH) {
+                    int64_t tsv[NSS_PREFETCH];
+                    double wvv[NSS_PREFETCH];
+#pragma unroll
+                    for (int u = 0; u < NSS_PREFETCH; ++u) {
+                        const int64_t e = gbase + u * 64 + lane;
+                        tsv[u] = (has_state && e < e1) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
+                        wvv[u] = (weighted && e < e1) ? __builtin_nontemporal_load(&p.weights[e]) : 0.0;
                     }
-                    if (ok && rank < (uint32_t)k) slot_ptr[rank] = e; // sampling.rs:12-15 / :37-45
-                    if (hit_slot != 0xffffffffu) atomicMax(&slot_rank[hit_slot], rank);
-                    wave_lds_handoff();
-                    if (hit_slot != 0xffffffffu && slot_rank[hit_slot] == rank) slot_ptr[hit_slot] = e; // last hit wins
-                    wave_lds_handoff();
-                    n += (uint32_t)__popcll(mask);
+#pragma unroll
+                    for (int u = 0; u < NSS_PREFETCH; ++u) {
+                        const int64_t base = gbase + u * 64;
+                        if (base >= e1) break;
+                        const int64_t e = base + lane;
+                        const bool ok = e < e1 && filter_value_pass(p, st, tsv[u]);
+                        const uint64_t mask = __ballot(ok);
+                        const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
+                        uint32_t hit_slot = 0xffffffffu;
+                        if (weighted) { // sampling.rs:28-55
+                            const double wv = ok ? wvv[u] : 0.0;
+                            double tot;
+                            const double pref = wave_serial_prefix(wv, w_sum, &tot);
+                            w_sum = tot;
+                            if (ok && rank >= (uint32_t)k) {
+                                if (!(0.0 < pref)) {
+                                    panic_flag = 1;
+                                } else {
+                                    const Draw d = draw(ck, (uint64_t)(p.id_base + i), rank, D1_WEIGHTED);
+                                    const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                                    if (j < wv) hit_slot = (uint32_t)bounded64(d.b(), (uint64_t)k);
+                                }
+                            }
+                        } else if (ok && rank >= (uint32_t)k) { // sampling.rs:17-24, one addressed draw per item
+                            const Draw d = draw(ck, (uint64_t)(p.id_base + i), rank, D1_LITERAL);
+                            const uint64_t j = bounded64(d.a(), (uint64_t)rank);
+                            if (j < (uint64_t)k) hit_slot = (uint32_t)j;
+                        }
+                        const bool fill = ok && rank < (uint32_t)k;
+                        if (__ballot(fill || hit_slot != 0xffffffffu) != 0ull) { // most chunks of a long column: no hit
+                            if (fill) slot_ptr[rank] = e; // sampling.rs:12-15 / :37-45
+                            if (hit_slot != 0xffffffffu) atomicMax(&slot_rank[hit_slot], rank);
+                            wave_lds_handoff();
+                            if (hit_slot != 0xffffffffu && slot_rank[hit_slot] == rank) slot_ptr[hit_slot] = e; // last hit
+                            wave_lds_handoff();
+                        }
+                        n += (uint32_t)__popcll(mask);
+                    }
                 }
             }
             wave_lds_handoff();
@@ -231,8 +329,8 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                 const uint32_t incl = wave_inclusive_scan(cnt);
                 const uint32_t excl = incl - cnt;
                 const uint32_t total = __shfl(incl, 63, 64);
-                for (uint32_t s = 0; s < cnt; ++s) {
-                    ebuf[excl + s] = park[(i - begin) * k + s];
+                for (uint32_t s = 0; s < cnt; ++s) { // only (lane, slot) is staged; the pointer is re-read from `park`
+                    eslot[excl + s] = (uint8_t)s;
                     elane[excl + s] = (uint8_t)lane;
                 }
                 wave_lds_handoff();
@@ -240,7 +338,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
 #pragma unroll 2
                 for (uint32_t q = lane; q < total; q += 64) {
                     const int l = elane[q];
-                    const int64_t ep = ebuf[q];
+                    const int64_t ep = park[(i0 + l - begin) * k + eslot[q]];
                     const int64_t e = e_chunk + q;
                     samples[n_seeds + e] = p.indices[ep];
                     cols[e] = i0 + l;
@@ -317,7 +415,10 @@ int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_
     int threads = (n_batches < 256) ? 1024 : 256;
     while (threads > 64 && tg::nss_block_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads >>= 1;
     const size_t lds = tg::nss_block_lds_bytes(p.kmax, threads / 64);
-    hipLaunchKernelGGL(tg::ns_homo_scan_kernel, dim3((unsigned)n_batches), dim3(threads), lds, stream, p);
+    if (p.sampler == TG_SAMPLER_WEIGHTED)
+        hipLaunchKernelGGL(tg::ns_homo_scan_kernel<true>, dim3((unsigned)n_batches), dim3(threads), lds, stream, p);
+    else
+        hipLaunchKernelGGL(tg::ns_homo_scan_kernel<false>, dim3((unsigned)n_batches), dim3(threads), lds, stream, p);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
