@@ -155,6 +155,24 @@ TG_API int tg_ns_hop_workspace_bytes(int64_t m, int64_t *bytes);
 TG_API int tg_ns_hop(const tg_graph *csc, const tg_hop_in *in, const tg_rng *rng, const tg_hop_out *out,
                      void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same flat hop for the unweighted samplers UNDER A TEMPORAL FILTER (neighbor_sampling.rs:36-77): columns are
+ * cut into groups of 512 edges that are counted all over the device, then every vertex draws its ranks (ticket
+ * form) and fetches them.  `states` is the filter state of every frontier vertex, states_out [m * fanout] that of
+ * every sample.  group_cap bounds the number of 512-edge groups the frontier's columns may have
+ * (sum of ceil(deg / 512)); if it is reached status[0] (device int32, zeroed by the caller) becomes 1 and all
+ * counts are 0 -- retry with a larger workspace. */
+typedef struct {
+    int32_t filter_mode; /* TG_FILTER_STATIC / RELATIVE / DYNAMIC */
+    int32_t forward;
+    int64_t win_lo, win_hi; /* inclusive window */
+    const int64_t *states;  /* [m] */
+} tg_hop_filter;
+
+TG_API int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t group_cap, int64_t *bytes);
+TG_API int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *filter, const tg_rng *rng,
+                          const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                          int64_t workspace_bytes, int64_t group_cap, void *stream);
+
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */
 TG_API int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,

@@ -1,0 +1,332 @@
+// One hop of the UNIFORM samplers under a temporal filter over a flat frontier, spread over the whole chip
+// (the filtered counterpart of ns_hop.hip; reference: neighbor_sampling.rs:36-77 filter, :195-218 hop body).
+// A column has to be inspected edge by edge, and columns differ by five orders of magnitude, so the work is cut
+// into GROUPS of 512 consecutive edges of one column, independent of which vertex or batch they belong to:
+//   groups   lane per frontier vertex: ceil(deg / 512) -> device scan -> first group of every vertex
+//   count    wavefront per run of 32 groups: stream the timestamps (8 x 512 B in flight per lane), ballot +
+//            popcount -> admissible edges per group                                     [the HBM-bound kernel]
+//   scan     device scan of the group counts -> rank of every group's first admissible edge
+//   select   wavefront per vertex: n = its admissible edges; ranks to keep = all of them when n <= k, k draws of
+//            U[0,n) with replacement, or the reservoir's ticket chain; each rank is located by
+//            a binary search over the vertex's groups and a re-read of that one group -> parked edge pointers
+//   emit     device scan of the per-vertex counts, then coalesced gather / write of (neighbour, edge pointer,
+//            parent, new filter state)
+// Same draws and same per-vertex output order as ns_homo_scan.hip, hence the same results.  No synchronisation;
+// if the frontier needs group_cap groups or more, `status[0]` is set to 1 and nothing is sampled.
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "tg_device.h"
+#include "tg_host.h"
+
+namespace tg {
+
+constexpr int HS_GROUP = 512;  // edges per group = 8 chunks of 64
+constexpr int HS_RUN = 32;     // groups per wavefront work unit
+constexpr int HS_CHUNKS = 8;
+
+struct HopScanParams {
+    const int64_t *ptrs, *indices, *timestamps;
+    const int64_t *vertices, *states, *ids, *call_ids;
+    int64_t m, id_base;
+    int32_t k, replace;
+    int32_t filter_mode, forward;
+    int64_t win_lo, win_hi;
+    uint32_t tag;
+    uint64_t seed, call_id;
+    int64_t group_cap;
+    // workspace
+    int64_t *vgroups; // [m + 1] groups per vertex, then (in place) first group of every vertex; [m] = total
+    uint32_t *gcount; // [group_cap]
+    int64_t *gpref;   // [group_cap + 1] exclusive prefix of gcount
+    int64_t *park;    // [m * k]
+    int32_t *status;  // [0] overflow flag
+    // outputs
+    int64_t *cnt, *offsets, *neighbors, *edge_ptrs, *parents, *states_out;
+};
+
+__device__ __forceinline__ bool hs_pass(const HopScanParams &p, int64_t state, int64_t t) { // neighbor_sampling.rs:55-67
+    const int64_t x = (p.filter_mode == TG_FILTER_STATIC) ? t : (p.forward ? (t - state) : -(t - state));
+    return p.win_lo <= x && x <= p.win_hi;
+}
+
+__global__ void hs_groups_kernel(const HopScanParams p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.m; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = p.vertices[i];
+        int64_t g = 0;
+        if (w >= 0) g = (p.ptrs[w + 1] - p.ptrs[w] + HS_GROUP - 1) / HS_GROUP;
+        p.vgroups[i + 1] = g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.vgroups[0] = 0;
+}
+// after the inclusive scan: vgroups[i] = first group of vertex i, vgroups[m] = number of groups
+__global__ void hs_check_kernel(const HopScanParams p) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && p.vgroups[p.m] >= p.group_cap) p.status[0] = 1;
+}
+
+// wavefront per run of HS_RUN consecutive groups
+__global__ void hs_count_kernel(const HopScanParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t gt = p.vgroups[p.m];
+    if (gt >= p.group_cap) return;
+    for (int64_t g0 = wave_id * HS_RUN; g0 < gt; g0 += n_waves * HS_RUN) {
+        // vertex owning group g0: last v with vgroups[v] <= g0
+        int64_t lo = 0, hi = p.m - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (p.vgroups[mid] <= g0)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        int64_t v = lo;
+        const int64_t g1 = min(g0 + HS_RUN, gt);
+        for (int64_t g = g0; g < g1; ++g) {
+            while (g >= p.vgroups[v + 1]) ++v; // skip to the owner (vertices without groups own nothing)
+            const int64_t w = p.vertices[v];
+            const int64_t st = p.states[v];
+            const int64_t e1 = p.ptrs[w + 1];
+            const int64_t gb = p.ptrs[w] + (g - p.vgroups[v]) * HS_GROUP;
+            int64_t tsv[HS_CHUNKS];
+#pragma unroll
+            for (int u = 0; u < HS_CHUNKS; ++u) {
+                const int64_t e = gb + u * 64 + lane;
+                tsv[u] = (e < e1) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
+            }
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < HS_CHUNKS; ++u) {
+                const int64_t e = gb + u * 64 + lane;
+                c += (uint32_t)__popcll(__ballot(e < e1 && hs_pass(p, st, tsv[u])));
+            }
+            if (lane == 0) p.gcount[g] = c;
+        }
+    }
+}
+
+// wavefront per frontier vertex
+__global__ void hs_select_kernel(const HopScanParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool overflow = p.vgroups[p.m] >= p.group_cap;
+    const CallKey ck0 = call_key(p.seed, p.call_id, p.tag);
+    const int k = p.k;
+    for (int64_t v = wave_id; v < p.m; v += n_waves) {
+        const int64_t w = p.vertices[v];
+        const int64_t gfirst = p.vgroups[v], glast = p.vgroups[v + 1];
+        uint32_t n = 0;
+        int64_t base_rank = 0;
+        if (w >= 0 && !overflow && glast > gfirst) {
+            base_rank = p.gpref[gfirst];
+            n = (uint32_t)(p.gpref[glast] - base_rank);
+        }
+        const uint32_t cnt_sel = p.replace ? (n > 0 ? (uint32_t)k : 0u) : min(n, (uint32_t)k);
+        if (lane == 0) p.cnt[v] = cnt_sel;
+        uint32_t myrank = (uint32_t)lane;
+        if (cnt_sel > 0) {
+            const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
+            const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[v], p.tag) : ck0;
+            if (p.replace) { // sampling.rs:57-69
+                if (lane < k) {
+                    const Draw d = draw(ck, did, (uint32_t)(lane >> 1), D1_REPLACE);
+                    myrank = bounded32(d.half(lane & 1), n);
+                }
+            } else if (n > (uint32_t)k) { // reservoir by tickets, lane s owns slot s
+                uint32_t myK = 0xffffffffu, myV = 0;
+                Draw d;
+                for (int s = 0; s < k; ++s) {
+                    const uint32_t mm = (n - 1u) - (uint32_t)s;
+                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
+                    const uint32_t r = bounded32(d.half(s & 1), mm), last = mm - 1u;
+                    const uint64_t mr = __ballot(lane < s && myK == r);
+                    const uint64_t ml = __ballot(lane < s && myK == last);
+                    const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);
+                    const uint32_t vl = __shfl(myV, ml ? 63 - __clzll((long long)ml) : 0, 64);
+                    const uint32_t tr = mr ? vr : r, tl = ml ? vl : last;
+                    if (lane == s) {
+                        myK = r;
+                        myV = tl;
+                        myrank = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+                    }
+                }
+            }
+        }
+        // locate every kept rank: binary search over the vertex's groups, then re-read that group
+        int64_t my_ep = -1;
+        if (cnt_sel > 0) {
+            const int64_t st = p.states[v];
+            const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
+            for (uint32_t s = 0; s < cnt_sel; ++s) {
+                const int64_t target = base_rank + (int64_t)__shfl(myrank, (int)s, 64);
+                int64_t lo = gfirst, hi = glast - 1; // last group g with gpref[g] <= target
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi + 1) >> 1;
+                    if (p.gpref[mid] <= target)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                const int64_t gb = e0 + (lo - gfirst) * HS_GROUP;
+                int64_t seen = p.gpref[lo];
+                int64_t tsv[HS_CHUNKS];
+#pragma unroll
+                for (int u = 0; u < HS_CHUNKS; ++u) {
+                    const int64_t e = gb + u * 64 + lane;
+                    tsv[u] = (e < e1) ? p.timestamps[e] : 0;
+                }
+                bool found = false;
+#pragma unroll
+                for (int u = 0; u < HS_CHUNKS; ++u) {
+                    const int64_t e = gb + u * 64 + lane;
+                    const bool ok = e < e1 && hs_pass(p, st, tsv[u]);
+                    const uint64_t mask = __ballot(ok);
+                    const int64_t c = __popcll(mask);
+                    if (!found && target - seen < c) {
+                        const uint64_t owner = __ballot(ok && seen + (int64_t)__popcll(mask & lt_mask) == target);
+                        const int64_t ep = __shfl(e, __ffsll((long long)owner) - 1, 64);
+                        if (lane == (int)s) my_ep = ep;
+                        found = true;
+                    }
+                    seen += c;
+                }
+            }
+        }
+        if (lane < k) p.park[v * k + lane] = ((uint32_t)lane < cnt_sel) ? my_ep : -1;
+    }
+}
+
+// thread per output edge: owner vertex by binary search over offsets, slot from the difference
+__global__ void hs_emit_kernel(const HopScanParams p) {
+    const int64_t total = p.offsets[p.m];
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = p.m - 1; // last v with offsets[v] <= o
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (p.offsets[mid] <= o)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const int64_t v = lo, s = o - p.offsets[v];
+        const int64_t ep = p.park[v * p.k + s];
+        p.neighbors[o] = p.indices[ep];
+        p.edge_ptrs[o] = ep;
+        p.parents[o] = v;
+        p.states_out[o] = (p.filter_mode == TG_FILTER_DYNAMIC) ? p.timestamps[ep] : p.states[v]; // :69-76
+    }
+}
+
+static inline size_t hs_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t hs_scan_temp(int64_t n) {
+    size_t a = 0, b = 0;
+    (void)rocprim::inclusive_scan(nullptr, a, (int64_t *)nullptr, (int64_t *)nullptr, (size_t)(n > 0 ? n : 1),
+                                  rocprim::plus<int64_t>(), (hipStream_t)0, false);
+    (void)rocprim::exclusive_scan(nullptr, b, (uint32_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)(n > 0 ? n : 1),
+                                  rocprim::plus<int64_t>(), (hipStream_t)0, false);
+    return a > b ? a : b;
+}
+
+} // namespace tg
+
+extern "C" int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t group_cap, int64_t *bytes) {
+    TG_REQUIRE(m >= 0 && fanout >= 1 && group_cap >= 1 && bytes, "tg_ns_hop_scan_workspace_bytes: bad arguments");
+    using namespace tg;
+    const int64_t big = group_cap + 1 > m + 1 ? group_cap + 1 : m + 1;
+    *bytes = (int64_t)(hs_align(8 * (size_t)(m + 1)) + hs_align(4 * (size_t)group_cap) + hs_align(8 * (size_t)(group_cap + 1)) +
+                       hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(hs_scan_temp(big)) + 512);
+    return TG_OK;
+}
+
+extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
+                              const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                              int64_t workspace_bytes, int64_t group_cap, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(csc && csc->ptrs && in && flt && rng && out && status, "tg_ns_hop_scan: null argument");
+    TG_REQUIRE(csc->timestamps, "tg_ns_hop_scan: the graph has no edge timestamps");
+    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= 64, "tg_ns_hop_scan: bad frontier size or fan-out (<= 64)");
+    TG_REQUIRE(in->sampler == TG_SAMPLER_UNIFORM || in->sampler == TG_SAMPLER_UNIFORM_REPL,
+               "tg_ns_hop_scan: only the unweighted samplers");
+    TG_REQUIRE(flt->filter_mode >= TG_FILTER_STATIC && flt->filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_scan: bad filter");
+    TG_REQUIRE(out->cnt && out->offsets && group_cap >= 1, "tg_ns_hop_scan: null outputs");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (in->m == 0) {
+        TG_HIP(hipMemsetAsync(out->offsets, 0, sizeof(int64_t), stream));
+        return TG_OK;
+    }
+    int64_t need = 0;
+    int rc = tg_ns_hop_scan_workspace_bytes(in->m, in->fanout, group_cap, &need);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(workspace && workspace_bytes >= need, "tg_ns_hop_scan: workspace too small");
+    TG_REQUIRE(in->vertices && flt->states && out->neighbors && out->edge_ptrs && out->parents && states_out,
+               "tg_ns_hop_scan: null buffers");
+    HopScanParams p;
+    p.ptrs = csc->ptrs;
+    p.indices = csc->indices;
+    p.timestamps = csc->timestamps;
+    p.vertices = in->vertices;
+    p.states = flt->states;
+    p.ids = in->ids;
+    p.call_ids = in->call_ids;
+    p.m = in->m;
+    p.id_base = in->id_base;
+    p.k = in->fanout;
+    p.replace = in->sampler == TG_SAMPLER_UNIFORM_REPL;
+    p.filter_mode = flt->filter_mode;
+    p.forward = flt->forward;
+    p.win_lo = flt->win_lo;
+    p.win_hi = flt->win_hi;
+    p.tag = in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO;
+    p.seed = rng->seed;
+    p.call_id = rng->call_id;
+    p.group_cap = group_cap;
+    unsigned char *base = reinterpret_cast<unsigned char *>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *q = base + off;
+        off += hs_align(bytes);
+        return q;
+    };
+    p.vgroups = reinterpret_cast<int64_t *>(take(8 * (size_t)(p.m + 1)));
+    p.gcount = reinterpret_cast<uint32_t *>(take(4 * (size_t)group_cap));
+    p.gpref = reinterpret_cast<int64_t *>(take(8 * (size_t)(group_cap + 1)));
+    p.park = reinterpret_cast<int64_t *>(take(8 * (size_t)p.m * p.k));
+    void *temp = base + off;
+    size_t temp_bytes = (size_t)workspace_bytes - off;
+    p.status = status;
+    p.cnt = out->cnt;
+    p.offsets = out->offsets;
+    p.neighbors = out->neighbors;
+    p.edge_ptrs = out->edge_ptrs;
+    p.parents = out->parents;
+    p.states_out = states_out;
+
+    auto grid = [](int64_t n, int threads) {
+        int64_t g = (n + threads - 1) / threads;
+        if (g < 1) g = 1;
+        if (g > 256 * 32) g = 256 * 32;
+        return dim3((unsigned)g);
+    };
+    hipLaunchKernelGGL(hs_groups_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
+    size_t st = temp_bytes;
+    TG_HIP(rocprim::inclusive_scan(temp, st, p.vgroups + 1, p.vgroups + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
+                                   false));
+    hipLaunchKernelGGL(hs_check_kernel, dim3(1), dim3(64), 0, stream, p);
+    TG_HIP(hipMemsetAsync(p.gcount, 0, 4 * (size_t)group_cap, stream)); // groups beyond the frontier's count as empty
+    hipLaunchKernelGGL(hs_count_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+    st = temp_bytes;
+    TG_HIP(rocprim::exclusive_scan(temp, st, p.gcount, p.gpref, (int64_t)0, (size_t)group_cap, rocprim::plus<int64_t>(),
+                                   stream, false));
+    // the frontier uses fewer than group_cap groups (else status = 1), so gpref[n_groups] is inside the scanned range
+    hipLaunchKernelGGL(hs_select_kernel, grid(p.m * 64, 256), dim3(256), 0, stream, p);
+    TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
+    st = temp_bytes;
+    TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
+    hipLaunchKernelGGL(hs_emit_kernel, grid(p.m * p.k, 256), dim3(256), 0, stream, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}

@@ -20,7 +20,8 @@ FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
            "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
-           "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range"]
+           "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
+           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan"]
 
 
 class TgGraph(C.Structure):
@@ -61,6 +62,11 @@ class TgHopIn(C.Structure):
 class TgHopOut(C.Structure):
     _fields_ = [("cnt", C.c_void_p), ("offsets", C.c_void_p), ("neighbors", C.c_void_p), ("edge_ptrs", C.c_void_p),
                 ("parents", C.c_void_p)]
+
+
+class TgHopFilter(C.Structure):
+    _fields_ = [("filter_mode", C.c_int32), ("forward", C.c_int32), ("win_lo", C.c_int64), ("win_hi", C.c_int64),
+                ("states", C.c_void_p)]
 
 
 class TchGeoError(RuntimeError):
@@ -246,3 +252,33 @@ def ns_hop(graph, vertices, fanout, seed, call_id=0, sampler=SAMPLER_UNIFORM, id
     check(lib.tg_ns_hop(C.byref(graph), C.byref(hin), C.byref(rng), C.byref(hout), ptr(ws), C.c_int64(nbytes.value),
                         stream_ptr(dev)))
     return cnt[:m], offsets, nbr, ep, par
+
+
+def ns_hop_scan(graph, vertices, states, fanout, seed, filter_mode, window, forward=False, call_id=0,
+                sampler=SAMPLER_UNIFORM, ids=None, call_ids=None, id_base=0, rng_tag=0, group_cap=None):
+    """One flat hop under a temporal filter (tg_ns_hop_scan).
+    -> (cnt[m], offsets[m+1], neighbors, edge_ptrs, parents, states_out, status) -- no host synchronisation."""
+    m, dev = vertices.numel(), vertices.device
+    o = dict(dtype=torch.int64, device=dev)
+    if group_cap is None:
+        group_cap = max(1024, graph.n_edges // 512 + 2 * m + 2)
+    cnt, offsets = torch.empty(max(m, 1), **o), torch.empty(m + 1, **o)
+    nbr, ep, par, st_out = (torch.empty(max(m * fanout, 1), **o) for _ in range(4))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hin, hout, flt = TgHopIn(), TgHopOut(), TgHopFilter()
+    hin.vertices = vertices.data_ptr() if m else None
+    hin.ids = ids.data_ptr() if ids is not None else None
+    hin.call_ids = call_ids.data_ptr() if call_ids is not None else None
+    hin.m, hin.id_base, hin.fanout, hin.sampler, hin.rng_tag = m, id_base, fanout, sampler, rng_tag
+    hout.cnt, hout.offsets = cnt.data_ptr(), offsets.data_ptr()
+    hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+    flt.filter_mode, flt.forward = filter_mode, int(bool(forward))
+    flt.win_lo, flt.win_hi = window
+    flt.states = states.data_ptr() if m else None
+    nbytes = C.c_int64(0)
+    check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(fanout), C.c_int64(group_cap), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, **o)
+    rng = TgRng(seed, call_id)
+    check(lib.tg_ns_hop_scan(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout), ptr(st_out),
+                             ptr(status), ptr(ws), C.c_int64(nbytes.value), C.c_int64(group_cap), stream_ptr(dev)))
+    return cnt[:m], offsets, nbr, ep, par, st_out, status

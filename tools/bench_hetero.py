@@ -60,4 +60,14 @@ res["hgt_sampling"] = {"ms_per_call": dt * 1e3, "nodes_per_call": nodes, "edges_
 dt, out = timeit(lambda: tg.neighbor_sampling_homogenous(P["A__e0__A"], I["A__e0__A"], seeds(), [15, 10]))
 res["neighbor_sampling_homogenous_single_call"] = {"ms_per_call": dt * 1e3, "sampled_edges_per_call": int(out[1].numel()),
                                                    "edges_per_s": int(out[1].numel()) / dt}
+g = torch.Generator(device=dev)
+g.manual_seed(3)
+ts = torch.randint(0, 100, (I["A__e0__A"].numel(),), device=dev, generator=g)
+flt = lambda sd: (tg.TemporalEdgeFilter((0, 49), ts, False, tg.TEMPORAL_SAMPLE_STATIC), torch.full_like(sd, 50))
+def filtered():
+    sd = seeds()
+    return tg.neighbor_sampling_homogenous(P["A__e0__A"], I["A__e0__A"], sd, [15, 10], None, flt(sd))
+dt, out = timeit(filtered)
+res["neighbor_sampling_homogenous_temporal_single_call"] = {"ms_per_call": dt * 1e3,
+                                                            "sampled_edges_per_call": int(out[1].numel())}
 print(json.dumps(res))

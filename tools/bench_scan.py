@@ -60,4 +60,18 @@ for name, kw, per_edge in VARIANTS:
     res[name] = {"ms": ms, "inspected_edges": inspected, "sampled_edges": edges,
                  "algorithmic_GBps": per_edge * inspected / ms / 1e6,
                  "frac_of_8TBps": per_edge * inspected / ms / 1e6 / 8000.0, "sampled_edges_per_s": edges / ms * 1e3}
+# one filtered call through the operator surface (whole-device flat hops, tg_ns_hop_scan)
+import time  # noqa: E402
+import tch_geometric as tg  # noqa: E402
+flt = (tg.TemporalEdgeFilter((0, 49), ts, False, tg.TEMPORAL_SAMPLE_STATIC), torch.full((B,), 50, dtype=torch.int64, device=dev))
+tg.seed(0)
+for _ in range(3):
+    o = tg.neighbor_sampling_homogenous(ptrs, idx, seeds[0], fan, None, flt)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for j in range(10):
+    o = tg.neighbor_sampling_homogenous(ptrs, idx, seeds[j % nb], fan, None, flt)
+torch.cuda.synchronize()
+res["temporal_static_single_call_through_surface"] = {"ms_per_call": (time.perf_counter() - t0) / 10 * 1e3,
+                                                       "sampled_edges": int(o[1].numel())}
 print(json.dumps(res))
