@@ -173,6 +173,14 @@ TG_API int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg_hop
                           const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
                           int64_t workspace_bytes, int64_t group_cap, void *stream);
 
+/* The flat hop for the WEIGHTED sampler (sampling.rs:28-55), with or without a temporal filter (filter = NULL or
+ * filter_mode = TG_FILTER_NONE: none).  One wavefront per frontier vertex all over the device; a column's
+ * left-to-right f64 running sum is kept exactly.  status[0] |= 2 where the reference panics (sum <= 0).
+ * Workspace: tg_ns_hop_scan_workspace_bytes(m, fanout, 1). */
+TG_API int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *filter, const tg_rng *rng,
+                              const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                              int64_t workspace_bytes, void *stream);
+
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */
 TG_API int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,

@@ -253,6 +253,7 @@ __global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_
                                               int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
                                               int64_t *chosen, int64_t *n_chosen, int *panic) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double pbuf[64]; // serial prefix scratch (one wavefront per launch)
     uint32_t *slot_pos = reinterpret_cast<uint32_t *>(smem);
     uint32_t *slot_rank = slot_pos + k;
     const int lane = threadIdx.x & 63;
@@ -280,13 +281,9 @@ __global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_
             const double sc = ty.bscore[live[m]];
             wv = sc * sc;
         }
-        double running = w_sum, pref = 0.0;
-#pragma unroll 8
-        for (int l = 0; l < 64; ++l) { // left-to-right sum, sampling.rs:40,48
-            running = running + __shfl(wv, l, 64);
-            if (lane == l) pref = running;
-        }
-        w_sum = running;
+        double tot;
+        const double pref = wave_serial_prefix_f64(wv, w_sum, &tot, pbuf); // left-to-right sum, sampling.rs:40,48
+        w_sum = tot;
         int64_t hit = -1;
         if (ok && m >= k) {
             if (!(0.0 < pref)) {

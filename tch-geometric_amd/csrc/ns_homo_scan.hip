@@ -47,7 +47,7 @@ struct NsScanParams {
 __host__ __device__ inline size_t nss_wave_lds_bytes(int kmax) {
     // slot_ptr[k] i64 | tgt[k] i64 | slot_rank[k] u32 (padded) | eslot[64*k] u8 | elane[64*k] u8 (padded) | gpref
     return (size_t)kmax * 8 * 2 + (((size_t)kmax * 4 + 15) & ~(size_t)15) + 2 * (((size_t)64 * kmax + 15) & ~(size_t)15) +
-           (size_t)NSS_GROUPS * 4;
+           (size_t)NSS_GROUPS * 4 + 64 * 8; // + 64 doubles for the weighted sampler's serial prefix
 }
 __host__ __device__ inline size_t nss_block_lds_bytes(int kmax, int n_waves) {
     return (((size_t)(NSS_CHUNKS_PER_ROUND + 1) * 4 + 15) & ~(size_t)15) + (size_t)n_waves * nss_wave_lds_bytes(kmax);
@@ -71,20 +71,6 @@ __device__ __forceinline__ bool filter_value_pass(const NsScanParams &p, int64_t
     return p.win_lo <= x && x <= p.win_hi;
 }
 
-// serial (left-to-right) inclusive prefix of one f64 per lane, starting from `carry`:
-// keeps the reference's summation order of sampling.rs:40,48 bit for bit
-__device__ __forceinline__ double wave_serial_prefix(double v, double carry, double *total) {
-    const int lane = lane_id();
-    double running = carry, mine = 0.0;
-#pragma unroll 8
-    for (int l = 0; l < 64; ++l) {
-        running = running + __shfl(v, l, 64);
-        if (lane == l) mine = running;
-    }
-    *total = running;
-    return mine;
-}
-
 template <bool WEIGHTED>
 __global__ void ns_homo_scan_kernel(const NsScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -102,6 +88,8 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
     uint8_t *elane = eslot + (((size_t)64 * p.kmax + 15) & ~(size_t)15);
     uint32_t *gpref = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(elane) +
                                                    (((size_t)64 * p.kmax + 15) & ~(size_t)15));
+    double *pbuf = reinterpret_cast<double *>(gpref + NSS_GROUPS);
+    (void)pbuf;
 
     int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges;
@@ -260,7 +248,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                         if (weighted) { // sampling.rs:28-55
                             const double wv = ok ? wvv[u] : 0.0;
                             double tot;
-                            const double pref = wave_serial_prefix(wv, w_sum, &tot);
+                            const double pref = wave_serial_prefix_f64(wv, w_sum, &tot, pbuf);
                             w_sum = tot;
                             if (ok && rank >= (uint32_t)k) {
                                 if (!(0.0 < pref)) {

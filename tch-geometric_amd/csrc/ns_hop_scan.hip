@@ -28,6 +28,7 @@ constexpr int HS_CHUNKS = 8;
 
 struct HopScanParams {
     const int64_t *ptrs, *indices, *timestamps;
+    const double *weights;
     const int64_t *vertices, *states, *ids, *call_ids;
     int64_t m, id_base;
     int32_t k, replace;
@@ -47,6 +48,7 @@ struct HopScanParams {
 };
 
 __device__ __forceinline__ bool hs_pass(const HopScanParams &p, int64_t state, int64_t t) { // neighbor_sampling.rs:55-67
+    if (p.filter_mode == TG_FILTER_NONE) return true;
     const int64_t x = (p.filter_mode == TG_FILTER_STATIC) ? t : (p.forward ? (t - state) : -(t - state));
     return p.win_lo <= x && x <= p.win_hi;
 }
@@ -200,6 +202,83 @@ __global__ void hs_select_kernel(const HopScanParams p) {
     }
 }
 
+// ---------------------------------------------------------------- weighted sampler (sampling.rs:28-55)
+// The reference's weighted reservoir IS a per-candidate algorithm with a left-to-right f64 running sum: the chain
+// of one column cannot be split without changing its rounding, but columns are independent -- one wavefront per
+// frontier vertex, all over the device.  status[0] |= 2 where the reference panics (running sum <= 0).
+__global__ void hw_select_kernel(const HopScanParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = p.k;
+    int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem) + (size_t)wave * (2 * k + 64);
+    uint32_t *slot_rank = reinterpret_cast<uint32_t *>(slot_ptr + k);
+    double *pbuf = reinterpret_cast<double *>(slot_ptr + 2 * k); // 64 doubles for the serial prefix
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const CallKey ck0 = call_key(p.seed, p.call_id, p.tag);
+    for (int64_t v = wave_id; v < p.m; v += n_waves) {
+        const int64_t w = p.vertices[v];
+        uint32_t n = 0;
+        if (lane < k) slot_rank[lane] = 0;
+        wave_lds_handoff();
+        if (w >= 0) {
+            const int64_t st = p.states ? p.states[v] : 0;
+            const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
+            const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
+            const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[v], p.tag) : ck0;
+            double w_sum = 0.0;
+            for (int64_t gbase = e0; gbase < e1; gbase += 64 * HS_CHUNKS) {
+                int64_t tsv[HS_CHUNKS];
+                double wvv[HS_CHUNKS];
+#pragma unroll
+                for (int u = 0; u < HS_CHUNKS; ++u) {
+                    const int64_t e = gbase + u * 64 + lane;
+                    tsv[u] = (p.filter_mode != TG_FILTER_NONE && e < e1) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
+                    wvv[u] = (e < e1) ? __builtin_nontemporal_load(&p.weights[e]) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < HS_CHUNKS; ++u) {
+                    const int64_t base = gbase + u * 64;
+                    if (base >= e1) break;
+                    const int64_t e = base + lane;
+                    const bool ok = e < e1 && hs_pass(p, st, tsv[u]);
+                    const uint64_t mask = __ballot(ok);
+                    const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
+                    const double wv = ok ? wvv[u] : 0.0; // x + 0.0 == x: excluded edges leave the running sum alone
+                    double tot;
+                    const double pref = wave_serial_prefix_f64(wv, w_sum, &tot, pbuf); // left-to-right, sampling.rs:40,48
+                    w_sum = tot;
+                    uint32_t hit_slot = 0xffffffffu;
+                    if (ok && rank >= (uint32_t)k) {
+                        if (!(0.0 < pref)) {
+                            atomicOr(p.status, 2);
+                        } else {
+                            const Draw d = draw(ck, did, rank, D1_WEIGHTED);
+                            const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                            if (j < wv) hit_slot = (uint32_t)bounded64(d.b(), (uint64_t)k);
+                        }
+                    }
+                    const bool fill = ok && rank < (uint32_t)k;
+                    if (__ballot(fill || hit_slot != 0xffffffffu) != 0ull) {
+                        if (fill) slot_ptr[rank] = e;
+                        if (hit_slot != 0xffffffffu) atomicMax(&slot_rank[hit_slot], rank);
+                        wave_lds_handoff();
+                        if (hit_slot != 0xffffffffu && slot_rank[hit_slot] == rank) slot_ptr[hit_slot] = e; // last hit wins
+                        wave_lds_handoff();
+                    }
+                    n += (uint32_t)__popcll(mask);
+                }
+            }
+        }
+        wave_lds_handoff();
+        const uint32_t cnt_sel = min(n, (uint32_t)k);
+        if (lane == 0) p.cnt[v] = cnt_sel;
+        if (lane < k) p.park[v * k + lane] = ((uint32_t)lane < cnt_sel) ? slot_ptr[lane] : -1;
+        wave_lds_handoff();
+    }
+}
+
 // thread per output edge: owner vertex by binary search over offsets, slot from the difference
 __global__ void hs_emit_kernel(const HopScanParams p) {
     const int64_t total = p.offsets[p.m];
@@ -217,7 +296,8 @@ __global__ void hs_emit_kernel(const HopScanParams p) {
         p.neighbors[o] = p.indices[ep];
         p.edge_ptrs[o] = ep;
         p.parents[o] = v;
-        p.states_out[o] = (p.filter_mode == TG_FILTER_DYNAMIC) ? p.timestamps[ep] : p.states[v]; // :69-76
+        if (p.filter_mode != TG_FILTER_NONE)
+            p.states_out[o] = (p.filter_mode == TG_FILTER_DYNAMIC) ? p.timestamps[ep] : p.states[v]; // :69-76
     }
 }
 
@@ -268,6 +348,7 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
     p.ptrs = csc->ptrs;
     p.indices = csc->indices;
     p.timestamps = csc->timestamps;
+    p.weights = nullptr;
     p.vertices = in->vertices;
     p.states = flt->states;
     p.ids = in->ids;
@@ -327,6 +408,82 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
     st = temp_bytes;
     TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
     hipLaunchKernelGGL(hs_emit_kernel, grid(p.m * p.k, 256), dim3(256), 0, stream, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
+                                  const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                                  int64_t workspace_bytes, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(csc && csc->ptrs && csc->weights && in && rng && out && status, "tg_ns_hop_weighted: null argument");
+    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= 64, "tg_ns_hop_weighted: bad frontier size or fan-out (<= 64)");
+    const int filter_mode = flt ? flt->filter_mode : TG_FILTER_NONE;
+    TG_REQUIRE(filter_mode >= TG_FILTER_NONE && filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_weighted: bad filter");
+    TG_REQUIRE(filter_mode == TG_FILTER_NONE || (csc->timestamps && flt->states && states_out),
+               "tg_ns_hop_weighted: the filter needs edge timestamps and states");
+    TG_REQUIRE(out->cnt && out->offsets, "tg_ns_hop_weighted: null outputs");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (in->m == 0) {
+        TG_HIP(hipMemsetAsync(out->offsets, 0, sizeof(int64_t), stream));
+        return TG_OK;
+    }
+    int64_t need = 0;
+    int rc = tg_ns_hop_scan_workspace_bytes(in->m, in->fanout, 1, &need);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(workspace && workspace_bytes >= need, "tg_ns_hop_weighted: workspace too small");
+    TG_REQUIRE(in->vertices && out->neighbors && out->edge_ptrs && out->parents, "tg_ns_hop_weighted: null buffers");
+    HopScanParams p{};
+    p.ptrs = csc->ptrs;
+    p.indices = csc->indices;
+    p.timestamps = csc->timestamps;
+    p.weights = csc->weights;
+    p.vertices = in->vertices;
+    p.states = filter_mode == TG_FILTER_NONE ? nullptr : flt->states;
+    p.ids = in->ids;
+    p.call_ids = in->call_ids;
+    p.m = in->m;
+    p.id_base = in->id_base;
+    p.k = in->fanout;
+    p.filter_mode = filter_mode;
+    p.forward = flt ? flt->forward : 0;
+    p.win_lo = flt ? flt->win_lo : 0;
+    p.win_hi = flt ? flt->win_hi : 0;
+    p.tag = in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO;
+    p.seed = rng->seed;
+    p.call_id = rng->call_id;
+    p.group_cap = 1;
+    unsigned char *base = reinterpret_cast<unsigned char *>(workspace);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *q = base + off;
+        off += hs_align(bytes);
+        return q;
+    };
+    p.vgroups = reinterpret_cast<int64_t *>(take(8 * (size_t)(p.m + 1)));
+    p.gcount = reinterpret_cast<uint32_t *>(take(4));
+    p.gpref = reinterpret_cast<int64_t *>(take(16));
+    p.park = reinterpret_cast<int64_t *>(take(8 * (size_t)p.m * p.k));
+    void *temp = base + off;
+    size_t temp_bytes = (size_t)workspace_bytes - off;
+    p.status = status;
+    p.cnt = out->cnt;
+    p.offsets = out->offsets;
+    p.neighbors = out->neighbors;
+    p.edge_ptrs = out->edge_ptrs;
+    p.parents = out->parents;
+    p.states_out = states_out;
+    const int n_waves = 4;
+    const size_t lds = (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t);
+    int64_t blocks = (p.m + n_waves - 1) / n_waves;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
+    TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
+    size_t st = temp_bytes;
+    TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
+    int64_t g = (p.m * p.k + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(hs_emit_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -107,4 +107,29 @@ __device__ __forceinline__ void wave_lds_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Left-to-right inclusive prefix of one f64 per lane starting from `carry`: lane l receives
+// (((carry + v0) + v1) + ... + vl) with exactly the reference's rounding (sampling.rs:40,48 sums weights in
+// candidate order).  The chain is inherently serial, so it is kept as short as the hardware allows: the 64 values
+// go to LDS (`buf`, 64 doubles owned by this wavefront), ONE lane runs the dependent v_add_f64 chain over them
+// (the LDS reads pipeline ahead of the adds, the writes trail them), every lane then reads its prefix.
+// *total = the value after lane 63.
+__device__ __forceinline__ double wave_serial_prefix_f64(double v, double carry, double *total, double *buf) {
+    const int lane = lane_id();
+    buf[lane] = v;
+    wave_lds_handoff();
+    if (lane == 0) {
+        double r = carry;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) {
+            r = r + buf[l];
+            buf[l] = r;
+        }
+    }
+    wave_lds_handoff();
+    const double mine = buf[lane];
+    *total = buf[63];
+    wave_lds_handoff();
+    return mine;
+}
+
 } // namespace tg

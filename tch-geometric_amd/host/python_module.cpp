@@ -92,26 +92,29 @@ struct NsResult {
 };
 // Uniform samplers under a temporal filter: hop by hop through tg_ns_hop_scan, which spreads the column scans
 // over the whole device (the one-workgroup-per-batch kernel needs many batches in one launch to do that).
-NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const Tensor &indices,
+NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const Tensor &indices, const Tensor &weights,
                               const Tensor &timestamps, const Tensor &seeds, const Tensor &seeds_state,
                               const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f,
                               const tg_rng &rng, uint32_t tag, int64_t id_base) {
     NsResult r;
     const int64_t n_seeds = seeds.numel();
+    const bool weighted = s.kind == TG_SAMPLER_WEIGHTED, filtered = f.mode != TG_FILTER_NONE;
     tg_graph g{};
     g.ptrs = ptrs.data_ptr<int64_t>();
     g.indices = indices.numel() ? indices.data_ptr<int64_t>() : nullptr;
-    g.timestamps = timestamps.data_ptr<int64_t>();
+    g.timestamps = filtered ? timestamps.data_ptr<int64_t>() : nullptr;
+    g.weights = weighted ? weights.data_ptr<double>() : nullptr;
     g.n_major = ptrs.numel() - 1;
     g.n_edges = indices.numel();
-    std::vector<Tensor> samples{seeds}, states{seeds_state}, rows, cols, eidx;
+    std::vector<Tensor> samples{seeds}, states, rows, cols, eidx;
+    if (filtered) states.push_back(seeds_state);
     Tensor frontier = seeds, fstate = seeds_state;
     int64_t ne = 0, slot0 = 0;
     for (int64_t k : fanout) {
         r.layer_offsets.emplace_back(n_seeds + ne, ne, n_seeds + ne); // neighbor_sampling.rs:193
         const int64_t m = frontier.numel();
         if (m == 0) continue;
-        if (k > 64) throw py::value_error("num_neighbors above 64 is not supported together with a temporal filter");
+        if (k > 64) throw py::value_error("num_neighbors above 64 is not supported with a temporal filter or weights");
         Tensor cnt = at::empty({m}, i64(dev)), offsets = at::empty({m + 1}, i64(dev));
         Tensor nbr = at::empty({m * k}, i64(dev)), ep = at::empty({m * k}, i64(dev)), par = at::empty({m * k}, i64(dev));
         Tensor st_out = at::empty({m * k}, i64(dev));
@@ -127,10 +130,21 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
         flt.forward = f.forward ? 1 : 0;
         flt.win_lo = f.win_lo;
         flt.win_hi = f.win_hi;
-        flt.states = fstate.data_ptr<int64_t>();
+        flt.states = filtered ? fstate.data_ptr<int64_t>() : nullptr;
         tg_hop_out out{cnt.data_ptr<int64_t>(), offsets.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(),
                        ep.data_ptr<int64_t>(), par.data_ptr<int64_t>()};
         int64_t group_cap = std::max<int64_t>(1024, indices.numel() / 512 + 2 * m + 2), total = 0;
+        if (weighted) { // sampling.rs:28-55, one wavefront per frontier vertex all over the device
+            Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+            int64_t ws_bytes = 0;
+            check_rc(tg_ns_hop_scan_workspace_bytes(m, (int32_t)k, 1, &ws_bytes));
+            Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
+            check_rc(tg_ns_hop_weighted(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
+                                        ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
+            total = offsets[m].item<int64_t>();
+            if (status.item<int32_t>() & 2) // sampling.rs:49: gen_range over an empty float range panics
+                throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+        } else
         for (;;) { // the frontier's columns need sum(ceil(deg/512)) groups; grow the workspace if the guess was low
             Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
             int64_t ws_bytes = 0;
@@ -144,7 +158,7 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
         }
         if (total > 0) {
             samples.push_back(nbr.narrow(0, 0, total));
-            states.push_back(st_out.narrow(0, 0, total));
+            if (filtered) states.push_back(st_out.narrow(0, 0, total));
             rows.push_back(at::arange(n_seeds + ne, n_seeds + ne + total, i64(dev)));
             cols.push_back(par.narrow(0, 0, total) + slot0);
             eidx.push_back(ep.narrow(0, 0, total));
@@ -156,7 +170,7 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
     }
     auto cat_or_empty = [&](const std::vector<Tensor> &v) { return v.empty() ? at::empty({0}, i64(dev)) : at::cat(v); };
     r.samples = at::cat(samples);
-    r.states = at::cat(states);
+    if (filtered) r.states = at::cat(states);
     r.rows = cat_or_empty(rows);
     r.cols = cat_or_empty(cols);
     r.edge_index = cat_or_empty(eidx);
@@ -169,8 +183,9 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
                 const Tensor &timestamps, const Tensor &seeds, const Tensor &seeds_state,
                 const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f, const tg_rng &rng,
                 uint32_t tag, int64_t id_base) {
-    if (f.mode != TG_FILTER_NONE && s.kind != TG_SAMPLER_WEIGHTED)
-        return run_ns_filtered_flat(dev, ptrs, indices, timestamps, seeds, seeds_state, fanout, s, f, rng, tag, id_base);
+    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED) // whole-device flat hops (scan / weighted)
+        return run_ns_filtered_flat(dev, ptrs, indices, weights, timestamps, seeds, seeds_state, fanout, s, f, rng, tag,
+                                    id_base);
     const int32_t H = (int32_t)fanout.size();
     int64_t cap_nodes = 0, cap_edges = 0;
     check_rc(tg_ns_homo_capacity(seeds.numel(), fanout.data(), H, &cap_nodes, &cap_edges));

@@ -74,4 +74,14 @@ for j in range(10):
 torch.cuda.synchronize()
 res["temporal_static_single_call_through_surface"] = {"ms_per_call": (time.perf_counter() - t0) / 10 * 1e3,
                                                        "sampled_edges": int(o[1].numel())}
+wsampler = tg.WeightedEdgeSampler(w)
+for _ in range(2):
+    o = tg.neighbor_sampling_homogenous(ptrs, idx, seeds[0], fan, wsampler)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for j in range(5):
+    o = tg.neighbor_sampling_homogenous(ptrs, idx, seeds[j % nb], fan, wsampler)
+torch.cuda.synchronize()
+res["weighted_single_call_through_surface"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3,
+                                                "sampled_edges": int(o[1].numel())}
 print(json.dumps(res))
