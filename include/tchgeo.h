@@ -307,6 +307,15 @@ TG_API int tg_check_range(const int64_t *values, int64_t n, int64_t lo, int64_t 
 /* ind2ptr (src/data/storage.rs:67-101) on the device: sorted `ind` [numel] -> out [m+1]. */
 TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out, void *stream);
 
+/* Mini-batch materialisation, the step AFTER the path: dst[i, :] = src[index[i], :] for
+ * i < n, rows of `row_bytes` bytes, source rows `src_stride_bytes` apart (>= row_bytes), dst rows packed.  This is the
+ * `x[samples]` / `edge_attr[perm[edge_index]]` gather the reference's examples leave to PyG's filter_data
+ * (examples/neighbor_sampling.py:24,36,48; examples/neighbor_sampling_typed.py:27).  dtype-agnostic (bytes); uses
+ * 16-byte vectors when pointers, stride and row length are 16-byte multiples.  An index outside [0, n_src_rows)
+ * writes a zero row and sets status[0] |= 1 (device int32, zeroed by the caller; may be NULL). */
+TG_API int tg_gather_rows(const void *src, int64_t n_src_rows, int64_t row_bytes, int64_t src_stride_bytes,
+                          const int64_t *index, int64_t n, void *dst, int32_t *status, void *stream);
+
 /* Harness calibration (not part of the sampling path): n_threads lanes each issue per_thread
  * independent random 8-byte loads from table[0..n_table); sink: [n_threads]. */
 TG_API int tg_probe_random_gather(const int64_t *table, int64_t n_table, int64_t n_threads, int64_t per_thread,

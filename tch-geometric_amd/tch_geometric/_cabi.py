@@ -21,7 +21,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
            "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
-           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted"]
+           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows"]
 
 
 class TgGraph(C.Structure):
@@ -221,6 +221,30 @@ def coo_to_csx(row, col, size0, size1, csc):
                             C.c_int64(size1), C.c_int32(int(csc)), ptr(ptrs), ptr(indices), ptr(perm), ptr(ws),
                             C.c_int64(nbytes.value), stream_ptr(dev)))
     return ptrs, indices, perm
+
+
+def gather_rows(src, index, status=None):
+    """dst[i] = src[index[i]] over dim 0 (tg_gather_rows).  `src` may be strided over dim 0 only.  Returns
+    (dst, status): status is a device int32 word, 1 when an index fell outside [0, src.shape[0])."""
+    dev = src.device
+    if src.dim() == 0:
+        raise ValueError("gather_rows needs at least one dimension")
+    inner = src[0].is_contiguous() if src.shape[0] else True
+    if not inner or (src.dim() > 1 and src.shape[0] > 1 and src.stride(0) < src[0].numel()):
+        src = src.contiguous()
+    row_elems = 1
+    for d in src.shape[1:]:
+        row_elems *= d
+    item = src.element_size()
+    stride = src.stride(0) * item if src.shape[0] > 1 else row_elems * item
+    index = index.contiguous()
+    dst = torch.empty((index.numel(),) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.tg_gather_rows(C.c_void_p(src.data_ptr()), C.c_int64(src.shape[0]), C.c_int64(row_elems * item),
+                             C.c_int64(max(stride, row_elems * item)), ptr(index), C.c_int64(index.numel()),
+                             C.c_void_p(dst.data_ptr()), C.c_void_p(status.data_ptr()), stream_ptr(dev)))
+    return dst, status
 
 
 def probe_random_gather(table, n_threads, per_thread, seed=1):
