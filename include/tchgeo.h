@@ -192,6 +192,23 @@ TG_API int tg_tempo_random_walk(const tg_graph *csr, const int64_t *node_ts, con
                          const int64_t *start_ts, int64_t n, int64_t walk_length, int64_t win0, int64_t win1,
                          const tg_rng *rng, int64_t *walks, int64_t *walks_ts, void *stream);
 
+/* biased_tempo_random_walk (random_walk.rs:160-288; binding python.rs:645-687): time-respecting walk whose next
+ * vertex is drawn with BiasType weights (random_walk.rs:165-182) by the one-slot weighted reservoir (f32,
+ * utils/sampling.rs:28-55); a walker without candidates restarts from its start vertex, at most retry_count times.
+ * walks, walks_ts: [n, walk_length] device int64.  status (device int32, zeroed by the caller): bit 1 = the reference
+ * would have panicked (empty float range, sampling.rs:49), bit 0 = a row longer than `max_degree` met the linear
+ * bias.  `max_degree` (largest CSR row) sizes the sort slab the linear bias needs for rows above 1024 edges:
+ * workspace = tg_biased_walk_workspace_bytes(n, max_degree, bias), 0 for the other biases. */
+#define TG_BIAS_UNIFORM 0
+#define TG_BIAS_LINEAR 1
+#define TG_BIAS_EXPONENTIAL 2
+TG_API int tg_biased_walk_workspace_bytes(int64_t n, int64_t max_degree, int32_t bias, int64_t *bytes);
+TG_API int tg_biased_tempo_random_walk(const tg_graph *csr, const int64_t *node_ts, const int64_t *edge_ts,
+                                       const int64_t *start, const int64_t *start_ts, int64_t n, int64_t walk_length,
+                                       int32_t bias, int32_t forward, int64_t retry_count, int64_t max_degree,
+                                       const tg_rng *rng, int64_t *walks, int64_t *walks_ts, int32_t *status,
+                                       void *workspace, int64_t workspace_bytes, void *stream);
+
 /* negative_sample_neighbors_homogenous / _heterogenous (src/algo/negative_sampling.rs:6-131; bindings
  * python.rs:690-783) as one problem description.  Host arrays are indexed by node type (order of the caller's
  * `node_types`) and relation (order of `edge_types`); the reference's HashMap visiting order is replaced by

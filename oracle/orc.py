@@ -296,6 +296,25 @@ def tempo_random_walk(row_ptrs, col_indices, node_ts, edge_ts, start, start_ts, 
     return walks, wts
 
 
+BIAS = {"uniform": 0, "linear": 1, "exponential": 2}
+
+
+def biased_tempo_random_walk(row_ptrs, col_indices, node_ts, edge_ts, start, start_ts, walk_length, bias_type, forward,
+                             retry_count, rng):
+    """random_walk.rs:184-288; raises RuntimeError where the reference panics."""
+    ptrs, indices, start = _i64(row_ptrs), _i64(col_indices), _i64(start)
+    node_ts, edge_ts, start_ts = _i64(node_ts), _i64(edge_ts), _i64(start_ts)
+    walks = np.empty((start.size, walk_length), dtype=np.int64)
+    wts = np.empty((start.size, walk_length), dtype=np.int64)
+    rc = lib().orc_biased_tempo_random_walk(_p(ptrs), _p(indices), _p(node_ts), _p(edge_ts), _p(start), _p(start_ts),
+                                            C.c_int64(start.size), C.c_int64(walk_length), C.c_int32(BIAS[bias_type]),
+                                            C.c_int32(int(forward)), C.c_int64(retry_count), C.byref(rng), _p(walks),
+                                            _p(wts))
+    if rc != 0:
+        raise RuntimeError("cannot sample empty range (sampling.rs:49)")
+    return walks, wts
+
+
 # ---------------------------------------------------------------- negative sampling
 def neg_homo(row_ptrs, col_indices, graph_size, inputs, num_neg, try_count, rng):
     ptrs, indices, inputs = _i64(row_ptrs), _i64(col_indices), _i64(inputs)

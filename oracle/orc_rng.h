@@ -45,6 +45,7 @@
 #define ORC_TAG_RMAT 8u
 #define ORC_TAG_SEEDS 9u
 #define ORC_TAG_BUDGET 10u /* | node-type index << 8 */
+#define ORC_TAG_RW_BIASED 11u
 
 typedef struct {
     int32_t mode;

@@ -582,6 +582,164 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
 }
 
 /* ------------------------------------------------------------------ */
+/* random_walk.rs:160-288 biased_tempo_random_walk (CTDNE-style walk)  */
+/* ------------------------------------------------------------------ */
+#include "orc_exp_table.h"
+
+#define ORC_BIAS_UNIFORM 0
+#define ORC_BIAS_LINEAR 1
+#define ORC_BIAS_EXPONENTIAL 2
+
+typedef struct {
+    int32_t time;
+    int32_t pos;
+} orc_timepos;
+/* descending time, ties by ascending position: `times.argsort(0, true)` (random_walk.rs:171) made deterministic.
+ * tch 0.7.2's argsort is the non-stable at::argsort, whose tie order the reference leaves to libtorch. */
+static int orc_timepos_desc(const void *a, const void *b) {
+    const orc_timepos *x = (const orc_timepos *)a, *y = (const orc_timepos *)b;
+    if (x->time != y->time) return x->time > y->time ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+
+/* BiasType::apply (random_walk.rs:165-182) over the candidates' i32 times.  Arithmetic the reference delegates to
+ * libtorch and that therefore has no order / rounding fixed by the reference's own sources is pinned here as:
+ *   Linear       weight[c] = (f32)perm[c] / (f32)(n(n-1)/2), perm = argsort above (n == 1 gives 0/0 = NaN, as there);
+ *   Exponential  softmax of the i32 (wrapping) differences: e[c] = exp(-(m[c])) from the correctly rounded table,
+ *                m[c] = max_delta - delta[c] evaluated in f32 as softmax does, weight 0 from m >= 104;
+ *                denominator = sum over m = 0..103 of count[m] * e(m) accumulated in f64 in that order, rounded to
+ *                f32 (libtorch's vectorised summation order is not part of the reference). */
+static void orc_bias_weights(int bias, const int32_t *times, int64_t n, int64_t t, int forward, float *w) {
+    if (bias == ORC_BIAS_UNIFORM) {
+        for (int64_t c = 0; c < n; c++) w[c] = 1.0f;
+    } else if (bias == ORC_BIAS_LINEAR) {
+        orc_timepos *tp = (orc_timepos *)malloc(sizeof(orc_timepos) * (size_t)(n > 0 ? n : 1));
+        for (int64_t c = 0; c < n; c++) {
+            tp[c].time = times[c];
+            tp[c].pos = (int32_t)c;
+        }
+        qsort(tp, (size_t)n, sizeof(orc_timepos), orc_timepos_desc);
+        const float den = (float)(n * (n - 1) / 2);
+        for (int64_t c = 0; c < n; c++) w[c] = (float)tp[c].pos / den;
+        free(tp);
+    } else {
+        const uint32_t t32 = (uint32_t)(uint64_t)t;
+        float mx = 0.0f;
+        for (int64_t c = 0; c < n; c++) {
+            const int32_t d = (int32_t)(forward ? t32 - (uint32_t)times[c] : (uint32_t)times[c] - t32);
+            if (c == 0 || (float)d > mx) mx = (float)d;
+        }
+        int64_t hist[ORC_EXP_NEG_BITS_N];
+        memset(hist, 0, sizeof(hist));
+        for (int64_t c = 0; c < n; c++) {
+            const int32_t d = (int32_t)(forward ? t32 - (uint32_t)times[c] : (uint32_t)times[c] - t32);
+            const float m = mx - (float)d;
+            float e = 0.0f;
+            if (m < (float)ORC_EXP_NEG_BITS_N) {
+                memcpy(&e, &orc_exp_neg_bits[(int)m], 4);
+                hist[(int)m]++;
+            }
+            w[c] = e;
+        }
+        double acc = 0.0;
+        for (int m = 0; m < ORC_EXP_NEG_BITS_N; m++) {
+            float e;
+            memcpy(&e, &orc_exp_neg_bits[m], 4);
+            acc = acc + (double)hist[m] * (double)e;
+        }
+        const float den = (float)acc;
+        for (int64_t c = 0; c < n; c++) w[c] = w[c] / den;
+    }
+}
+
+/* walks, walks_ts: [n, walk_length].  Returns 0, or -1 where the reference panics (gen_range over an empty float range,
+ * sampling.rs:49: every weight so far underflowed to zero).  Philox address of candidate c of step l of attempt a of
+ * walker i: id = (i * retry_count + a) * walk_length + l, d0 = c, d1 = "WGT". */
+ORC_API int32_t orc_biased_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, const int64_t *node_ts,
+                                             const int64_t *edge_ts, const int64_t *start, const int64_t *start_ts,
+                                             int64_t n, int64_t walk_length, int32_t bias, int32_t forward,
+                                             int64_t retry_count, orc_rng *rng, int64_t *walks, int64_t *walks_ts) {
+    orc_ctx c;
+    orc_ctx_init(&c, rng, ORC_TAG_RW_BIASED);
+    const int64_t L = walk_length;
+    for (int64_t i = 0; i < n * L; i++) { /* :199-208 */
+        walks[i] = -1;
+        walks_ts[i] = -1;
+    }
+    vec64 cn = {0}, ct = {0};
+    int32_t *times = NULL;
+    float *w = NULL;
+    int64_t cap = 0;
+    int32_t status = 0;
+    for (int64_t i = 0; i < n && status == 0; i++) {
+        for (int64_t attempt = 0; attempt < retry_count && status == 0; attempt++) { /* :217 */
+            int64_t cur = start[i], cur_ts = start_ts[i];
+            walks[i * L] = cur;
+            walks_ts[i * L] = cur_ts;
+            for (int64_t l = 0; l < L - 1; l++) walks[i * L + l + 1] = -1; /* :223-225: timestamps are NOT reset */
+            int restart = 0;
+            for (int64_t l = 0; l < L - 1; l++) {
+                cn.n = ct.n = 0;
+                for (int64_t e = ptrs[cur]; e < ptrs[cur + 1]; e++) { /* :228-251 */
+                    const int64_t v = indices[e];
+                    const int64_t t = edge_ts[e] != ORC_NAN_TS ? edge_ts[e] : node_ts[v];
+                    if (t == ORC_NAN_TS || cur_ts == ORC_NAN_TS || cur_ts <= t) {
+                        vpush(&cn, v);
+                        vpush(&ct, t);
+                    }
+                }
+                const int64_t m = cn.n;
+                if (m > cap) {
+                    cap = m * 2;
+                    times = (int32_t *)realloc(times, sizeof(int32_t) * (size_t)cap);
+                    w = (float *)realloc(w, sizeof(float) * (size_t)cap);
+                }
+                for (int64_t k = 0; k < m; k++) /* :253-256 */
+                    times[k] = (int32_t)(uint32_t)(uint64_t)(ct.p[k] == ORC_NAN_TS ? cur_ts : ct.p[k]);
+                orc_bias_weights(cur_ts == ORC_NAN_TS ? ORC_BIAS_UNIFORM : bias, times, m, cur_ts, forward, w); /* :258-262 */
+                if (m == 0) { /* :273-276 */
+                    restart = 1;
+                    break;
+                }
+                /* reservoir_sampling_weighted with one slot and f32 weights (sampling.rs:28-55) */
+                const uint64_t step_id = ((uint64_t)i * (uint64_t)retry_count + (uint64_t)attempt) * (uint64_t)L + (uint64_t)l;
+                int64_t pick = 0;
+                float w_sum = 0.0f + w[0];
+                for (int64_t k = 1; k < m; k++) {
+                    w_sum = w_sum + w[k];
+                    if (!(0.0f < w_sum)) {
+                        status = -1;
+                        break;
+                    }
+                    float j;
+                    if (rng->mode == ORC_RNG_REF) {
+                        j = orc_ref_gen_range_f32(rng, w_sum);
+                    } else {
+                        j = orc_u32_to_f32_01(orc_ctx_draw(&c, step_id, (uint32_t)k, 0x57475400u).w[0]) * w_sum + 0.0f;
+                    }
+                    if (j < w[k]) {
+                        if (rng->mode == ORC_RNG_REF) (void)orc_ref_gen_range_u64(rng, 1); /* dst[gen_range(0..1)] */
+                        pick = k;
+                    }
+                }
+                if (status != 0) break;
+                const int64_t next = cn.p[pick], next_ts = ct.p[pick]; /* :278-284 */
+                cur = next;
+                if (next_ts != -1) cur_ts = next_ts;
+                walks[i * L + l + 1] = cur;
+                walks_ts[i * L + l + 1] = next_ts;
+            }
+            if (!restart) break; /* :286 */
+        }
+    }
+    vfree(&cn);
+    vfree(&ct);
+    free(times);
+    free(w);
+    return status;
+}
+
+/* ------------------------------------------------------------------ */
 /* Negative sampling: src/algo/negative_sampling.rs                    */
 /* ------------------------------------------------------------------ */
 /* tiny open-addressing map i64 -> i64 (first-seen order is kept by the

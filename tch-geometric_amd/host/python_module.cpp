@@ -490,9 +490,58 @@ std::tuple<Tensor, Tensor> tempo_random_walk(const Tensor &row_ptrs, const Tenso
     return {back(walks, start.device()), back(wts, start.device())};
 }
 
-[[noreturn]] void out_of_scope(const char *name) {
-    throw std::runtime_error(std::string(name) + " is outside this backend's scope (SURVEY.md section 8: not on the "
-                                                 "mini-batch construction hot path)");
+// python.rs:645-687
+std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, const Tensor &col_indices,
+                                                    const Tensor &node_timestamps, const Tensor &edge_timestamps,
+                                                    const Tensor &start, const Tensor &start_timestamps,
+                                                    int64_t walk_length, const std::string &bias_type, bool forward,
+                                                    int64_t retry_count) {
+    int32_t bias;
+    if (bias_type == "uniform") bias = TG_BIAS_UNIFORM;
+    else if (bias_type == "linear") bias = TG_BIAS_LINEAR;
+    else if (bias_type == "exponential") bias = TG_BIAS_EXPONENTIAL;
+    else throw py::value_error("Unknown bias type: " + bias_type); // python.rs:666-671
+    const c10::Device dev = compute_device({&row_ptrs, &col_indices, &start});
+    DeviceGuard guard(dev);
+    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
+    Tensor nts = on(node_timestamps, dev, at::kLong), ets = on(edge_timestamps, dev, at::kLong);
+    Tensor st = on(start, dev, at::kLong).reshape({-1}), sts = on(start_timestamps, dev, at::kLong).reshape({-1});
+    if (walk_length < 1) throw py::value_error("walk_length must be >= 1");
+    if (retry_count < 0) throw py::value_error("retry_count must be >= 0");
+    if (sts.numel() != st.numel()) throw py::value_error("start_timestamps must have one entry per start node");
+    if (nts.numel() < ptrs.numel() - 1) throw py::value_error("node_timestamps must have one entry per node");
+    if (ets.numel() != idx.numel()) throw py::value_error("edge_timestamps must have one entry per edge");
+    RangeCheck rc(dev);
+    rc.add(st, ptrs.numel() - 1);
+    rc.verify("biased_tempo_random_walk start");
+    Tensor walks = at::empty({st.numel(), walk_length}, i64(dev));
+    Tensor wts = at::empty({st.numel(), walk_length}, i64(dev));
+    if (st.numel() == 0) return {back(walks, start.device()), back(wts, start.device())};
+    // the linear bias sorts a row's candidates: rows above the LDS capacity need a slab sized by the largest row
+    int64_t max_degree = 0;
+    if (bias == TG_BIAS_LINEAR && ptrs.numel() > 1)
+        max_degree = (ptrs.slice(0, 1) - ptrs.slice(0, 0, ptrs.numel() - 1)).max().item<int64_t>();
+    int64_t ws_bytes = 0;
+    check_rc(tg_biased_walk_workspace_bytes(st.numel(), max_degree, bias, &ws_bytes));
+    Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
+    Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+    tg_graph g{};
+    g.ptrs = ptrs.data_ptr<int64_t>();
+    g.indices = idx.numel() ? idx.data_ptr<int64_t>() : nullptr;
+    g.n_major = ptrs.numel() - 1;
+    g.n_edges = idx.numel();
+    const tg_rng rng = next_rng();
+    check_rc(tg_biased_tempo_random_walk(&g, nts.data_ptr<int64_t>(), ets.numel() ? ets.data_ptr<int64_t>() : nullptr,
+                                         st.data_ptr<int64_t>(), sts.data_ptr<int64_t>(), st.numel(), walk_length, bias,
+                                         forward ? 1 : 0, retry_count, max_degree, &rng, walks.data_ptr<int64_t>(),
+                                         wts.data_ptr<int64_t>(), status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(),
+                                         ws_bytes, stream_of(dev)));
+    const int32_t flags = status.item<int32_t>();
+    if (flags & 2)
+        throw std::runtime_error("cannot sample empty range: every bias weight so far underflowed to zero (the "
+                                 "reference panics here, utils/sampling.rs:49)");
+    if (flags & 1) throw std::runtime_error("biased_tempo_random_walk: sort slab too small for a CSR row");
+    return {back(walks, start.device()), back(wts, start.device())};
 }
 
 } // namespace
@@ -536,6 +585,8 @@ PYBIND11_MODULE(tch_geometric, m) {
     m.def("tempo_random_walk", &tempo_random_walk, py::arg("row_ptrs"), py::arg("col_indices"),
           py::arg("node_timestamps"), py::arg("edge_timestamps"), py::arg("start"), py::arg("start_timestamps"),
           py::arg("walk_length"), py::arg("window"));
-    m.def("biased_tempo_random_walk", [](py::args, py::kwargs) { out_of_scope("biased_tempo_random_walk"); });
+    m.def("biased_tempo_random_walk", &biased_tempo_random_walk, py::arg("row_ptrs"), py::arg("col_indices"),
+          py::arg("node_timestamps"), py::arg("edge_timestamps"), py::arg("start"), py::arg("start_timestamps"),
+          py::arg("walk_length"), py::arg("bias_type"), py::arg("forward"), py::arg("retry_count"));
     register_more(m);
 }

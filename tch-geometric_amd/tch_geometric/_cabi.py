@@ -21,7 +21,8 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
            "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
-           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows"]
+           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows",
+           "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk"]
 
 
 class TgGraph(C.Structure):
@@ -175,6 +176,30 @@ def tempo_random_walk(graph, node_ts, edge_ts, start, start_ts, walk_length, win
                                    C.c_int64(window[1]), C.byref(rng), ptr(walks), ptr(wts),
                                    stream_ptr(start.device)))
     return walks, wts
+
+
+BIAS = {"uniform": 0, "linear": 1, "exponential": 2}
+
+
+def biased_tempo_random_walk(graph, node_ts, edge_ts, start, start_ts, walk_length, bias, forward, retry_count, seed,
+                             call_id, max_degree=None):
+    """-> (walks, walks_ts, status word)."""
+    dev, n = start.device, start.numel()
+    walks = torch.empty((n, walk_length), dtype=torch.int64, device=dev)
+    wts = torch.empty((n, walk_length), dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbytes = C.c_int64(0)
+    if max_degree is None:
+        max_degree = 0
+    check(lib.tg_biased_walk_workspace_bytes(C.c_int64(n), C.c_int64(max_degree), C.c_int32(BIAS[bias]), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, dtype=torch.int64, device=dev)
+    rng = TgRng(seed, call_id)
+    check(lib.tg_biased_tempo_random_walk(C.byref(graph), ptr(node_ts), ptr(edge_ts), ptr(start), ptr(start_ts),
+                                          C.c_int64(n), C.c_int64(walk_length), C.c_int32(BIAS[bias]),
+                                          C.c_int32(int(forward)), C.c_int64(retry_count), C.c_int64(max_degree),
+                                          C.byref(rng), ptr(walks), ptr(wts), ptr(status), ptr(ws),
+                                          C.c_int64(nbytes.value), stream_ptr(dev)))
+    return walks, wts, status
 
 
 def rmat_edges(scale, n_edges, seed, device):

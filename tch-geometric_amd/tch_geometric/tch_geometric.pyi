@@ -71,5 +71,7 @@ def budget_sampling(
 ) -> Tuple[Dict[NodeType, Tensor], Dict[NodeType, Tensor], Dict[RelType, Tensor], Dict[RelType, Tensor],
            Dict[RelType, Tensor]]: ...
 
-# outside this backend's scope; the name exists and raises RuntimeError
-def biased_tempo_random_walk(*args, **kwargs): ...
+def biased_tempo_random_walk(
+    row_ptrs: Tensor, col_indices: Tensor, node_timestamps: Tensor, edge_timestamps: Tensor, start: Tensor,
+    start_timestamps: Tensor, walk_length: int, bias_type: str, forward: bool, retry_count: int,
+) -> Tuple[Tensor, Tensor]: ...

@@ -98,8 +98,9 @@ def test_error_behaviour(tg):
                                         tg.WeightedEdgeSampler(torch.ones(2).cuda()))
     with pytest.raises(ValueError):
         tg.neighbor_sampling_homogenous(P, I, torch.tensor([0]).cuda(), [0])
-    with pytest.raises(RuntimeError, match="outside this backend's scope"):
-        tg.biased_tempo_random_walk()
+    with pytest.raises(ValueError, match="Unknown bias type: cubic"):           # python.rs:670
+        tg.biased_tempo_random_walk(P, I, torch.zeros(2, dtype=torch.int64).cuda(), torch.zeros(2, dtype=torch.int64).cuda(),
+                                    torch.tensor([0]).cuda(), torch.tensor([0]).cuda(), 3, "cubic", True, 2)
     with pytest.raises(RuntimeError):                                           # sampling.rs:49 panic
         tg.neighbor_sampling_homogenous(torch.tensor([0, 2, 2]).cuda(), torch.tensor([0, 1]).cuda(),
                                         torch.tensor([0]).cuda(), [1],      # 2 candidates, 1 slot: one float draw
