@@ -23,7 +23,10 @@ namespace tg {
 
 constexpr int NSS_CHUNKS_PER_ROUND = 1024;
 constexpr int NSS_PREFETCH = 8; // 64-edge chunks whose loads are in flight together per wavefront
-constexpr int NSS_GROUPS = 512;  // running-count slots per wavefront (group = 512 << shift edges)
+constexpr int NSS_GROUPS = 1024; // running-count slots per wavefront (group = 128 << shift edges)
+constexpr int NSS_PAIRS = 4;     // 16-byte loads per lane and round of the count pass (round = 512 edges)
+constexpr int NSS_FETCH = 8;     // slots whose groups are re-read together in the fetch pass
+typedef long long ts_pair __attribute__((ext_vector_type(2)));
 
 struct NsScanParams {
     const int64_t *ptrs;
@@ -65,11 +68,24 @@ __device__ __forceinline__ bool filter_pass(const NsScanParams &p, int64_t state
     return p.win_lo <= x && x <= p.win_hi;
 }
 
-__device__ __forceinline__ bool filter_value_pass(const NsScanParams &p, int64_t state, int64_t t) {
-    if (p.filter_mode == TG_FILTER_NONE) return true;
-    const int64_t x = (p.filter_mode == TG_FILTER_STATIC) ? t : (p.forward ? (t - state) : -(t - state));
-    return p.win_lo <= x && x <= p.win_hi;
-}
+// The same predicate without control flow, for the streaming loops: x = t (static), t - state (forward) or
+// state - t (backward) is (t ^ m) - m + off with m = 0 / -1; no filter = the full i64 window.  (Two's-complement
+// wrap-around is what the reference's release build does on overflow.)
+struct FilterEval {
+    int64_t m, off, lo, hi;
+    __device__ __forceinline__ FilterEval(const NsScanParams &p, int64_t state) {
+        const bool none = p.filter_mode == TG_FILTER_NONE, stat = p.filter_mode == TG_FILTER_STATIC;
+        const bool neg = !none && !stat && !p.forward;
+        m = neg ? -1 : 0;
+        off = (none || stat) ? 0 : (neg ? state : -state);
+        lo = none ? INT64_MIN : p.win_lo;
+        hi = none ? INT64_MAX : p.win_hi;
+    }
+    __device__ __forceinline__ bool operator()(int64_t t) const {
+        const int64_t x = (int64_t)(((uint64_t)(t ^ m) - (uint64_t)m) + (uint64_t)off);
+        return (int)(lo <= x) & (int)(x <= hi);
+    }
+};
 
 template <bool WEIGHTED>
 __global__ void ns_homo_scan_kernel(const NsScanParams p) {
@@ -105,6 +121,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
     }
     const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
     __shared__ int panic_flag; // the reference panics (empty float range) -- reported through counts
+    __shared__ unsigned long long next_vertex;
     if (tid == 0) panic_flag = 0;
     __syncthreads();
 
@@ -121,10 +138,30 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
         const int64_t hop_ne0 = ne;
 
         // ================= P1: one wavefront per frontier vertex
-        for (int64_t i = begin + wave; i < end; i += n_waves) {
-            const int64_t w = samples[i];
-            const int64_t st = has_state ? states[i] : 0;
-            const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
+        // (the next vertex's id, state and column bounds are loaded while the current column streams)
+        // Vertices are handed out dynamically (one LDS counter per workgroup): column lengths differ by orders of
+        // magnitude, a static split would leave three wavefronts waiting for the one that met a hub.
+        int64_t w_nx = 0, st_nx = 0, e0_nx = 0, e1_nx = 0;
+        if (tid == 0) next_vertex = (unsigned long long)(begin + n_waves);
+        __syncthreads();
+        if (begin + wave < end) {
+            w_nx = samples[begin + wave];
+            st_nx = has_state ? states[begin + wave] : 0;
+            e0_nx = p.ptrs[w_nx];
+            e1_nx = p.ptrs[w_nx + 1];
+        }
+        int64_t i_take = begin + wave;
+        while (i_take < end) {
+            const int64_t i = i_take;
+            const int64_t st = st_nx;
+            const int64_t e0 = e0_nx, e1 = e1_nx;
+            unsigned long long taken = 0;
+            if (lane == 0) taken = atomicAdd(&next_vertex, 1ull);
+            i_take = (int64_t)__shfl(taken, 0, 64);
+            const int64_t i_nx = min(i_take, end - 1); // clamped: the loads below stay unconditional
+            w_nx = samples[i_nx];
+            st_nx = has_state ? states[i_nx] : 0;
+            const FilterEval fpass(p, st);
             uint32_t n = 0; // admissible candidates seen so far
             if (lane < k) slot_rank[lane] = 0;
             wave_lds_handoff();
@@ -132,28 +169,51 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                 // ---- uniform samplers under a filter: count, draw ranks, fetch only the groups that hold them.
                 // pass 1 streams the column once (8 chunks in flight per lane) and keeps the running count of
                 // admissible edges at the end of every group of 512 << shift edges in LDS;
-                const int64_t deg = e1 - e0;
+                // (16-byte loads: two timestamps per lane, pairs aligned to 16 B, so groups are cut relative to the
+                // aligned start a0 <= e0; two rounds of 4 loads per lane are in flight -- the next round is issued
+                // before the current one is counted)
+                const int64_t a0 = e0 - (int64_t)((((uintptr_t)p.timestamps >> 3) ^ (uintptr_t)e0) & 1);
+                const int64_t deg = e1 - a0;
                 int shift = 0;
-                while (((deg + 511) >> (9 + shift)) > NSS_GROUPS) ++shift;
-                const int64_t gsize = (int64_t)512 << shift;
+                while (((deg + 127) >> (7 + shift)) > NSS_GROUPS) ++shift;
+                const int64_t n_sub = (deg + 127) >> 7; // 128-edge sub-blocks: one 16-byte load per lane
+                const int64_t n_rounds = (n_sub + NSS_PAIRS - 1) / NSS_PAIRS;
+                const int64_t spg_mask = ((int64_t)1 << shift) - 1;
                 int g = 0;
-                for (int64_t gb = e0; gb < e1; gb += gsize, ++g) {
-                    const int64_t ge = min(gb + gsize, e1);
-                    for (int64_t cb = gb; cb < ge; cb += 64 * NSS_PREFETCH) {
-                        int64_t tsv[NSS_PREFETCH];
+                ts_pair bufA[NSS_PAIRS], bufB[NSS_PAIRS];
+                auto issue = [&](ts_pair *buf, int64_t r) {
 #pragma unroll
-                        for (int u = 0; u < NSS_PREFETCH; ++u) {
-                            const int64_t e = cb + u * 64 + lane;
-                            tsv[u] = (e < ge) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
-                        }
+                    for (int u = 0; u < NSS_PAIRS; ++u) {
+                        // unconditional (out-of-column lanes re-read the column's first pair and are masked when
+                        // counted): a branch per load would make the compiler wait for ALL loads in flight
+                        const int64_t e = a0 + (((r * NSS_PAIRS + u) << 6) + lane) * 2;
+                        buf[u] = __builtin_nontemporal_load(reinterpret_cast<const ts_pair *>(p.timestamps + ((e < e1) ? e : a0)));
+                    }
+                };
+                auto count = [&](const ts_pair *buf, int64_t r) {
 #pragma unroll
-                        for (int u = 0; u < NSS_PREFETCH; ++u) {
-                            const int64_t e = cb + u * 64 + lane;
-                            n += (uint32_t)__popcll(__ballot(e < ge && filter_value_pass(p, st, tsv[u])));
+                    for (int u = 0; u < NSS_PAIRS; ++u) {
+                        const int64_t sb = r * NSS_PAIRS + u;
+                        const int64_t e = a0 + ((sb << 6) + lane) * 2;
+                        n += (uint32_t)__popcll(__ballot((int)(e >= e0) & (int)(e < e1) & (int)fpass(buf[u].x)));
+                        n += (uint32_t)__popcll(__ballot((int)(e + 1 < e1) & (int)fpass(buf[u].y)));
+                        if (sb < n_sub && (((sb + 1) & spg_mask) == 0 || sb + 1 == n_sub)) {
+                            if (lane == 0) gpref[g] = n;
+                            ++g;
                         }
                     }
-                    if (lane == 0) gpref[g] = n;
+                };
+                // rounds past the column's end are issued too (they re-read its first pair and count nothing): the
+                // loop body stays free of branches around loads, which keeps the s_waitcnt counts exact
+                issue(bufA, 0);
+                for (int64_t r = 0; r < n_rounds; r += 2) {
+                    issue(bufB, r + 1);
+                    count(bufA, r);
+                    issue(bufA, r + 2);
+                    count(bufB, r + 1);
                 }
+                e0_nx = p.ptrs[w_nx]; // next vertex's column bounds: in flight during the fetch pass
+                e1_nx = p.ptrs[w_nx + 1];
                 const int n_groups = g;
                 wave_lds_handoff();
                 // the ranks to fetch: every candidate when there are few, k draws of U[0,n) with replacement
@@ -186,43 +246,80 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                         }
                     }
                 }
-                // pass 2: slot by slot, re-read only the group that contains the rank
-                for (uint32_t s = 0; s < cnt_sel; ++s) {
-                    const uint32_t r = __shfl(myrank, (int)s, 64);
-                    int lo_g = 0, hi_g = n_groups - 1; // first group whose running count exceeds r
+                // pass 2: lane s finds the group that holds slot s's rank (first group whose running count exceeds
+                // it); the groups of NSS_FETCH slots are then re-read together, one 16-byte load per lane and slot
+                int mygroup = 0;
+                if ((uint32_t)lane < cnt_sel) {
+                    int lo_g = 0, hi_g = n_groups - 1;
                     while (lo_g < hi_g) {
                         const int mid = (lo_g + hi_g) >> 1;
-                        if (gpref[mid] > r)
+                        if (gpref[mid] > myrank)
                             hi_g = mid;
                         else
                             lo_g = mid + 1;
                     }
-                    uint32_t seen = lo_g > 0 ? gpref[lo_g - 1] : 0u;
-                    const int64_t gb = e0 + (int64_t)lo_g * gsize, ge = min(gb + gsize, e1);
-                    bool found = false;
-                    for (int64_t cb = gb; cb < ge && !found; cb += 64 * NSS_PREFETCH) {
-                        int64_t tsv[NSS_PREFETCH];
+                    mygroup = lo_g;
+                }
+                if (shift == 0) {
+                    for (uint32_t s0 = 0; s0 < cnt_sel; s0 += NSS_FETCH) {
+                        ts_pair v[NSS_FETCH];
+                        int gq[NSS_FETCH];
 #pragma unroll
-                        for (int u = 0; u < NSS_PREFETCH; ++u) {
-                            const int64_t e = cb + u * 64 + lane;
-                            tsv[u] = (e < ge) ? p.timestamps[e] : 0;
+                        for (int u = 0; u < NSS_FETCH; ++u) {
+                            gq[u] = __shfl(mygroup, (int)min(s0 + (uint32_t)u, 63u), 64);
+                            const int64_t e = a0 + ((int64_t)gq[u] << 7) + 2 * lane;
+                            v[u] = *reinterpret_cast<const ts_pair *>(p.timestamps + ((e < e1) ? e : a0));
                         }
 #pragma unroll
-                        for (int u = 0; u < NSS_PREFETCH; ++u) {
-                            if (found) break;
-                            const int64_t e = cb + u * 64 + lane;
-                            const bool ok = e < ge && filter_value_pass(p, st, tsv[u]);
-                            const uint64_t mask = __ballot(ok);
-                            const uint32_t c = (uint32_t)__popcll(mask);
-                            if (r - seen < c) {
-                                if (ok && seen + (uint32_t)__popcll(mask & lt_mask) == r) slot_ptr[s] = e;
-                                found = true;
+                        for (int u = 0; u < NSS_FETCH; ++u) {
+                            const uint32_t sl = s0 + (uint32_t)u;
+                            const uint32_t r = __shfl(myrank, (int)min(sl, 63u), 64);
+                            const uint32_t seen = gq[u] > 0 ? gpref[gq[u] - 1] : 0u;
+                            const int64_t e = a0 + ((int64_t)gq[u] << 7) + 2 * lane;
+                            const bool okx = (int)(e >= e0) & (int)(e < e1) & (int)fpass(v[u].x);
+                            const bool oky = (int)(e + 1 < e1) & (int)fpass(v[u].y);
+                            const uint64_t mx = __ballot(okx), my = __ballot(oky);
+                            const uint32_t before = seen + (uint32_t)__popcll(mx & lt_mask) + (uint32_t)__popcll(my & lt_mask);
+                            if (sl < cnt_sel) {
+                                if (okx && before == r) slot_ptr[sl] = e;
+                                if (oky && before + (uint32_t)okx == r) slot_ptr[sl] = e + 1;
                             }
-                            seen += c;
+                        }
+                    }
+                } else { // columns above 128 * NSS_GROUPS edges: groups of 128 << shift edges, slot by slot
+                    const int64_t gsize = (int64_t)128 << shift;
+                    for (uint32_t sl = 0; sl < cnt_sel; ++sl) {
+                        const uint32_t r = __shfl(myrank, (int)sl, 64);
+                        const int lo_g = __shfl(mygroup, (int)sl, 64);
+                        uint32_t seen = lo_g > 0 ? gpref[lo_g - 1] : 0u;
+                        const int64_t gb = a0 + (int64_t)lo_g * gsize, ge = min(gb + gsize, e1);
+                        bool found = false;
+                        for (int64_t cb = gb; cb < ge && !found; cb += 64 * NSS_PREFETCH) {
+                            int64_t tsv[NSS_PREFETCH];
+#pragma unroll
+                            for (int u = 0; u < NSS_PREFETCH; ++u) {
+                                const int64_t e = cb + u * 64 + lane;
+                                tsv[u] = p.timestamps[(e >= e0 && e < ge) ? e : e0];
+                            }
+#pragma unroll
+                            for (int u = 0; u < NSS_PREFETCH; ++u) {
+                                if (found) break;
+                                const int64_t e = cb + u * 64 + lane;
+                                const bool ok = (int)(e >= e0) & (int)(e < ge) & (int)fpass(tsv[u]);
+                                const uint64_t mask = __ballot(ok);
+                                const uint32_t c = (uint32_t)__popcll(mask);
+                                if (r - seen < c) {
+                                    if (ok && seen + (uint32_t)__popcll(mask & lt_mask) == r) slot_ptr[sl] = e;
+                                    found = true;
+                                }
+                                seen += c;
+                            }
                         }
                     }
                 }
             } else {
+                e0_nx = p.ptrs[w_nx];
+                e1_nx = p.ptrs[w_nx + 1];
                 // The column is streamed NSS_PREFETCH chunks at a time: all loads of a group are issued before any
                 // of them is consumed, so a wavefront keeps several HBM requests in flight instead of one.
                 double w_sum = 0.0;
@@ -241,7 +338,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                         const int64_t base = gbase + u * 64;
                         if (base >= e1) break;
                         const int64_t e = base + lane;
-                        const bool ok = e < e1 && filter_value_pass(p, st, tsv[u]);
+                        const bool ok = e < e1 && fpass(tsv[u]);
                         const uint64_t mask = __ballot(ok);
                         const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
                         uint32_t hit_slot = 0xffffffffu;

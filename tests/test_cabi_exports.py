@@ -55,3 +55,32 @@ def test_argument_errors_do_not_touch_the_gpu(lib):
     assert lib.tg_ns_homo_batched(None, None, C.c_int64(1), C.c_int64(1), None, 0, None, None, None, None) == 1
     assert b"null graph" in lib.tg_last_error()
     assert lib.tg_rmat_edges(0, C.c_int64(4), C.c_uint64(0), None, None, None) == 1
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary must be bindable from C / cgo / Rust bindgen: no C++ or HIP types in include/tchgeo.h"""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "tchgeo.h"\nint main(void) { tg_graph g; tg_rng r; (void)g; (void)r; return TG_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.dirname(HEADER),
+                           "-fsyntax-only", str(src)])
+    text = open(HEADER).read()
+    assert "hipStream_t stream" not in text and "at::" not in text and "torch" not in text.replace("no torch", "")
+
+
+def test_new_entry_points_reject_bad_arguments(lib):
+    lib.tg_last_error.restype = C.c_char_p
+    st = C.c_int32(0)
+    # negative sizes / short stride are refused before any launch
+    assert lib.tg_gather_rows(None, C.c_int64(4), C.c_int64(16), C.c_int64(8), None, C.c_int64(1), None, C.byref(st), None) == 1
+    assert b"stride" in lib.tg_last_error()
+    assert lib.tg_gather_rows(None, C.c_int64(0), C.c_int64(16), C.c_int64(16), None, C.c_int64(0), None, None, None) == 0
+    nbytes = C.c_int64(-1)
+    assert lib.tg_biased_walk_workspace_bytes(C.c_int64(10), C.c_int64(100), C.c_int32(1), C.byref(nbytes)) == 0
+    assert nbytes.value == 0                               # rows of <= 1024 edges sort in LDS
+    assert lib.tg_biased_walk_workspace_bytes(C.c_int64(10), C.c_int64(5000), C.c_int32(1), C.byref(nbytes)) == 0
+    assert nbytes.value == 3 * 4 * 8192 * 8                # 3 workgroups x 4 wavefronts x 2^13 keys
+    assert lib.tg_biased_walk_workspace_bytes(C.c_int64(10), C.c_int64(5000), C.c_int32(2), C.byref(nbytes)) == 0
+    assert nbytes.value == 0
+    assert lib.tg_biased_tempo_random_walk(None, None, None, None, None, C.c_int64(1), C.c_int64(2), C.c_int32(7),
+                                           C.c_int32(1), C.c_int64(1), C.c_int64(0), None, None, None, None, None,
+                                           C.c_int64(0), None) == 1
