@@ -23,13 +23,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
-    ap.add_argument("--warmup", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=16384)
+    ap.add_argument("--warmup", type=int, default=4096)
     ap.add_argument("--scale", type=int, default=24)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanout", type=str, default="15,10")
-    ap.add_argument("--batches-per-launch", type=int, default=1024)
+    ap.add_argument("--batches-per-launch", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")

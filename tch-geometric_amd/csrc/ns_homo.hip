@@ -47,7 +47,7 @@ struct NsHomoParams {
     uint64_t seed, call_id;
     uint32_t tag;
     int64_t id_base;
-    int32_t flags; // bit 0: streaming (non-temporal) gather loads
+    int32_t flags; // tuning knobs
     const int64_t *seed_ids, *seed_call_ids; // remote-frontier mode (n_hops == 1)
 };
 
@@ -60,6 +60,65 @@ __host__ __device__ inline size_t ns_wave_lds_bytes(int kmax, bool strips) {
 __host__ __device__ inline size_t ns_block_lds_bytes(int kmax, int n_waves, bool strips) {
     return (((size_t)(NS_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) +
            (size_t)n_waves * ns_wave_lds_bytes(kmax, strips);
+}
+
+constexpr int NS_EMIT = 4; // gathers per lane and batch of the emit loop (two batches in flight)
+
+// Emit of one 64-vertex chunk: the staged (lane, position) pairs are walked by consecutive lanes, the neighbour id is
+// gathered and the four output columns are written coalesced (neighbor_sampling.rs:211-217).  The gathers are the
+// kernel's HBM-latency exposure (each one is its own 128-byte line), so they are issued in batches of NS_EMIT per
+// lane with the next batch in flight while the current one is stored, and unconditionally -- lanes past the end
+// re-read element 0's address and skip the stores; a branch around a load would make the compiler wait for every
+// load in flight (s_waitcnt vmcnt(0)).
+template <typename IDX, bool NT>
+__device__ __forceinline__ void emit_chunk(const IDX *__restrict__ idx, uint32_t total, int lane, const uint8_t *slane,
+                                           const uint32_t *spos, const int64_t *ebase, int64_t e_chunk, int64_t i0,
+                                           int64_t n_seeds, int64_t *samples, int64_t *rows, int64_t *cols,
+                                           int64_t *eidx) {
+    if (total == 0) return;
+    struct Batch {
+        int l[NS_EMIT];
+        int64_t ep[NS_EMIT];
+        IDX v[NS_EMIT];
+    };
+    auto issue = [&](Batch &t, uint32_t q0) {
+#pragma unroll
+        for (int u = 0; u < NS_EMIT; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+            const uint32_t qq = q < total ? q : 0u;
+            t.l[u] = slane[qq];
+            t.ep[u] = ebase[t.l[u]] + (int64_t)spos[qq];
+        }
+#pragma unroll
+        for (int u = 0; u < NS_EMIT; ++u) t.v[u] = __builtin_nontemporal_load(&idx[t.ep[u]]); // each line is used once
+    };
+    auto store = [&](const Batch &t, uint32_t q0) {
+#pragma unroll
+        for (int u = 0; u < NS_EMIT; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+            if (q < total) {
+                const int64_t e = e_chunk + q;
+                samples[n_seeds + e] = (int64_t)t.v[u]; // :215 (re-read as the next hop's frontier: keep it cacheable)
+                if (NT) { // write-once outputs: stream them past L2 so gathers keep the cache
+                    __builtin_nontemporal_store(n_seeds + e, &rows[e]);          // :217 j
+                    __builtin_nontemporal_store(i0 + (int64_t)t.l[u], &cols[e]); // :217 i
+                    __builtin_nontemporal_store(t.ep[u], &eidx[e]);              // :217 edge_ptr
+                } else {
+                    rows[e] = n_seeds + e;
+                    cols[e] = i0 + (int64_t)t.l[u];
+                    eidx[e] = t.ep[u];
+                }
+            }
+        }
+    };
+    Batch a, b;
+    issue(a, 0u);
+    for (uint32_t q0 = 0; q0 < total; q0 += 2u * 64u * NS_EMIT) {
+        issue(b, q0 + 64u * NS_EMIT);
+        store(a, q0);
+        issue(a, q0 + 2u * 64u * NS_EMIT);
+        store(b, q0 + 64u * NS_EMIT);
+    }
 }
 
 template <int KMAX, bool REPLACE, bool NT>
@@ -174,27 +233,25 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 }
                 wave_lds_handoff();
                 const int64_t e_chunk = ne + (int64_t)chunk_off[c];
+                if (p.flags & 2) { // A/B knob: one gather in flight per lane
 #pragma unroll 4
-                for (uint32_t q = lane; q < total; q += 64) {
-                    const int l = slane[q];
-                    const int64_t ep = ebase[l] + (int64_t)spos[q];
-                    int64_t v; // :211
-                    if (p.indices32)
-                        v = (int64_t)((p.flags & 1) ? __builtin_nontemporal_load(&p.indices32[ep]) : p.indices32[ep]);
-                    else
-                        v = (p.flags & 1) ? __builtin_nontemporal_load(&p.indices[ep]) : p.indices[ep];
-                    const int64_t e = e_chunk + q;
-                    samples[n_seeds + e] = v; // :215 (re-read as the next hop's frontier: keep it cacheable)
-                    if (NT) { // write-once outputs: stream them past L2 so gathers keep the cache
-                        __builtin_nontemporal_store(n_seeds + e, &rows[e]); // :217 j
-                        __builtin_nontemporal_store(i0 + l, &cols[e]);      // :217 i
-                        __builtin_nontemporal_store(ep, &eidx[e]);          // :217 edge_ptr
-                    } else {
-                        rows[e] = n_seeds + e;
-                        cols[e] = i0 + l;
-                        eidx[e] = ep;
+                    for (uint32_t q = lane; q < total; q += 64) {
+                        const int l = slane[q];
+                        const int64_t ep = ebase[l] + (int64_t)spos[q];
+                        const int64_t v = p.indices32 ? (int64_t)__builtin_nontemporal_load(&p.indices32[ep])
+                                                      : __builtin_nontemporal_load(&p.indices[ep]);
+                        const int64_t e = e_chunk + q;
+                        samples[n_seeds + e] = v;
+                        __builtin_nontemporal_store(n_seeds + e, &rows[e]);
+                        __builtin_nontemporal_store(i0 + l, &cols[e]);
+                        __builtin_nontemporal_store(ep, &eidx[e]);
                     }
-                }
+                } else if (p.indices32)
+                    emit_chunk<uint32_t, NT>(p.indices32, total, lane, slane, spos, ebase, e_chunk, i0, n_seeds, samples,
+                                             rows, cols, eidx);
+                else
+                    emit_chunk<int64_t, NT>(p.indices, total, lane, slane, spos, ebase, e_chunk, i0, n_seeds, samples, rows,
+                                            cols, eidx);
                 wave_lds_handoff();
             }
             __syncthreads();
@@ -319,7 +376,7 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     p.call_id = rng->call_id;
     p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
     p.id_base = cfg ? cfg->id_base : 0;
-    p.flags = tg::env_int("TG_NS_NTLOAD", 1) ? 1 : 0; // each gathered line is used once: stream it
+    p.flags = tg::env_int("TG_NS_EMIT_SIMPLE", 0) ? 2 : 0;
     p.seed_ids = cfg ? cfg->seed_ids : nullptr;
     p.seed_call_ids = cfg ? cfg->seed_call_ids : nullptr;
     TG_REQUIRE((p.seed_ids == nullptr) == (p.seed_call_ids == nullptr),
