@@ -51,11 +51,17 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
                          % (args.gpus, world))
-    dev = torch.device("cuda", local_rank)
+    # TG_BENCH_REHEARSE=1: rehearsal of the N > 1 path on a one-GPU box -- every rank uses cuda:0 and the timing
+    # protocol's collectives go over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearse = os.environ.get("TG_BENCH_REHEARSE", "0") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     fanout = [int(x) for x in args.fanout.split(",")]
     n_nodes = 1 << args.scale

@@ -17,12 +17,14 @@ def rank_batch_range(rank: int, world: int, batches_per_rank: int):
 
 def reduce_measurement(elapsed_s: float, counters: torch.Tensor):
     """-> (max elapsed over ranks, counters summed over ranks).  No-op without a process group."""
-    t = torch.tensor([elapsed_s], dtype=torch.float64, device=counters.device)
-    tot = counters.clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    where = torch.device("cpu") if active and dist.get_backend() == "gloo" else counters.device  # gloo: host tensors
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=where)
+    tot = counters.clone().to(where)
+    if active:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    return float(t.item()), tot
+    return float(t.item()), tot.to(counters.device)
 
 
 def fence(device=None):
