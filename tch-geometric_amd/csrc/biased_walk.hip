@@ -17,6 +17,7 @@
 // everything else is order-free.  A walker whose candidate set is empty restarts from its start vertex, up to
 // retry_count times (:217, :273-276); timestamps written by abandoned attempts stay, as in the reference (:223-225
 // resets the vertices only).
+#include "row_stream.h"
 #include "tg_device.h"
 #include "tg_exp_table.h"
 #include "tg_host.h"
@@ -27,6 +28,7 @@ constexpr uint32_t TAG_RW_BIASED = 11u;
 constexpr int BW_WAVES = 4;
 constexpr int BW_SORT_LDS = 1024; // keys per wavefront sorted in LDS
 constexpr int BW_HIST = 128;      // >= TG_EXP_NEG_BITS_N
+constexpr int BW_P = 4;           // 64-edge chunks per load round of the row streamer (two rounds in flight)
 
 struct BwWaveLds {
     float chain[64];
@@ -87,25 +89,14 @@ __device__ __forceinline__ float wave_serial_prefix_f32(float v, float carry, fl
 
 struct Cand {
     bool ok;
-    int64_t v, ts;
     int32_t time32;
 };
 
-// candidate test of one edge (random_walk.rs:228-256)
-__device__ __forceinline__ Cand load_candidate(const int64_t *__restrict__ indices, const int64_t *__restrict__ node_ts,
-                                               const int64_t *__restrict__ edge_ts, int64_t ee, int64_t e, int64_t cur_ts) {
+// candidate test of one streamed edge (random_walk.rs:239-256)
+__device__ __forceinline__ Cand classify(bool valid, int64_t ts, int64_t cur_ts) {
     Cand c;
-    c.ok = false;
-    c.v = 0;
-    c.ts = 0;
-    c.time32 = 0;
-    if (ee < e) {
-        c.v = indices[ee];
-        c.ts = edge_ts[ee];
-        if (c.ts == -1) c.ts = node_ts[c.v];
-        c.ok = (c.ts == -1 || cur_ts == -1) || (cur_ts <= c.ts);
-        c.time32 = (int32_t)(uint32_t)(uint64_t)(c.ts == -1 ? cur_ts : c.ts);
-    }
+    c.ok = valid && ((ts == -1 || cur_ts == -1) || (cur_ts <= ts));
+    c.time32 = (int32_t)(uint32_t)(uint64_t)(ts == -1 ? cur_ts : ts);
     return c;
 }
 
@@ -151,27 +142,27 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
 
                 if (bias_now == 0) {
                     // ---- uniform: one pass; w_sum after candidate c is min(c + 1, 2^24) exactly in f32
-                    for (int64_t base = b; base < e; base += 64) {
-                        const Cand cd = load_candidate(indices, node_ts, edge_ts, base + lane, e, cur_ts);
+                    stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
+                        const Cand cd = classify(valid, ts, cur_ts);
                         const uint64_t mask = __ballot(cd.ok);
                         if (cd.ok) {
                             const uint32_t c = n_c + (uint32_t)__popcll(mask & lt_mask);
                             if (c == 0) {
-                                first_v = cd.v;
-                                first_t = cd.ts;
+                                first_v = v;
+                                first_t = ts;
                                 has_first = true;
                             } else {
                                 const float w_sum = (float)(c < 16777216u ? c + 1u : 16777216u);
                                 const float j = u32_to_f32_01(draw(ck, step_id, c, D1_WEIGHTED).w[0]) * w_sum + 0.0f;
                                 if (j < 1.0f) {
                                     best_rank = c;
-                                    best_v = cd.v;
-                                    best_t = cd.ts;
+                                    best_v = v;
+                                    best_t = ts;
                                 }
                             }
                         }
                         n_c += (uint32_t)__popcll(mask);
-                    }
+                    });
                 } else {
                     // ---- pass 1: count, first candidate, maximum exponent / sort keys
                     const int64_t deg = e - b;
@@ -183,14 +174,14 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                         break;
                     }
                     float mx = -__builtin_inff();
-                    for (int64_t base = b; base < e; base += 64) {
-                        const Cand cd = load_candidate(indices, node_ts, edge_ts, base + lane, e, cur_ts);
+                    stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
+                        const Cand cd = classify(valid, ts, cur_ts);
                         const uint64_t mask = __ballot(cd.ok);
                         if (cd.ok) {
                             const uint32_t c = n_c + (uint32_t)__popcll(mask & lt_mask);
                             if (c == 0) {
-                                first_v = cd.v;
-                                first_t = cd.ts;
+                                first_v = v;
+                                first_t = ts;
                                 has_first = true;
                             }
                             if (bias_now == 1) // descending time, ties by ascending position
@@ -199,7 +190,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                                 mx = fmaxf(mx, exp_delta(cd.time32, t32, forward));
                         }
                         n_c += (uint32_t)__popcll(mask);
-                    }
+                    });
                     if (n_c >= 2) {
                         float den;
                         if (bias_now == 1) {
@@ -215,13 +206,13 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                             for (int m = lane; m < BW_HIST; m += 64) lds.hist[m] = 0u;
                             wave_lds_handoff();
                             // ---- pass 2 (exponential): histogram of the integer exponents
-                            for (int64_t base = b; base < e; base += 64) {
-                                const Cand cd = load_candidate(indices, node_ts, edge_ts, base + lane, e, cur_ts);
+                            stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t, int64_t ts) {
+                                const Cand cd = classify(valid, ts, cur_ts);
                                 if (cd.ok) {
                                     const float m = mx - exp_delta(cd.time32, t32, forward);
                                     if (m < (float)TG_EXP_NEG_BITS_N) atomicAdd(&lds.hist[(int)m], 1u);
                                 }
-                            }
+                            });
                             wave_lds_handoff();
                             double acc = 0.0;
                             if (lane == 0) {
@@ -234,8 +225,8 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                         // ---- selection pass: weighted reservoir with one slot (sampling.rs:47-53)
                         float carry = 0.0f;
                         n_c = 0;
-                        for (int64_t base = b; base < e; base += 64) {
-                            const Cand cd = load_candidate(indices, node_ts, edge_ts, base + lane, e, cur_ts);
+                        stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
+                            const Cand cd = classify(valid, ts, cur_ts);
                             const uint64_t mask = __ballot(cd.ok);
                             const uint32_t c = n_c + (uint32_t)__popcll(mask & lt_mask);
                             float w = 0.0f;
@@ -258,13 +249,13 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                                     const float j = u32_to_f32_01(draw(ck, step_id, c, D1_WEIGHTED).w[0]) * w_sum + 0.0f;
                                     if (j < w) {
                                         best_rank = c;
-                                        best_v = cd.v;
-                                        best_t = cd.ts;
+                                        best_v = v;
+                                        best_t = ts;
                                     }
                                 }
                             }
                             n_c += (uint32_t)__popcll(mask);
-                        }
+                        });
                     }
                 }
                 if (__ballot(panic) != 0ull) {

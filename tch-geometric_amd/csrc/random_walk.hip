@@ -14,6 +14,7 @@
 //   reservoir (sampling.rs:17-22 with k = 1: candidate m >= 1 replaces with
 //   probability 1/m, candidate 1 always does) from one addressed draw per
 //   candidate.  HBM-bound on 16 B per inspected edge.
+#include "row_stream.h"
 #include "tg_device.h"
 #include "tg_host.h"
 
@@ -127,15 +128,7 @@ __global__ void rw_tempo_kernel(const int64_t *__restrict__ ptrs, const int64_t 
         int64_t best_rank = -1, best_v = -1, best_t = -1; // this lane's last reservoir hit
         int64_t first_v = -1, first_t = -1;               // candidate of rank 0 (held by one lane)
         bool has_first = false;
-        for (int64_t base = b; base < e; base += 64) {
-            const int64_t ee = base + lane;
-            const bool valid = ee < e;
-            int64_t v = 0, ts = 0;
-            if (valid) {
-                v = indices[ee];
-                ts = edge_ts[ee];
-                if (ts == -1) ts = node_ts[v]; // :121-125
-            }
+        stream_row<4>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
             const bool ok = valid && ((ts == -1 || it == -1) || (wlo <= ts && ts < whi)); // :129-138
             const uint64_t mask = __ballot(ok);
             if (ok) {
@@ -154,7 +147,7 @@ __global__ void rw_tempo_kernel(const int64_t *__restrict__ ptrs, const int64_t 
                 }
             }
             n_pass += (uint32_t)__popcll(mask);
-        }
+        });
         int64_t next, next_t;
         if (n_pass == 0) { // :144-148 restart from an earlier position of this walk
             const Draw d = draw(ck, step_id, 0u, D1_RESTART);

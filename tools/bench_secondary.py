@@ -21,7 +21,7 @@ g = _cabi.graph_view(ptrs, idx)
 n_walkers, L = 1 << 20, 80
 start = _cabi.seed_batches(0x57A27, 0, 1, n_walkers, n, dev)[0].contiguous()
 res = {}
-for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)):
+for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)) if os.environ.get("NODE2VEC", "1") == "1" else ():
     _cabi.random_walk(g, start, L, p, q, 0, 0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,4 +37,42 @@ for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)):
     alg = 32 * steps + 8 * n_walkers + 8 * (cells - steps)       # 32 B per executed step, 8 B per -1 cell
     res[name] = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3,
                  "algorithmic_GBps": alg / ms / 1e6, "frac_of_8TBps": alg / ms / 1e6 / 8000.0}
+# ---- temporal walks on the same graph: edge timestamps in [0, 100), start timestamps in [0, 50)
+gen = torch.Generator(device=dev)
+gen.manual_seed(3)
+ets = torch.randint(0, 100, (idx.numel(),), device=dev, generator=gen)
+nts = torch.full((n,), -1, dtype=torch.int64, device=dev)
+sts = torch.randint(0, 50, (n_walkers,), device=dev, generator=gen)
+max_deg = int((ptrs[1:] - ptrs[:-1]).max().item())
+Lt = 20
+
+
+def timed(fn, reps=2):
+    fn(0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(reps):
+        out = fn(r + 1)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, out
+
+
+if os.environ.get("TEMPORAL", "1") == "1":
+    ms, (w, t) = timed(lambda c: _cabi.tempo_random_walk(g, nts, ets, start, sts, Lt, (0, 30), 0, c))
+    steps = int((w[:, 1:] >= 0).sum().item())
+    deg = ptrs[1:] - ptrs[:-1]
+    src = w[:, :-1]
+    inspected = int(deg[src[src >= 0]].sum().item())         # every position but the last is expanded
+    res["tempo_random_walk_len20_window30"] = {"ms": ms, "steps": steps, "steps_per_s": steps / ms * 1e3,
+                                               "inspected_edges": inspected,
+                                               "algorithmic_GBps": 16 * inspected / ms / 1e6,  # index + edge timestamp
+                                               "frac_of_8TBps": 16 * inspected / ms / 1e6 / 8000.0}
+    for bias in os.environ.get("BIASES", "uniform,exponential,linear").split(","):
+        ms, (w, t, st) = timed(lambda c: _cabi.biased_tempo_random_walk(g, nts, ets, start, sts, Lt, bias, True, 2, 0, c,
+                                                                      max_degree=max_deg))
+        steps = int((w[:, 1:] >= 0).sum().item())
+        res["biased_tempo_random_walk_len20_%s" % bias] = {"ms": ms, "steps": steps, "steps_per_s": steps / ms * 1e3,
+                                                          "status": int(st.item())}
 print(json.dumps({"config": "random_walk walk_length=80, %d starts, RMAT-%d CSR" % (n_walkers, scale), **res}))
