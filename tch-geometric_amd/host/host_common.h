@@ -93,6 +93,17 @@ inline Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
 inline Tensor back(const Tensor &t, const c10::Device &out_dev) { return t.device() == out_dev ? t : t.to(out_dev); }
 inline at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions().dtype(at::kLong).device(dev); }
 
+// Blocking read-backs run WITHOUT the GIL (libtorch does not need it), so DataLoader-style worker threads, each on its
+// own HIP stream, overlap their latency-bound calls.  The reference holds the GIL throughout (SURVEY 8(b) Threading).
+template <typename T> inline T read_scalar(const Tensor &t) {
+    py::gil_scoped_release nogil;
+    return t.item<T>();
+}
+inline Tensor to_host(const Tensor &t) {
+    py::gil_scoped_release nogil;
+    return t.cpu();
+}
+
 // Collects range checks of node-id inputs on the device; `verify()` reads the flag (one tiny copy) and raises.
 // The reference panics (index out of bounds) on such inputs; a device kernel would fault instead.
 struct RangeCheck {
@@ -105,7 +116,7 @@ struct RangeCheck {
                                 stream_of(dev)));
     }
     void verify(const char *what) const {
-        if (flag.item<int32_t>() != 0)
+        if (read_scalar<int32_t>(flag) != 0)
             throw py::index_error(std::string(what) + ": a node id is outside the graph (the reference panics with an "
                                                       "index out of bounds here)");
     }

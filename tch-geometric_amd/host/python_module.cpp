@@ -141,8 +141,8 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
             Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
             check_rc(tg_ns_hop_weighted(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
                                         ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
-            total = offsets[m].item<int64_t>();
-            if (status.item<int32_t>() & 2) // sampling.rs:49: gen_range over an empty float range panics
+            total = read_scalar<int64_t>(offsets[m]);
+            if (read_scalar<int32_t>(status) & 2) // sampling.rs:49: gen_range over an empty float range panics
                 throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
         } else
         for (;;) { // the frontier's columns need sum(ceil(deg/512)) groups; grow the workspace if the guess was low
@@ -152,8 +152,8 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
             Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
             check_rc(tg_ns_hop_scan(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
                                     ws.data_ptr<int64_t>(), ws_bytes, group_cap, stream_of(dev)));
-            total = offsets[m].item<int64_t>(); // the hop's size read-back
-            if (status.item<int32_t>() == 0) break;
+            total = read_scalar<int64_t>(offsets[m]); // the hop's size read-back
+            if (read_scalar<int32_t>(status) == 0) break;
             group_cap *= 8;
         }
         if (total > 0) {
@@ -226,7 +226,7 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
     out.cap_edges = r.rows.numel();
     check_rc(tg_ns_homo_batched(&g, seeds.numel() ? seeds.data_ptr<int64_t>() : nullptr, 1, seeds.numel(),
                                 fanout.data(), H, &cfg, &rng, &out, stream_of(dev)));
-    Tensor c = counts.cpu(), l = lo.cpu(); // the only synchronisation of the call
+    Tensor c = to_host(counts), l = to_host(lo); // the only synchronisation of the call
     r.n_samples = c[0].item<int64_t>();
     r.n_edges = c[1].item<int64_t>();
     if (r.n_samples < 0) // sampling.rs:49: gen_range over an empty float range panics in the reference
@@ -520,7 +520,7 @@ std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, cons
     // the linear bias sorts a row's candidates: rows above the LDS capacity need a slab sized by the largest row
     int64_t max_degree = 0;
     if (bias == TG_BIAS_LINEAR && ptrs.numel() > 1)
-        max_degree = (ptrs.slice(0, 1) - ptrs.slice(0, 0, ptrs.numel() - 1)).max().item<int64_t>();
+        max_degree = read_scalar<int64_t>((ptrs.slice(0, 1) - ptrs.slice(0, 0, ptrs.numel() - 1)).max());
     int64_t ws_bytes = 0;
     check_rc(tg_biased_walk_workspace_bytes(st.numel(), max_degree, bias, &ws_bytes));
     Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
@@ -536,7 +536,7 @@ std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, cons
                                          forward ? 1 : 0, retry_count, max_degree, &rng, walks.data_ptr<int64_t>(),
                                          wts.data_ptr<int64_t>(), status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(),
                                          ws_bytes, stream_of(dev)));
-    const int32_t flags = status.item<int32_t>();
+    const int32_t flags = read_scalar<int32_t>(status);
     if (flags & 2)
         throw std::runtime_error("cannot sample empty range: every bias weight so far underflowed to zero (the "
                                  "reference panics here, utils/sampling.rs:49)");

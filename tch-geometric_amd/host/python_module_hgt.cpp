@@ -145,7 +145,7 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
     Tensor ws = at::empty({ws_bytes / 8 + 2}, i64(dev));
     const tg_rng rng = next_rng();
     check_rc(tg_hgt_sample(&pb, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
-    Tensor c = counts.cpu(); // the call's only synchronisation
+    Tensor c = to_host(counts); // the call's only synchronisation
     if ((c[T + R].item<int64_t>() & 0xffffffff) != 0)
         throw std::runtime_error("hgt_sampling: num_samples has no entry for a node type that owns a budget, or a "
                                  "weight sum was not positive (the reference panics here)");

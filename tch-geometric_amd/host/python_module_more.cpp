@@ -74,7 +74,7 @@ NegRun run_neg(const c10::Device &dev, int T, const std::vector<int32_t> &rel_sr
     out.panic = reinterpret_cast<int32_t *>(counts.data_ptr<int64_t>() + T + R);
     const tg_rng rng = next_rng();
     check_rc(tg_neg_sample(&pb, &rng, &out, ws.data_ptr<int64_t>(), stream_of(dev)));
-    Tensor c = counts.cpu(); // the call's only synchronisation
+    Tensor c = to_host(counts); // the call's only synchronisation
     if ((c[T + R].item<int64_t>() & 0xffffffff) != 0)
         throw std::runtime_error("inbound negative sampling indexed a CSR row out of range (the reference panics here, "
                                  "negative_sampling.rs:113)");

@@ -70,4 +70,61 @@ def filtered():
 dt, out = timeit(filtered)
 res["neighbor_sampling_homogenous_temporal_single_call"] = {"ms_per_call": dt * 1e3,
                                                             "sampled_edges_per_call": int(out[1].numel())}
+# ---- worker threads, each on its own HIP stream (the blocking size read-backs release the GIL): throughput of the
+# latency-bound per-call operators when a DataLoader keeps several mini-batches in flight
+import threading  # noqa: E402
+
+
+def threaded(make_call, n_threads, per_thread=20):
+    seeds_per = [[_cabi.seed_batches(0xBA7C4, 1000 + t * per_thread + j, 1, 1024, 1 << 23, dev)[0].contiguous()
+                  for j in range(per_thread + 1)] for t in range(n_threads)]
+    torch.cuda.synchronize()
+    done = [0] * n_threads
+    barrier = threading.Barrier(n_threads + 1)
+
+    def work(t):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            make_call(seeds_per[t][0])          # warm-up
+            st.synchronize()
+            barrier.wait()
+            for j in range(per_thread):
+                out = make_call(seeds_per[t][j + 1])
+                done[t] += out
+            st.synchronize()
+        barrier.wait()
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    barrier.wait()
+    dt = time.perf_counter() - t0
+    for th in ths:
+        th.join()
+    return dt, sum(done), n_threads * per_thread
+
+
+def het_call(sd):
+    o = tg.neighbor_sampling_heterogenous(node_types, edge_types, P, I, {"A": sd}, nn, 2)
+    return sum(int(v.numel()) for v in o[1].values())
+
+
+def hgt_call(sd):
+    o = tg.hgt_sampling(node_types, edge_types, P, I, None, {"A": sd}, None, ns, 2)
+    return sum(int(v.numel()) for v in o[0].values()) + sum(int(v.numel()) for v in o[2].values())
+
+
+def homo_call(sd):
+    return int(tg.neighbor_sampling_homogenous(P["A__e0__A"], I["A__e0__A"], sd, [15, 10])[1].numel())
+
+
+res["threads"] = {}
+for name, fn in (("neighbor_sampling_heterogenous", het_call), ("hgt_sampling", hgt_call),
+                 ("neighbor_sampling_homogenous", homo_call)):
+    res["threads"][name] = {}
+    for nt in (1, 4, 8, 16):
+        dt, units, calls_done = threaded(fn, nt)
+        res["threads"][name]["%d_threads" % nt] = {"calls_per_s": calls_done / dt, "units_per_s": units / dt}
 print(json.dumps(res))
