@@ -181,6 +181,44 @@ TG_API int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, const tg
                               const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
                               int64_t workspace_bytes, void *stream);
 
+/* neighbor_sampling_heterogenous (src/algo/neighbor_sampling.rs:233-356; binding python.rs:275-395) in ONE launch for
+ * n_batches independent seed batches, unweighted samplers without filter (the surface's default).  Node types and
+ * relations are indexed in the caller's `node_types` / `edge_types` order, which is also the order relations are
+ * visited in every hop (the reference iterates a HashMap there).  Host arrays describe the problem; the pointers
+ * inside are device pointers.  Batch b owns samples[t][b*cap_nodes[t] ..], rows/cols/edge_index[r][b*cap_edges[r] ..],
+ * layer_offsets[((b*n_rels + r)*n_hops + h)*3 ..] = (len(samples[src]), len(edges r), len(samples[dst])) when hop h
+ * reaches relation r (:314-315), counts[b*(n_types+n_rels) ..] = {len(samples[t])..., len(edges r)...}.
+ * Draw address: tag TG_TAG_NS_HETERO | r << 8, id = slot of the frontier vertex in its type's list, call id
+ * rng.call_id + b.  Weighted / filtered heterogeneous sampling is driven per (hop, relation) through
+ * tg_ns_homo_batched / tg_ns_hop_scan / tg_ns_hop_weighted with the same addresses. */
+#define TG_HET_MAX_TYPES 8
+#define TG_HET_MAX_RELS 16
+typedef struct {
+    int32_t n_types, n_rels, n_hops;
+    int32_t sampler;               /* TG_SAMPLER_UNIFORM or TG_SAMPLER_UNIFORM_REPL */
+    const int32_t *rel_src;        /* [n_rels] node type sampled FROM (CSC rows) */
+    const int32_t *rel_dst;        /* [n_rels] node type whose frontier is expanded (CSC columns) */
+    const tg_graph *graphs;        /* [n_rels] CSC per relation */
+    const int64_t *fanout;         /* [n_rels * n_hops]; 0 = relation not sampled in that hop */
+    const int64_t *const *inputs;  /* [n_types] device [n_batches * n_inputs[t]], NULL where n_inputs[t] == 0 */
+    const int64_t *n_inputs;       /* [n_types] seeds per batch */
+} tg_het_problem;
+
+typedef struct {
+    int64_t *const *samples;    /* [n_types] device slabs [n_batches * cap_nodes[t]] */
+    const int64_t *cap_nodes;   /* [n_types] >= tg_ns_hetero_capacity() */
+    int64_t *const *rows;       /* [n_rels] device slabs [n_batches * cap_edges[r]] */
+    int64_t *const *cols;
+    int64_t *const *edge_index;
+    const int64_t *cap_edges;   /* [n_rels] */
+    int64_t *layer_offsets;     /* device [n_batches * n_rels * n_hops * 3] */
+    int64_t *counts;            /* device [n_batches * (n_types + n_rels)] */
+} tg_het_out;
+
+TG_API int tg_ns_hetero_capacity(const tg_het_problem *problem, int64_t *cap_nodes, int64_t *cap_edges);
+TG_API int tg_ns_hetero_batched(const tg_het_problem *problem, int64_t n_batches, const tg_rng *rng, const tg_het_out *out,
+                                void *stream);
+
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */
 TG_API int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,

@@ -385,6 +385,91 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         rc.verify("neighbor_sampling_heterogenous inputs");
     }
 
+    // ---- default samplers without a filter: all hops and relations in ONE launch (tg_ns_hetero_batched), one read-back
+    bool fused = !has_state && s.kind != TG_SAMPLER_WEIGHTED && T <= TG_HET_MAX_TYPES && rels.size() <= TG_HET_MAX_RELS &&
+                 num_hops >= 0 && num_hops <= TG_MAX_HOPS;
+    for (const Rel &r : rels)
+        for (int64_t h = 0; fused && r.active && h < num_hops; ++h) fused = r.fanout[(size_t)h] <= TG_MAX_FANOUT;
+    if (fused) {
+        const int R = (int)rels.size(), H = (int)num_hops;
+        std::vector<int32_t> rel_src((size_t)std::max(R, 1)), rel_dst((size_t)std::max(R, 1));
+        std::vector<tg_graph> graphs((size_t)std::max(R, 1));
+        std::vector<int64_t> fan((size_t)std::max(R * H, 1), 0), n_in(T, 0), cap_n(T, 0), cap_e((size_t)std::max(R, 1), 0);
+        std::vector<const int64_t *> in_ptr(T, nullptr);
+        for (int r = 0; r < R; ++r) {
+            rel_src[(size_t)r] = (int32_t)rels[(size_t)r].src;
+            rel_dst[(size_t)r] = (int32_t)rels[(size_t)r].dst;
+            tg_graph g{};
+            g.ptrs = rels[(size_t)r].ptrs.data_ptr<int64_t>();
+            g.indices = rels[(size_t)r].idx.numel() ? rels[(size_t)r].idx.data_ptr<int64_t>() : nullptr;
+            g.n_major = rels[(size_t)r].ptrs.numel() - 1;
+            g.n_edges = rels[(size_t)r].idx.numel();
+            graphs[(size_t)r] = g;
+            for (int h = 0; h < H && rels[(size_t)r].active; ++h) fan[(size_t)(r * H + h)] = rels[(size_t)r].fanout[(size_t)h];
+        }
+        for (size_t t = 0; t < T; ++t) {
+            n_in[t] = frontier[t].numel();
+            in_ptr[t] = n_in[t] ? frontier[t].data_ptr<int64_t>() : nullptr;
+        }
+        tg_het_problem pb{};
+        pb.n_types = (int32_t)T;
+        pb.n_rels = R;
+        pb.n_hops = H;
+        pb.sampler = s.kind;
+        pb.rel_src = rel_src.data();
+        pb.rel_dst = rel_dst.data();
+        pb.graphs = graphs.data();
+        pb.fanout = fan.data();
+        pb.inputs = in_ptr.data();
+        pb.n_inputs = n_in.data();
+        check_rc(tg_ns_hetero_capacity(&pb, cap_n.data(), cap_e.data()));
+        std::vector<Tensor> S(T), RW((size_t)R), CL((size_t)R), EI((size_t)R);
+        std::vector<int64_t *> s_ptr(T), r_ptr((size_t)std::max(R, 1)), c_ptr((size_t)std::max(R, 1)), e_ptr((size_t)std::max(R, 1));
+        for (size_t t = 0; t < T; ++t) {
+            S[t] = at::empty({std::max<int64_t>(cap_n[t], 1)}, i64(dev));
+            s_ptr[t] = S[t].data_ptr<int64_t>();
+        }
+        for (int r = 0; r < R; ++r) {
+            const int64_t c = std::max<int64_t>(cap_e[(size_t)r], 1);
+            RW[(size_t)r] = at::empty({c}, i64(dev));
+            CL[(size_t)r] = at::empty({c}, i64(dev));
+            EI[(size_t)r] = at::empty({c}, i64(dev));
+            r_ptr[(size_t)r] = RW[(size_t)r].data_ptr<int64_t>();
+            c_ptr[(size_t)r] = CL[(size_t)r].data_ptr<int64_t>();
+            e_ptr[(size_t)r] = EI[(size_t)r].data_ptr<int64_t>();
+        }
+        // counts | layer offsets in one tensor: one read-back for the call
+        Tensor meta = at::zeros({(int64_t)T + R + (int64_t)std::max(R * H, 1) * 3}, i64(dev));
+        tg_het_out out{};
+        out.samples = s_ptr.data();
+        out.cap_nodes = cap_n.data();
+        out.rows = r_ptr.data();
+        out.cols = c_ptr.data();
+        out.edge_index = e_ptr.data();
+        out.cap_edges = cap_e.data();
+        out.counts = meta.data_ptr<int64_t>();
+        out.layer_offsets = meta.data_ptr<int64_t>() + T + R;
+        check_rc(tg_ns_hetero_batched(&pb, 1, &rng, &out, stream_of(dev)));
+        Tensor m = to_host(meta); // the call's only synchronisation
+        const int64_t *mh = m.data_ptr<int64_t>();
+        py::dict samples, rows, cols, eidx, los;
+        for (size_t t = 0; t < T; ++t) samples[py::str(node_types[t])] = back(S[t].narrow(0, 0, mh[t]), out_dev);
+        for (int r = 0; r < R; ++r) {
+            const Rel &rl = rels[(size_t)r];
+            const int64_t ne = mh[T + (size_t)r];
+            rows[py::str(rl.key)] = back(RW[(size_t)r].narrow(0, 0, ne), out_dev);
+            cols[py::str(rl.key)] = back(CL[(size_t)r].narrow(0, 0, ne), out_dev);
+            eidx[py::str(rl.key)] = back(EI[(size_t)r].narrow(0, 0, ne), out_dev);
+            std::vector<std::tuple<int64_t, int64_t, int64_t>> lo;
+            for (int h = 0; h < H && rl.active; ++h) {
+                const int64_t *q = mh + T + R + ((size_t)r * H + (size_t)h) * 3;
+                lo.emplace_back(q[0], q[1], q[2]);
+            }
+            los[py::str(rl.key)] = lo;
+        }
+        return py::make_tuple(samples, rows, cols, eidx, los);
+    }
+
     for (int64_t ell = 0; ell < num_hops; ++ell) { // :292
         for (size_t t = 0; t < T; ++t) {
             new_chunks[t].clear();

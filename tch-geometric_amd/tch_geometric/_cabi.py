@@ -22,7 +22,8 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
            "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows",
-           "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk"]
+           "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
+           "tg_ns_hetero_batched"]
 
 
 class TgGraph(C.Structure):
@@ -176,6 +177,60 @@ def tempo_random_walk(graph, node_ts, edge_ts, start, start_ts, walk_length, win
                                    C.c_int64(window[1]), C.byref(rng), ptr(walks), ptr(wts),
                                    stream_ptr(start.device)))
     return walks, wts
+
+
+class TgHetProblem(C.Structure):
+    _fields_ = [("n_types", C.c_int32), ("n_rels", C.c_int32), ("n_hops", C.c_int32), ("sampler", C.c_int32),
+                ("rel_src", C.POINTER(C.c_int32)), ("rel_dst", C.POINTER(C.c_int32)), ("graphs", C.POINTER(TgGraph)),
+                ("fanout", C.POINTER(C.c_int64)), ("inputs", C.POINTER(C.c_void_p)), ("n_inputs", C.POINTER(C.c_int64))]
+
+
+class TgHetOut(C.Structure):
+    _fields_ = [("samples", C.POINTER(C.c_void_p)), ("cap_nodes", C.POINTER(C.c_int64)),
+                ("rows", C.POINTER(C.c_void_p)), ("cols", C.POINTER(C.c_void_p)), ("edge_index", C.POINTER(C.c_void_p)),
+                ("cap_edges", C.POINTER(C.c_int64)), ("layer_offsets", C.c_void_p), ("counts", C.c_void_p)]
+
+
+class NsHeteroBatched:
+    """Problem description + output slabs of tg_ns_hetero_batched.  rels: list of (src type index, dst type index,
+    ptrs, indices, [fanout per hop]); inputs: list over node types of [n_batches, n_inputs] tensors or None."""
+
+    def __init__(self, n_types, rels, inputs, n_hops, n_batches, device, sampler=SAMPLER_UNIFORM):
+        T, R = n_types, len(rels)
+        self.T, self.R, self.H, self.nb, self.dev = T, R, n_hops, n_batches, device
+        self._keep = [rels, inputs]
+        self.rel_src = (C.c_int32 * max(R, 1))(*[r[0] for r in rels])
+        self.rel_dst = (C.c_int32 * max(R, 1))(*[r[1] for r in rels])
+        self.graphs = (TgGraph * max(R, 1))()
+        for i, r in enumerate(rels):
+            self.graphs[i] = graph_view(r[2], r[3])
+        flat = [int(k) for r in rels for k in r[4]]
+        self.fanout = (C.c_int64 * max(len(flat), 1))(*flat)
+        self.n_inputs = (C.c_int64 * T)(*[0 if x is None else int(x.shape[1]) for x in inputs])
+        self.inputs = (C.c_void_p * T)(*[None if x is None else x.data_ptr() for x in inputs])
+        self.problem = TgHetProblem(T, R, n_hops, sampler, self.rel_src, self.rel_dst, self.graphs, self.fanout,
+                                    self.inputs, self.n_inputs)
+        self.cap_nodes, self.cap_edges = (C.c_int64 * T)(), (C.c_int64 * max(R, 1))()
+        check(lib.tg_ns_hetero_capacity(C.byref(self.problem), self.cap_nodes, self.cap_edges))
+        o = dict(dtype=torch.int64, device=device)
+        self.samples = [torch.empty((n_batches, max(self.cap_nodes[t], 1)), **o) for t in range(T)]
+        self.rows = [torch.empty((n_batches, max(self.cap_edges[r], 1)), **o) for r in range(R)]
+        self.cols = [torch.empty((n_batches, max(self.cap_edges[r], 1)), **o) for r in range(R)]
+        self.edge_index = [torch.empty((n_batches, max(self.cap_edges[r], 1)), **o) for r in range(R)]
+        self.layer_offsets = torch.zeros((n_batches, max(R, 1), max(n_hops, 1), 3), **o)
+        self.counts = torch.zeros((n_batches, T + R), **o)
+        # the slabs are allocated with at least one column; tell the library their true pitch
+        self.cap_nodes_alloc = (C.c_int64 * T)(*[max(self.cap_nodes[t], 1) for t in range(T)])
+        self.cap_edges_alloc = (C.c_int64 * max(R, 1))(*[max(self.cap_edges[r], 1) for r in range(R)])
+        vp = lambda ts: (C.c_void_p * max(len(ts), 1))(*[t.data_ptr() for t in ts])
+        self._ptrs = [vp(self.samples), vp(self.rows), vp(self.cols), vp(self.edge_index)]
+        self.out = TgHetOut(self._ptrs[0], self.cap_nodes_alloc, self._ptrs[1], self._ptrs[2], self._ptrs[3],
+                            self.cap_edges_alloc, self.layer_offsets.data_ptr(), self.counts.data_ptr())
+
+    def run(self, seed, call_id):
+        rng = TgRng(seed, call_id)
+        check(lib.tg_ns_hetero_batched(C.byref(self.problem), C.c_int64(self.nb), C.byref(rng), C.byref(self.out),
+                                       stream_ptr(self.dev)))
 
 
 BIAS = {"uniform": 0, "linear": 1, "exponential": 2}

@@ -70,6 +70,25 @@ def filtered():
 dt, out = timeit(filtered)
 res["neighbor_sampling_homogenous_temporal_single_call"] = {"ms_per_call": dt * 1e3,
                                                             "sampled_edges_per_call": int(out[1].numel())}
+# ---- the batched C ABI (tg_ns_hetero_batched): many seed batches of type A in one launch, all hops and relations fused
+tix = {t: i for i, t in enumerate(node_types)}
+rels_c = [(tix[s_], tix[d_], P["%s__%s__%s" % (s_, n_, d_)], I["%s__%s__%s" % (s_, n_, d_)], [15, 10]) for (s_, n_, d_) in edge_types]
+res["tg_ns_hetero_batched"] = {}
+for nbatch in (1, 64, 512):
+    sd = _cabi.seed_batches(0xBA7C4, 5000, nbatch, 1024, 1 << 23, dev)
+    hb = _cabi.NsHeteroBatched(3, rels_c, [sd, None, None], 2, nbatch, dev)
+    hb.run(0, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for rep in range(5):
+        hb.run(0, rep * nbatch)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    ne = int(hb.counts[:, 3:].sum().item())
+    res["tg_ns_hetero_batched"]["%d_batches" % nbatch] = {"ms_per_launch": ms, "sampled_edges": ne, "edges_per_s": ne / ms * 1e3}
+    del hb
 # ---- worker threads, each on its own HIP stream (the blocking size read-backs release the GIL): throughput of the
 # latency-bound per-call operators when a DataLoader keeps several mini-batches in flight
 import threading  # noqa: E402
