@@ -371,6 +371,13 @@ TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out
 TG_API int tg_gather_rows(const void *src, int64_t n_src_rows, int64_t row_bytes, int64_t src_stride_bytes,
                           const int64_t *index, int64_t n, void *dst, int32_t *status, void *stream);
 
+/* Per-batch slabs of tg_ns_homo_batched -> flat batch-major arrays: batch b's samples to flat_samples[node_off[b] ..],
+ * its rows / cols / edge pointers to flat_*[edge_off[b] ..] (offsets: device arrays, exclusive prefixes of the batch
+ * counts).  What a loader hands on to tg_gather_rows (tch_geometric/loader.py). */
+TG_API int tg_ns_homo_compact(const tg_ns_out *out, int64_t n_batches, const int64_t *node_off, const int64_t *edge_off,
+                              int64_t *flat_samples, int64_t *flat_rows, int64_t *flat_cols, int64_t *flat_edge_index,
+                              void *stream);
+
 /* Harness calibration (not part of the sampling path): n_threads lanes each issue per_thread
  * independent random 8-byte loads from table[0..n_table); sink: [n_threads]. */
 TG_API int tg_probe_random_gather(const int64_t *table, int64_t n_table, int64_t n_threads, int64_t per_thread,

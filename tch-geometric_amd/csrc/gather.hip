@@ -89,7 +89,39 @@ static int launch_gather(const void *src, int64_t n_src_rows, int64_t row_bytes,
     return TG_OK;
 }
 
+// Per-batch output slabs of tg_ns_homo_batched -> flat, batch-major arrays (what a loader hands on): batch b's
+// samples go to flat_samples[node_off[b] ..], its rows / cols / edge pointers to flat_*[edge_off[b] ..].
+__global__ void ns_compact_kernel(tg_ns_out o, const int64_t *__restrict__ node_off, const int64_t *__restrict__ edge_off,
+                                  int64_t *flat_samples, int64_t *flat_rows, int64_t *flat_cols, int64_t *flat_eidx) {
+    const int64_t b = blockIdx.x;
+    const int64_t n_nodes = o.counts[b * 2], n_edges = o.counts[b * 2 + 1];
+    const int64_t step = (int64_t)gridDim.y * blockDim.x, first = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    const int64_t *s = o.samples + b * o.cap_nodes;
+    const int64_t *r = o.rows + b * o.cap_edges, *c = o.cols + b * o.cap_edges, *e = o.edge_index + b * o.cap_edges;
+    const int64_t no = node_off[b], eo = edge_off[b];
+    for (int64_t i = first; i < n_nodes; i += step) flat_samples[no + i] = s[i];
+    for (int64_t i = first; i < n_edges; i += step) {
+        flat_rows[eo + i] = r[i];
+        flat_cols[eo + i] = c[i];
+        flat_eidx[eo + i] = e[i];
+    }
+}
+
 } // namespace tg
+
+extern "C" int tg_ns_homo_compact(const tg_ns_out *out, int64_t n_batches, const int64_t *node_off, const int64_t *edge_off,
+                                  int64_t *flat_samples, int64_t *flat_rows, int64_t *flat_cols, int64_t *flat_edge_index,
+                                  void *stream) {
+    TG_REQUIRE(out && n_batches >= 0 && n_batches <= 0x7fffffff, "tg_ns_homo_compact: bad arguments");
+    if (n_batches == 0) return TG_OK;
+    TG_REQUIRE(out->samples && out->counts && node_off && edge_off && flat_samples, "tg_ns_homo_compact: null buffers");
+    TG_REQUIRE(out->cap_edges == 0 || (out->rows && out->cols && out->edge_index && flat_rows && flat_cols && flat_edge_index),
+               "tg_ns_homo_compact: null edge buffers");
+    hipLaunchKernelGGL(tg::ns_compact_kernel, dim3((unsigned)n_batches, 8), dim3(256), 0, (hipStream_t)stream, *out, node_off,
+                       edge_off, flat_samples, flat_rows, flat_cols, flat_edge_index);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
 
 extern "C" int tg_gather_rows(const void *src, int64_t n_src_rows, int64_t row_bytes, int64_t src_stride_bytes,
                               const int64_t *index, int64_t n, void *dst, int32_t *status, void *stream) {

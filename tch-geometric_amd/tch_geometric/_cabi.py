@@ -23,7 +23,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
            "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows",
            "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
-           "tg_ns_hetero_batched"]
+           "tg_ns_hetero_batched", "tg_ns_homo_compact"]
 
 
 class TgGraph(C.Structure):
@@ -301,6 +301,23 @@ def coo_to_csx(row, col, size0, size1, csc):
                             C.c_int64(size1), C.c_int32(int(csc)), ptr(ptrs), ptr(indices), ptr(perm), ptr(ws),
                             C.c_int64(nbytes.value), stream_ptr(dev)))
     return ptrs, indices, perm
+
+
+def ns_homo_compact(out, n_batches, counts_host):
+    """Flat batch-major (samples, rows, cols, edge_index) of the first n_batches of an NsBatchedOut; counts_host: the
+    [n_batches, 2] counts already read back (sizes the flat arrays)."""
+    dev = out.samples.device
+    total_n, total_e = int(counts_host[:, 0].sum()), int(counts_host[:, 1].sum())
+    c = out.counts[:n_batches]
+    off = torch.zeros((2, n_batches + 1), dtype=torch.int64, device=dev)
+    off[:, 1:] = torch.cumsum(c.t(), dim=1)
+    o = dict(dtype=torch.int64, device=dev)
+    fs, fr = torch.empty(total_n, **o), torch.empty(total_e, **o)
+    fc, fe = torch.empty(total_e, **o), torch.empty(total_e, **o)
+    so = out.struct()
+    check(lib.tg_ns_homo_compact(C.byref(so), C.c_int64(n_batches), ptr(off[0]), ptr(off[1]), ptr(fs), ptr(fr), ptr(fc),
+                                 ptr(fe), stream_ptr(dev)))
+    return fs, fr, fc, fe
 
 
 def gather_rows(src, index, status=None):

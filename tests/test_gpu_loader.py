@@ -1,0 +1,59 @@
+"""NeighborLoader: every mini-batch equals the oracle's neighbor_sampling_homogenous for its (seed, call id), whatever
+the prefetch depth, and carries the right attribute rows."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from helpers import load_karate
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _graph(n=500, e=6000, seed=1):
+    from tch_geometric.transforms import Graph
+    rs = np.random.default_rng(seed)
+    ei = np.stack([rs.integers(0, n, e), rs.integers(0, n, e)]).astype(np.int64)
+    x = rs.standard_normal((n, 12)).astype(np.float32)
+    y = rs.integers(0, 7, n)
+    ea = rs.standard_normal((e, 2)).astype(np.float32)
+    g = Graph(edge_index=torch.from_numpy(ei).to(DEV), num_nodes=n, x=torch.from_numpy(x).to(DEV),
+              y=torch.from_numpy(y).to(DEV), edge_attr=torch.from_numpy(ea).to(DEV))
+    return g, ei, x, y, ea
+
+
+@pytest.mark.parametrize("prefetch", [1, 3, 64])
+@pytest.mark.parametrize("replace", [False, True])
+def test_batches_equal_oracle_and_carry_attributes(prefetch, replace):
+    from tch_geometric.loader import NeighborLoader
+    g, ei, x, y, ea = _graph()
+    ptrs, idx, perm = orc.to_csc(ei, 500)
+    loader = NeighborLoader(g, [5, 4], batch_size=64, prefetch=prefetch, replace=replace, seed=9, call_id0=100)
+    assert len(loader) == 8                                   # 500 seeds: 7 full batches + a ragged one
+    seen = 0
+    for j, b in enumerate(loader):
+        seeds = np.arange(j * 64, min((j + 1) * 64, 500))
+        o = orc.ns_homo(ptrs, idx, seeds, [5, 4], orc.rng_philox(9, 100 + j), sampler=1 if replace else 0)
+        s = b.n_id.cpu().numpy()
+        assert b.call_id == 100 + j and b.batch_size == len(seeds)
+        assert np.array_equal(s, o[0]) and np.array_equal(b.edge_index.cpu().numpy(), np.stack([o[1], o[2]]))
+        assert np.array_equal(b.e_id.cpu().numpy(), perm[o[3]]) and b.layer_offsets == o[4]
+        assert np.array_equal(b.x.cpu().numpy(), x[s]) and np.array_equal(b.y.cpu().numpy(), y[s])
+        assert np.array_equal(b.edge_attr.cpu().numpy(), ea[perm[o[3]]])
+        seen += 1
+    assert seen == 8
+    assert sum(1 for _ in NeighborLoader(g, [5, 4], batch_size=64, prefetch=prefetch, drop_last=True)) == 7
+
+
+def test_input_nodes_and_shuffle():
+    from tch_geometric.loader import NeighborLoader
+    g, ei, x, y, ea = _graph(seed=2)
+    nodes = torch.tensor([5, 7, 7, 400, 3, 9, 11, 2, 450, 1])
+    plain = [b.n_id[:b.batch_size].cpu() for b in NeighborLoader(g, [3], input_nodes=nodes, batch_size=4, prefetch=2)]
+    assert torch.equal(torch.cat(plain), nodes)
+    sh = NeighborLoader(g, [3], input_nodes=nodes, batch_size=4, prefetch=2, shuffle=True, seed=3)
+    e1 = torch.cat([b.n_id[:b.batch_size].cpu() for b in sh])
+    e2 = torch.cat([b.n_id[:b.batch_size].cpu() for b in sh])
+    assert sorted(e1.tolist()) == sorted(nodes.tolist()) == sorted(e2.tolist())
+    assert not torch.equal(e1, e2) or not torch.equal(e1, nodes)   # epochs reshuffle
