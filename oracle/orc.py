@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libtg_oracle.so")
+# ORC_LIB=asan selects the AddressSanitizer/UBSan build (`make -C oracle asan`; run the CPU tests with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0)
+_LIB_PATH = os.path.join(_HERE, "_build", "libtg_oracle_asan.so" if os.environ.get("ORC_LIB") == "asan" else "libtg_oracle.so")
 
 RNG_REF, RNG_PHILOX = 0, 1
 RES_TICKETS, RES_LITERAL, RES_AUTO = 0, 1, -1

@@ -60,3 +60,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(base, f), errors="ignore").read()
                 assert "import orc" not in src and "oracle/" not in src and "tg_oracle" not in src, f
+
+
+def test_transform_helpers_without_a_gpu():
+    """attribute classification and containers of tch_geometric.transforms are plain host logic"""
+    import torch
+    from tch_geometric import transforms as tr
+    assert tr.rel_key(("a", "to", "b")) == "a__to__b"
+    n, e = 5, 7
+    assert tr._attr_kind("x", torch.zeros(n, 3), n, e) == "node"
+    assert tr._attr_kind("edge_attr", torch.zeros(e, 2), n, e) == "edge"
+    assert tr._attr_kind("edge_index", torch.zeros(2, e), n, e) is None
+    assert tr._attr_kind("timestamps", torch.zeros(n), n, n) == "edge"       # N == E: the name decides
+    assert tr._attr_kind("y", torch.zeros(n), n, n) == "node"
+    assert tr._attr_kind("other", torch.zeros(3), n, e) is None and tr._attr_kind("s", torch.tensor(1.0), n, e) is None
+    g = tr.HeteroGraph()
+    g["a"].x = torch.zeros(4, 2)
+    g[("a", "to", "b")].edge_index = torch.zeros(2, 3, dtype=torch.int64)
+    g["b"].num_nodes = 9
+    assert g.node_types == ["a", "b"] and g.edge_types == [("a", "to", "b")]
+    assert tr._num_nodes(g["a"]) == 4 and tr._num_nodes(g["b"]) == 9 and tr._is_hetero(g) and not tr._is_hetero(g["a"])
+    import pytest
+    with pytest.raises(ValueError):                                           # the row gather is a device kernel
+        tr.gather_rows(torch.zeros(3, 2), torch.tensor([0]))
