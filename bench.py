@@ -139,7 +139,7 @@ def main():
             traffic = None
 
     result = {
-        "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [15,10] on RMAT-24",
+        "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [%s] on RMAT-%d" % (args.fanout, args.scale),
         "value": edges_all / dt_max,
         "unit": "edges/s",
         "n_gpus": world,
