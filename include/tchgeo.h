@@ -219,6 +219,31 @@ TG_API int tg_ns_hetero_capacity(const tg_het_problem *problem, int64_t *cap_nod
 TG_API int tg_ns_hetero_batched(const tg_het_problem *problem, int64_t n_batches, const tg_rng *rng, const tg_het_out *out,
                                 void *stream);
 
+/* neighbor_sampling_homogenous over a RANGE-PARTITIONED CSC (graphs beyond one GPU's HBM; host protocol in
+ * tch_geometric/partitioned.py).  The origin rank keeps ordinary tg_ns_out slabs; per hop:
+ * tg_part_requests (origin) -> all-to-all -> tg_part_sample (owner) -> all-to-all -> tg_part_emit (origin).  Results
+ * equal tg_ns_homo_batched on the replicated graph bit for bit (requests carry the requester's draw address).
+ * workspace: tg_part_workspace_bytes(n_batches, world) bytes, int64 words laid out as
+ *   state[4 * n_batches] | batch_off[n_batches + 1] | bucket_sizes[world] | cursors[world];
+ * after tg_part_requests, batch_off[n_batches] = number of requests M and bucket_sizes[p] = requests owned by rank p
+ * (the all-to-all split sizes -- the only values the host reads per hop).
+ *  - tg_part_begin: copies the seeds into the slabs, frontier = the seeds.
+ *  - tg_part_requests: requests [M][3] = (vertex, call id, slot) grouped by owner = min(vertex / shard_size, world-1);
+ *    req_pos[M]: frontier slot (batch-major) -> position of its request.  request_cap = capacity of both arrays.
+ *  - tg_part_sample: owner of columns [v_lo, v_lo + shard.n_major): reply [m][fanout][2] = (neighbour id, global edge
+ *    pointer = local pointer + e_lo), -1 padded; unweighted samplers, fanout <= TG_MAX_FANOUT.
+ *  - tg_part_emit: compacts the replies (in request order) into the slabs in slot order and advances the frontier;
+ *    writes layer_offsets[hop] and counts. */
+TG_API int tg_part_workspace_bytes(int64_t n_batches, int32_t world, int64_t *bytes);
+TG_API int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, const tg_ns_out *out, void *workspace,
+                         void *stream);
+TG_API int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t request_cap, int64_t shard_size, int32_t world,
+                            uint64_t first_call_id, void *workspace, int64_t *requests, int64_t *req_pos, void *stream);
+TG_API int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const int64_t *requests, int64_t m,
+                          int32_t fanout, int32_t sampler, uint64_t seed, int64_t *reply, void *stream);
+TG_API int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int32_t fanout, int32_t hop, int32_t n_hops,
+                        void *workspace, const int64_t *req_pos, const int64_t *reply, void *stream);
+
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */
 TG_API int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,

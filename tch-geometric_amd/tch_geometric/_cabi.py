@@ -23,7 +23,8 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
            "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows",
            "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
-           "tg_ns_hetero_batched", "tg_ns_homo_compact"]
+           "tg_ns_hetero_batched", "tg_ns_homo_compact", "tg_part_workspace_bytes", "tg_part_begin",
+           "tg_part_requests", "tg_part_sample", "tg_part_emit"]
 
 
 class TgGraph(C.Structure):

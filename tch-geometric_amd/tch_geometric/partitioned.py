@@ -15,6 +15,9 @@ xGMI is point-to-point and these messages are small (<= 16 B per request, 16 B p
 latency-bound: all batches of a call travel in ONE set of collectives per hop.  With the "nccl" backend (RCCL)
 device tensors go straight into all_to_all_single; with "gloo" (tests) they are staged through the host.
 
+`ns_homo_partitioned_device` is the device form (csrc/partition.hip kernels, fixed-stride replies, ordinary per-batch
+output slabs); `ns_homo_partitioned` below is the same protocol spelled in torch operations, kept because it also
+runs on CPU tensors with any owner-side sampler (the gloo tests use the oracle there).
 Only the unweighted, unfiltered samplers are partitioned in this round.
 """
 import torch
@@ -106,6 +109,61 @@ def _ragged_gather_index(src_start, cnt):
     row = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device), cnt)
     dst_start = torch.cumsum(cnt, 0) - cnt
     return src_start[row] + (torch.arange(total, device=cnt.device) - dst_start[row])
+
+
+def _a2a_flat(send, send_rows, recv_rows, row_len, group):
+    """all-to-all of a flat int64 buffer made of rows of `row_len` words; *_rows: rows per peer (python lists)"""
+    return _all_to_all_rows(send.reshape(-1, row_len), send_rows, recv_rows, group).reshape(-1)
+
+
+def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None):
+    """The device form of the exchange (csrc/partition.hip): the origin keeps the ordinary per-batch slabs of
+    tg_ns_homo_batched; per hop  tg_part_requests -> all-to-all -> tg_part_sample (owner, fixed-stride replies, so no
+    reply sizes are exchanged) -> all-to-all -> tg_part_emit.  The host reads only the bucket sizes (world integers)
+    per hop.  Returns an `_cabi.NsBatchedOut` whose contents equal the replicated-graph sampler's bit for bit."""
+    import ctypes as C
+    lib, ptr = _cabi.lib, _cabi.ptr
+    world, rank = _world(group)
+    dev = seeds.device
+    nb, B = seeds.shape
+    H = len(fanout)
+    out = _cabi.NsBatchedOut(nb, B, fanout, dev)
+    so = out.struct()
+    stream = _cabi.stream_ptr(dev)
+    nbytes = C.c_int64(0)
+    _cabi.check(lib.tg_part_workspace_bytes(C.c_int64(nb), C.c_int32(world), C.byref(nbytes)))
+    ws = torch.zeros(nbytes.value // 8, dtype=torch.int64, device=dev)
+    seeds = seeds.contiguous()
+    _cabi.check(lib.tg_part_begin(ptr(seeds), C.c_int64(nb), C.c_int64(B), C.byref(so), ptr(ws), stream))
+    hist_at = 4 * nb + nb + 1                          # bucket_sizes[world] inside the workspace (include/tchgeo.h)
+    graph = shard.graph_view()
+    cap = nb * B                                       # worst-case frontier of the hop
+    for h, k in enumerate(fanout):
+        req = torch.empty(cap * 3, dtype=torch.int64, device=dev)
+        req_pos = torch.empty(cap, dtype=torch.int64, device=dev)
+        _cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(cap), C.c_int64(shard.shard_size),
+                                         C.c_int32(world), C.c_uint64(first_call_id), ptr(ws), ptr(req), ptr(req_pos), stream))
+        send = ws[hist_at:hist_at + world].tolist()    # the hop's only read-back: requests per owner
+        m_send = int(sum(send))
+        if world > 1:
+            recv = _exchange_counts(send, group)
+            got = _a2a_flat(req[:m_send * 3], send, recv, 3, group)
+        else:
+            recv, got = send, req
+        m_recv = int(sum(recv))
+        reply = torch.empty(max(m_recv, 1) * k * 2, dtype=torch.int64, device=dev)
+        _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
+                                       C.c_int64(m_recv), C.c_int32(int(k)), C.c_int32(sampler), C.c_uint64(seed),
+                                       ptr(reply), stream))
+        back = _a2a_flat(reply[:m_recv * k * 2], recv, send, 2 * k, group) if world > 1 else reply
+        if back.numel() == 0:
+            back = torch.empty(2, dtype=torch.int64, device=dev)
+        _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int32(int(k)), C.c_int32(h), C.c_int32(H),
+                                     ptr(ws), ptr(req_pos), ptr(back), stream))
+        cap *= k
+    if H == 0:
+        out.counts[:, 0] = B
+    return out
 
 
 def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,

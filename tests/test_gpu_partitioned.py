@@ -50,6 +50,28 @@ def test_single_rank_partitioned_equals_batched(sampler):
     o = orc.ns_homo(ptrs.cpu().numpy(), idx.cpu().numpy(), seeds[2].cpu().numpy(), FANOUT, orc.rng_philox(SEED, 42),
                     sampler=sampler)
     assert np.array_equal(res[2][0].cpu().numpy(), o[0]) and np.array_equal(res[2][3].cpu().numpy(), o[3])
+    # the device form of the exchange (csrc/partition.hip) fills ordinary per-batch slabs with the same contents
+    dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler)
+    torch.cuda.synchronize()
+    for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
+        s, r, c, e, lo = dout.batch(b)
+        assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_), b
+
+
+@pytest.mark.parametrize("fan", [[1], [32, 2], [3, 3, 3], []])
+def test_device_form_other_fanouts_and_empty_columns(fan):
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n = _graph(dev)
+    seeds = _cabi.seed_batches(11, 7, 3, 50, n, dev)
+    shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
+    dout = partitioned.ns_homo_partitioned_device(shard, seeds, fan, SEED, 7)
+    out = _cabi.NsBatchedOut(3, 50, fan, dev)
+    _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED, 7, out)
+    torch.cuda.synchronize()
+    for b in range(3):
+        for x, y in zip(dout.batch(b), out.batch(b)):
+            assert (x == y) if isinstance(x, list) else torch.equal(x, y)
 
 
 def _free_port():
@@ -75,6 +97,11 @@ def _worker(rank, world, port, q):
     ref = _replicated(ptrs, idx, seeds, first, 0)
     ok = all(lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_)
              for (s, r, c, e, lo), (rs, rr, rc, re_, rlo) in zip(res, ref))
+    dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, first)   # device form, same exchange
+    torch.cuda.synchronize()
+    for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
+        s, r, c, e, lo = dout.batch(b)
+        ok = ok and lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_)
     remote = sum(int(((s[B:] // shard.shard_size).clamp(max=world - 1) != rank).sum()) for s, *_ in res)
     q.put((rank, ok, remote, sum(int(r.numel()) for _, r, *_ in res)))
     dist.barrier()

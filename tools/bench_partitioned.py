@@ -22,6 +22,7 @@ ap.add_argument("--scale", type=int, default=24)
 ap.add_argument("--batches", type=int, default=256, help="seed batches per rank per exchange round")
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--form", default="device", choices=["device", "torch"], help="device kernels (partition.hip) or torch-level protocol")
 args = ap.parse_args()
 
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -55,14 +56,17 @@ for rnd in range(args.rounds + 1):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    res = partitioned.ns_homo_partitioned(shard, seeds, fan, 0, first)
+    if args.form == "device":
+        dres = partitioned.ns_homo_partitioned_device(shard, seeds, fan, 0, first)
+    else:
+        res = partitioned.ns_homo_partitioned(shard, seeds, fan, 0, first)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if rnd:                        # round 0 is warm-up
         times.append(dt)
-        edges += sum(int(r.numel()) for _, r, *_ in res)
+        edges += int(dres.counts[:, 1].sum()) if args.form == "device" else sum(int(r.numel()) for _, r, *_ in res)
 tot = torch.tensor([edges], dtype=torch.float64, device=dev)
 tmax = torch.tensor([sum(times)], dtype=torch.float64, device=dev)
 if world > 1:
@@ -70,7 +74,7 @@ if world > 1:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 if rank == 0:
     print(json.dumps({"metric": "sampled edges/sec, range-partitioned neighbor_sampling_homogenous", "n_gpus": world,
-                      "scale": args.scale, "batches_per_round_per_rank": args.batches, "rounds": args.rounds,
+                      "scale": args.scale, "form": args.form, "batches_per_round_per_rank": args.batches, "rounds": args.rounds,
                       "value": float(tot) / float(tmax), "unit": "edges/s", "seconds": float(tmax)}))
 if world > 1:
     dist.destroy_process_group()
