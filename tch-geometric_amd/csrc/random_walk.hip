@@ -22,12 +22,20 @@ namespace tg {
 
 constexpr int RW_STAGE = 16; // steps staged per walker between flushes
 
-__device__ __forceinline__ bool has_edge(const int64_t *__restrict__ ptrs, const int64_t *__restrict__ indices,
-                                         int64_t x, int64_t y) { // graph.rs:80-83
-    int64_t lo = ptrs[x], hi = ptrs[x + 1];
+// CSR accessors: the optional u32 shadows (tg_graph.ptrs32 / indices32) hold the same values in half the bytes --
+// twice the entries per gathered line, and the whole offset table of RMAT-24 (67 MB) stays in the Infinity Cache
+struct CsrView {
+    const int64_t *ptrs, *indices;
+    const uint32_t *ptrs32, *indices32;
+    __device__ __forceinline__ int64_t ptr(int64_t i) const { return ptrs32 ? (int64_t)ptrs32[i] : ptrs[i]; }
+    __device__ __forceinline__ int64_t idx(int64_t e) const { return indices32 ? (int64_t)indices32[e] : indices[e]; }
+};
+
+__device__ __forceinline__ bool has_edge(const CsrView &g, int64_t x, int64_t y) { // graph.rs:80-83
+    int64_t lo = g.ptr(x), hi = g.ptr(x + 1);
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);
-        const int64_t v = indices[mid];
+        const int64_t v = g.idx(mid);
         if (v == y) return true;
         if (v < y)
             lo = mid + 1;
@@ -37,8 +45,7 @@ __device__ __forceinline__ bool has_edge(const int64_t *__restrict__ ptrs, const
     return false;
 }
 
-__global__ void rw_node2vec_kernel(const int64_t *__restrict__ ptrs, const int64_t *__restrict__ indices,
-                                   const int64_t *__restrict__ start, int64_t n, int64_t walk_length, float prob0,
+__global__ void rw_node2vec_kernel(const CsrView g, const int64_t *__restrict__ start, int64_t n, int64_t walk_length, float prob0,
                                    float prob1, float prob2, uint64_t seed, uint64_t call_id, int64_t *walks) {
     __shared__ int64_t stage_all[4][64 * (RW_STAGE + 1)]; // [wave][walker * 17 + step]: odd pitch spreads LDS banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -62,7 +69,7 @@ __global__ void rw_node2vec_kernel(const int64_t *__restrict__ ptrs, const int64
                 val = cur;
             } else if (!dead) {
                 const int64_t l = col - 1;
-                const int64_t b = ptrs[cur], e = ptrs[cur + 1];
+                const int64_t b = g.ptr(cur), e = g.ptr(cur + 1);
                 if (e <= b) { // random_walk.rs:45-47
                     dead = true;
                 } else {
@@ -70,12 +77,12 @@ __global__ void rw_node2vec_kernel(const int64_t *__restrict__ ptrs, const int64
                     int64_t next;
                     for (uint32_t attempt = 0;; ++attempt) { // :52-66
                         const Draw d = draw(ck, (uint64_t)t, (uint32_t)l, attempt);
-                        next = indices[b + (int64_t)bounded64(d.a(), deg)];
+                        next = g.idx(b + (int64_t)bounded64(d.a(), deg));
                         if (always_accept) break;
                         const float r = u32_to_f32_01(d.w[2]);
                         if (next == prev) {
                             if (r < prob0) break;
-                        } else if (prev >= 0 && has_edge(ptrs, indices, next, prev)) {
+                        } else if (prev >= 0 && has_edge(g, next, prev)) {
                             if (r < prob1) break;
                         } else if (r < prob2) {
                             break;
@@ -193,8 +200,9 @@ extern "C" int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t
     if (inv_q >= max_prob) max_prob = inv_q;
     const float prob0 = 1.0f / p / max_prob, prob1 = 1.0f / max_prob, prob2 = 1.0f / q / max_prob;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(tg::rw_node2vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, csr->ptrs,
-                       csr->indices, start, n, walk_length, prob0, prob1, prob2, rng->seed, rng->call_id, walks);
+    const tg::CsrView view{csr->ptrs, csr->indices, csr->ptrs32, csr->indices32};
+    hipLaunchKernelGGL(tg::rw_node2vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, view, start, n,
+                       walk_length, prob0, prob1, prob2, rng->seed, rng->call_id, walks);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -56,6 +56,9 @@ def test_random_walk_rmat_with_dead_ends(cabi, dev, pq):
     ref = orc.random_walk(ptrs, idx, start, 40, pq[0], pq[1], orc.rng_philox(SEED, 1))
     assert np.array_equal(w, ref)
     assert (w == -1).any() and (w[:, -1] >= 0).any()
+    # the optional u32 shadows of the CSR change the bytes read, not the walk
+    g32 = cabi.graph_view(p_d, i_d, indices32=i_d.to(torch.int32), ptrs32=p_d.to(torch.int32))
+    assert np.array_equal(cabi.random_walk(g32, s_d, 40, pq[0], pq[1], SEED, 1).cpu().numpy(), ref)
 
 
 def test_random_walk_edge_cases(cabi, dev):

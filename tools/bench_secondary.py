@@ -18,17 +18,19 @@ row, col = _cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
 ptrs, idx, perm = _cabi.coo_to_csx(row, col, n, n, False)      # CSR for walks
 del row, col, perm
 g = _cabi.graph_view(ptrs, idx)
+shadows = os.environ.get("SHADOWS", "1") == "1"        # u32 shadows of the CSR for the node2vec walk (same results)
+g_walk = _cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32)) if shadows else g
 n_walkers, L = 1 << 20, 80
 start = _cabi.seed_batches(0x57A27, 0, 1, n_walkers, n, dev)[0].contiguous()
 res = {}
 for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)) if os.environ.get("NODE2VEC", "1") == "1" else ():
-    _cabi.random_walk(g, start, L, p, q, 0, 0)
+    _cabi.random_walk(g_walk, start, L, p, q, 0, 0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 3
     e0.record()
     for r in range(reps):
-        w = _cabi.random_walk(g, start, L, p, q, 0, r + 1)
+        w = _cabi.random_walk(g_walk, start, L, p, q, 0, r + 1)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
