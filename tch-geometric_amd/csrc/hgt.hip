@@ -249,11 +249,10 @@ __global__ void hgt_live_list_kernel(HgtType ty, const int64_t *__restrict__ fla
         if (flag[i]) live[rank[i]] = i;
 }
 // one wavefront: the reference's weighted reservoir over the live entries, weights score^2 (:110)
-__global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_ptr, const int64_t *__restrict__ live,
-                                              int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
-                                              int64_t *chosen, int64_t *n_chosen, int *panic) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double pbuf[64]; // serial prefix scratch (one wavefront per launch)
+__device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int64_t *n_live_ptr,
+                                                   const int64_t *__restrict__ live, int64_t k, uint64_t seed,
+                                                   uint64_t call_id, uint64_t draw_id, int64_t *chosen, int64_t *n_chosen,
+                                                   int *panic, unsigned char *smem, double *pbuf) {
     uint32_t *slot_pos = reinterpret_cast<uint32_t *>(smem);
     uint32_t *slot_rank = slot_pos + k;
     const int lane = threadIdx.x & 63;
@@ -303,6 +302,32 @@ __global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_
     const int64_t cnt = min(n, k);
     for (int64_t s = lane; s < cnt; s += 64) chosen[s] = (int64_t)slot_pos[s];
     if (lane == 0) *n_chosen = cnt;
+}
+__global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_ptr, const int64_t *__restrict__ live,
+                                              int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
+                                              int64_t *chosen, int64_t *n_chosen, int *panic) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double pbuf[64]; // serial prefix scratch (one wavefront per launch)
+    hgt_reservoir_body(ty, n_live_ptr, live, k, seed, call_id, draw_id, chosen, n_chosen, panic, smem, pbuf);
+}
+// The node types of a layer sample from their own budgets independently (:201-221), and each reservoir is one
+// wavefront bound by its running-sum chain: one workgroup per type runs them side by side.
+constexpr int HGT_MULTI_TYPES = 8;
+struct HgtMultiArgs {
+    HgtType ty[HGT_MULTI_TYPES];
+    const int64_t *n_live[HGT_MULTI_TYPES];
+    const int64_t *live[HGT_MULTI_TYPES];
+    int64_t *chosen[HGT_MULTI_TYPES];
+    int64_t *n_chosen[HGT_MULTI_TYPES];
+    int64_t k[HGT_MULTI_TYPES];
+};
+__global__ void hgt_weighted_reservoir_multi_kernel(const HgtMultiArgs a, uint64_t seed, uint64_t call_id, int64_t layer,
+                                                    int n_types, int *panic) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double pbuf[64];
+    const int t = blockIdx.x;
+    hgt_reservoir_body(a.ty[t], a.n_live[t], a.live[t], a.k[t], seed, call_id, (uint64_t)(layer * n_types + t), a.chosen[t],
+                       a.n_chosen[t], panic, smem, pbuf);
 }
 // :213-221 move the samples to the node list, give them local ids, erase them from the budget
 __global__ void hgt_append_kernel(HgtType ty, const int64_t *__restrict__ live, const int64_t *__restrict__ chosen,
@@ -474,8 +499,9 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     b += align16(8 * (size_t)pl.mc_cap) * 8;     // ckey, cinv, cts, cslot, skey, sval, skey2, sval2
     b += align16(8 * (size_t)pl.tmp_cap) * 2;    // tmp map
     b += align16(8 * (size_t)pl.scan_cap) * 2;   // flag, rank
-    b += align16(8 * (size_t)pl.max_budget);     // live
-    b += align16(8 * (size_t)pl.max_k);          // chosen
+    for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
+    b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T;                         // chosen, per type
+    b += align16(16 * (size_t)pl.T);                                           // n_live, n_chosen per type
     b += align16(8 * (size_t)pl.edge_cap) * 2;   // cand_j, cand_ep
     b += align16(pl.sort_temp_bytes);
     b += align16(pl.scan_temp_bytes);
@@ -560,8 +586,10 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     int64_t *tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
     int64_t *flag = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
     int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
-    int64_t *live = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_budget));
-    int64_t *chosen = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
+    std::vector<int64_t *> live_t((size_t)T), chosen_t((size_t)T);
+    for (int t = 0; t < T; ++t) live_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
+    for (int t = 0; t < T; ++t) chosen_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
+    int64_t *n_live_t = reinterpret_cast<int64_t *>(take(16 * (size_t)T)), *n_chosen_t = n_live_t + T;
     int64_t *cand_j = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
     int64_t *cand_ep = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
     void *sort_temp = take(pl.sort_temp_bytes);
@@ -629,20 +657,42 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         }
     // ---- :198-242 layers
     for (int layer = 0; layer < H; ++layer) {
-        for (int t = 0; t < T; ++t) { // :201 every type that owns a budget samples from it
+        size_t lds_max = 8;
+        for (int t = 0; t < T; ++t) { // :201 every type that owns a budget samples from it: first the live lists
             const int64_t k = pb->num_samples[(size_t)t * H + layer];
             hipLaunchKernelGGL(hgt_live_flags_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t],
                                pl.cap_budget[t], flag);
-            if (int rcs = device_scan(pl.cap_budget[t], scal + 2)) return rcs;
+            if (int rcs = device_scan(pl.cap_budget[t], n_live_t + t)) return rcs;
             hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], flag,
-                               rank, live);
+                               rank, live_t[(size_t)t]);
             const size_t lds = (size_t)(k > 0 ? k : 1) * 8;
             TG_REQUIRE(lds <= 64 * 1024, "tg_hgt_sample: num_samples %lld exceeds 8192 per layer", (long long)k);
-            hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(64), lds, stream, ty[t], scal + 2, live, k,
-                               rng->seed, rng->call_id, (uint64_t)((int64_t)layer * T + t), chosen, scal + 3, panic);
-            hipLaunchKernelGGL(hgt_append_kernel, dim3(1), dim3(256), 0, stream, ty[t], live, chosen, scal + 3);
-            TG_LAUNCH_CHECK();
+            if (lds > lds_max) lds_max = lds;
         }
+        if (T <= HGT_MULTI_TYPES) { // the types' reservoirs side by side, one workgroup each
+            HgtMultiArgs ma;
+            for (int t = 0; t < T; ++t) {
+                ma.ty[t] = ty[(size_t)t];
+                ma.n_live[t] = n_live_t + t;
+                ma.live[t] = live_t[(size_t)t];
+                ma.chosen[t] = chosen_t[(size_t)t];
+                ma.n_chosen[t] = n_chosen_t + t;
+                ma.k[t] = pb->num_samples[(size_t)t * H + layer];
+            }
+            hipLaunchKernelGGL(hgt_weighted_reservoir_multi_kernel, dim3((unsigned)T), dim3(64), lds_max, stream, ma,
+                               rng->seed, rng->call_id, (int64_t)layer, T, panic);
+        } else {
+            for (int t = 0; t < T; ++t) {
+                const int64_t k = pb->num_samples[(size_t)t * H + layer];
+                hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(64), (size_t)(k > 0 ? k : 1) * 8, stream,
+                                   ty[t], n_live_t + t, live_t[(size_t)t], k, rng->seed, rng->call_id,
+                                   (uint64_t)((int64_t)layer * T + t), chosen_t[(size_t)t], n_chosen_t + t, panic);
+            }
+        }
+        for (int t = 0; t < T; ++t)
+            hipLaunchKernelGGL(hgt_append_kernel, dim3(1), dim3(256), 0, stream, ty[t], live_t[(size_t)t],
+                               chosen_t[(size_t)t], n_chosen_t + t);
+        TG_LAUNCH_CHECK();
         if (layer < H - 1)
             for (int t = 0; t < T; ++t) { // :227 (types without samples return at :38-40)
                 rc = update_budget(t);
