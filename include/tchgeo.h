@@ -403,6 +403,12 @@ TG_API int tg_ns_homo_compact(const tg_ns_out *out, int64_t n_batches, const int
                               int64_t *flat_samples, int64_t *flat_rows, int64_t *flat_cols, int64_t *flat_edge_index,
                               void *stream);
 
+/* Ragged rows of an int64 slab -> one flat array: dst[offsets[r] + i] = src[r * pitch + i] for
+ * i < lens[r * lens_stride] (lens, offsets: device arrays).  The per-type / per-relation slabs of
+ * tg_ns_hetero_batched are flattened with it (tch_geometric/loader.py). */
+TG_API int tg_compact_rows(const int64_t *src, int64_t pitch, const int64_t *lens, int64_t lens_stride, const int64_t *offsets,
+                           int64_t n_rows, int64_t *dst, void *stream);
+
 /* Harness calibration (not part of the sampling path): n_threads lanes each issue per_thread
  * independent random 8-byte loads from table[0..n_table); sink: [n_threads]. */
 TG_API int tg_probe_random_gather(const int64_t *table, int64_t n_table, int64_t n_threads, int64_t per_thread,

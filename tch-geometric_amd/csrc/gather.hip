@@ -107,7 +107,26 @@ __global__ void ns_compact_kernel(tg_ns_out o, const int64_t *__restrict__ node_
     }
 }
 
+// ragged rows of an int64 slab -> one flat array: dst[off[r] + i] = src[r * pitch + i] for i < lens[r * lens_stride]
+__global__ void compact_rows_kernel(const int64_t *__restrict__ src, int64_t pitch, const int64_t *__restrict__ lens,
+                                    int64_t lens_stride, const int64_t *__restrict__ off, int64_t *dst) {
+    const int64_t r = blockIdx.x, n = lens[r * lens_stride], o = off[r];
+    const int64_t *s = src + r * pitch;
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.y * blockDim.x) dst[o + i] = s[i];
+}
+
 } // namespace tg
+
+extern "C" int tg_compact_rows(const int64_t *src, int64_t pitch, const int64_t *lens, int64_t lens_stride,
+                               const int64_t *offsets, int64_t n_rows, int64_t *dst, void *stream) {
+    TG_REQUIRE(n_rows >= 0 && n_rows <= 0x7fffffff && pitch >= 0 && lens_stride >= 1, "tg_compact_rows: bad sizes");
+    if (n_rows == 0) return TG_OK;
+    TG_REQUIRE(src && lens && offsets && dst, "tg_compact_rows: null buffers");
+    hipLaunchKernelGGL(tg::compact_rows_kernel, dim3((unsigned)n_rows, 8), dim3(256), 0, (hipStream_t)stream, src, pitch, lens,
+                       lens_stride, offsets, dst);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
 
 extern "C" int tg_ns_homo_compact(const tg_ns_out *out, int64_t n_batches, const int64_t *node_off, const int64_t *edge_off,
                                   int64_t *flat_samples, int64_t *flat_rows, int64_t *flat_cols, int64_t *flat_edge_index,

@@ -24,7 +24,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_gather_rows",
            "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
            "tg_ns_hetero_batched", "tg_ns_homo_compact", "tg_part_workspace_bytes", "tg_part_begin",
-           "tg_part_requests", "tg_part_sample", "tg_part_emit"]
+           "tg_part_requests", "tg_part_sample", "tg_part_emit", "tg_compact_rows"]
 
 
 class TgGraph(C.Structure):
@@ -319,6 +319,17 @@ def ns_homo_compact(out, n_batches, counts_host):
     check(lib.tg_ns_homo_compact(C.byref(so), C.c_int64(n_batches), ptr(off[0]), ptr(off[1]), ptr(fs), ptr(fr), ptr(fc),
                                  ptr(fe), stream_ptr(dev)))
     return fs, fr, fc, fe
+
+
+def compact_rows(slab, lens, total):
+    """Flat concatenation of slab[r, :lens[r]] (slab: [n_rows, pitch] int64; lens: device view, any stride; total: their
+    sum, known to the host)."""
+    n_rows = slab.shape[0]
+    off = torch.cumsum(lens, 0) - lens
+    dst = torch.empty(int(total), dtype=torch.int64, device=slab.device)
+    check(lib.tg_compact_rows(ptr(slab), C.c_int64(slab.stride(0)), ptr(lens), C.c_int64(lens.stride(0) if lens.dim() else 1),
+                              ptr(off), C.c_int64(n_rows), ptr(dst), stream_ptr(slab.device)))
+    return dst
 
 
 def gather_rows(src, index, status=None):

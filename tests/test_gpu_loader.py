@@ -57,3 +57,44 @@ def test_input_nodes_and_shuffle():
     e2 = torch.cat([b.n_id[:b.batch_size].cpu() for b in sh])
     assert sorted(e1.tolist()) == sorted(nodes.tolist()) == sorted(e2.tolist())
     assert not torch.equal(e1, e2) or not torch.equal(e1, nodes)   # epochs reshuffle
+
+
+def test_hetero_loader_equals_oracle_and_carries_attributes():
+    from tch_geometric.loader import HeteroNeighborLoader
+    from tch_geometric.transforms import HeteroGraph
+    from helpers import load_fake_hetero, rel_key
+    counts, edges = load_fake_hetero()
+    node_types, edge_types = sorted(counts), sorted(edges)
+    rs = np.random.default_rng(4)
+    data, feats, ets = HeteroGraph(), {}, {}
+    for nt in node_types:
+        feats[nt] = rs.standard_normal((counts[nt], 6)).astype(np.float32)
+        data[nt].x, data[nt].num_nodes = torch.from_numpy(feats[nt]).to(DEV), counts[nt]
+    for et in edge_types:
+        data[et].edge_index = torch.from_numpy(edges[et]).to(DEV)
+        ets[et] = rs.integers(0, 100, edges[et].shape[1])
+        data[et].timestamps = torch.from_numpy(ets[et]).to(DEV)
+    P, I, PERM = {}, {}, {}
+    for et in edge_types:
+        P[rel_key(et)], I[rel_key(et)], PERM[rel_key(et)] = orc.to_csc(edges[et], (counts[et[0]], counts[et[2]]))
+    nt0 = node_types[0]
+    nodes = torch.from_numpy(rs.integers(0, counts[nt0], 150))
+    loader = HeteroNeighborLoader(data, [4, 3], nt0, input_nodes=nodes, batch_size=32, prefetch=3, seed=5, call_id0=40)
+    assert len(loader) == 5
+    nn = {rel_key(et): [4, 3] for et in edge_types}
+    n_seen = 0
+    for j, b in enumerate(loader):
+        seeds = nodes[j * 32:(j + 1) * 32].numpy()
+        o = orc.ns_hetero(node_types, edge_types, P, I, {nt0: seeds}, nn, 2, orc.rng_philox(5, 40 + j))
+        for nt in node_types:
+            s = b[nt].n_id.cpu().numpy()
+            assert np.array_equal(s, o[0][nt]) and np.array_equal(b[nt].x.cpu().numpy(), feats[nt][s])
+        for et in edge_types:
+            k = rel_key(et)
+            assert np.array_equal(b[et].edge_index.cpu().numpy(), np.stack([o[1][k], o[2][k]]))
+            assert np.array_equal(b[et].e_id.cpu().numpy(), PERM[k][o[3][k]])
+            assert np.array_equal(b[et].timestamps.cpu().numpy(), ets[et][PERM[k][o[3][k]]])
+            assert b[et].layer_offsets == o[4][k]
+        assert b[nt0].batch_size == len(seeds) and b.call_id == 40 + j
+        n_seen += 1
+    assert n_seen == 5
