@@ -19,6 +19,10 @@
 // mask per pass; item order is node-type-major in `node_types` order.
 #include <vector>
 
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
 #include "tg_device.h"
 #include "tg_host.h"
 #include "tg_map.h"
@@ -131,44 +135,28 @@ __global__ void neg_insert_items_kernel(NegRelTable tab, int dst_type, const int
 //  mode 0: flag = item targets dst_type, is not an input, and holds its node's minimum position (first sight)
 //  mode 1: flag = item accepted and of relation `sel`
 // rank[p] is written for flagged items; total[0] receives the flag count.
-__global__ void neg_scan_kernel(NegRelTable tab, int mode, int sel, const int64_t *__restrict__ cand,
+__global__ void neg_flag_kernel(NegRelTable tab, int mode, int sel, const int64_t *__restrict__ cand,
                                 const int32_t *__restrict__ rel_of, const int64_t *__restrict__ ids, int64_t begin,
                                 int64_t end, const int64_t *new_keys, const int64_t *new_vals, int64_t new_mask,
-                                int64_t *rank, int64_t *total, int64_t total_add) {
-    __shared__ int64_t wave_tot[16];
-    __shared__ int64_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = begin; base < end; base += blockDim.x) {
-        const int64_t p = base + tid;
-        int64_t flag = 0;
-        if (p < end) {
-            const int64_t w = cand[p];
-            if (w >= 0) {
-                if (mode == 1) {
-                    flag = rel_of[p] == sel;
-                } else if (tab.r[rel_of[p]].dst_type == sel && ids[p] < 0) {
-                    const int64_t t = map_slot_find(new_keys, new_mask, w);
-                    flag = (t >= 0 && new_vals[t] == p);
-                }
+                                int64_t *flag) {
+    for (int64_t p = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < end; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t f = 0;
+        const int64_t w = cand[p];
+        if (w >= 0) {
+            if (mode == 1) {
+                f = rel_of[p] == sel;
+            } else if (tab.r[rel_of[p]].dst_type == sel && ids[p] < 0) {
+                const int64_t t = map_slot_find(new_keys, new_mask, w);
+                f = (t >= 0 && new_vals[t] == p);
             }
         }
-        const int64_t incl = wave_inclusive_scan(flag);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int64_t off = carry_s;
-        for (int wv = 0; wv < wave; ++wv) off += wave_tot[wv];
-        if (flag) rank[p] = off + incl - 1;
-        __syncthreads();
-        if (tid == 0) {
-            int64_t s = 0;
-            for (int wv = 0; wv < n_waves; ++wv) s += wave_tot[wv];
-            carry_s += s;
-        }
-        __syncthreads();
+        flag[p] = f;
     }
-    if (tid == 0) total[0] = carry_s + total_add;
+}
+// total[0] = number of flagged items in [begin, end) + total_add, from the exclusive scan `rank` of `flag`
+__global__ void neg_total_kernel(const int64_t *__restrict__ flag, const int64_t *__restrict__ rank, int64_t begin,
+                                 int64_t end, int64_t *total, int64_t total_add) {
+    total[0] = (end > begin ? rank[end - 1] + flag[end - 1] : 0) + total_add;
 }
 
 // after mode-0 ranks: first sights append their node to `samples`; every non-input item learns its id
@@ -212,8 +200,13 @@ extern "C" int tg_neg_workspace_bytes(const tg_neg_problem *pb, int64_t *bytes) 
         if (n > max_in) max_in = n;
     }
     const int64_t in_cap = tg::pow2_at_least(2 * max_in + 2), new_cap = tg::pow2_at_least(2 * m + 2);
-    // cand, ids, rank, erank: m i64 each; rel_of: m i32 (padded); maps: 2*(in_cap + new_cap) i64; totals; panic flag
-    *bytes = 8 * (4 * m + 2 * in_cap + 2 * new_cap + 8) + ((4 * m + 15) & ~(int64_t)15) + 64;
+    // cand, ids, rank, erank, flag: m i64 each; rel_of: m i32 (padded); maps: 2*(in_cap + new_cap) i64; totals; panic
+    // flag; temporary storage of the device-wide scans
+    size_t scan_temp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, scan_temp, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0,
+                                           (size_t)(m > 0 ? m : 1), rocprim::plus<int64_t>(), (hipStream_t)0, false);
+    if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::exclusive_scan size query failed: %s", hipGetErrorString(e));
+    *bytes = 8 * (5 * m + 2 * in_cap + 2 * new_cap + 8) + ((4 * m + 15) & ~(int64_t)15) + 64 + (int64_t)((scan_temp + 15) & ~(size_t)15) + 512;
     return TG_OK;
 }
 
@@ -245,6 +238,21 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
     int64_t *totals = new_vals + new_cap; // [0] scratch total
     int *panic = reinterpret_cast<int *>(totals + 4);
     int32_t *rel_of = reinterpret_cast<int32_t *>(totals + 8);
+    int64_t *flag = reinterpret_cast<int64_t *>(reinterpret_cast<unsigned char *>(rel_of) + ((4 * m + 15) & ~(int64_t)15));
+    void *scan_temp = reinterpret_cast<void *>(((uintptr_t)(flag + m) + 255) & ~(uintptr_t)255);
+    size_t scan_temp_bytes = 0;
+    TG_HIP(rocprim::exclusive_scan(nullptr, scan_temp_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0,
+                                   (size_t)(m > 0 ? m : 1), rocprim::plus<int64_t>(), stream, false));
+    // ranks of the flagged items of [b, e) (device-wide: flag kernel + rocPRIM scan), their count (+ add) into total
+    auto ranks_of = [&](int mode, int sel, int64_t b, int64_t e, int64_t *rank_out, int64_t *total, int64_t add) -> int {
+        hipLaunchKernelGGL(neg_flag_kernel, dim3(grid_1d(e - b)), dim3(256), 0, stream, tab, mode, sel, cand, rel_of, ids, b,
+                           e, new_keys, new_vals, new_cap - 1, flag);
+        size_t stb = scan_temp_bytes;
+        TG_HIP(rocprim::exclusive_scan(scan_temp, stb, flag + b, rank_out + b, (int64_t)0, (size_t)(e - b),
+                                       rocprim::plus<int64_t>(), stream, false));
+        hipLaunchKernelGGL(neg_total_kernel, dim3(1), dim3(1), 0, stream, flag, rank_out, b, e, total, add);
+        return TG_OK;
+    };
     TG_HIP(hipMemsetAsync(panic, 0, sizeof(int), stream));
 
     // ---- 1. candidates, one source type at a time (item order = node_types order, then i, then jn)
@@ -278,8 +286,7 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
         if (m > 0) {
             hipLaunchKernelGGL(neg_insert_items_kernel, dim3(grid_1d(m)), dim3(256), 0, stream, tab, dt, cand, rel_of,
                                m, in_keys, in_vals, in_cap - 1, new_keys, new_vals, new_cap - 1, ids);
-            hipLaunchKernelGGL(neg_scan_kernel, dim3(1), dim3(1024), 0, stream, tab, 0, dt, cand, rel_of, ids,
-                               (int64_t)0, m, new_keys, new_vals, new_cap - 1, rank, totals, n_in);
+            if (int rcs = ranks_of(0, dt, 0, m, rank, totals, n_in)) return rcs;
             hipLaunchKernelGGL(neg_assign_ids_kernel, dim3(grid_1d(m)), dim3(256), 0, stream, tab, dt, cand, rel_of, m,
                                n_in, new_keys, new_vals, new_cap - 1, rank, ids, out->samples[dt]);
         } else {
@@ -294,8 +301,7 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
         const int t = pb->rel_src[r];
         const int64_t b = item_begin[t], e = item_begin[t + 1];
         if (e > b) {
-            hipLaunchKernelGGL(neg_scan_kernel, dim3(1), dim3(1024), 0, stream, tab, 1, r, cand, rel_of, ids, b, e,
-                               new_keys, new_vals, new_cap - 1, erank, totals + 1, (int64_t)0);
+            if (int rcs = ranks_of(1, r, b, e, erank, totals + 1, 0)) return rcs;
             hipLaunchKernelGGL(neg_emit_edges_kernel, dim3(grid_1d(e - b)), dim3(256), 0, stream, r, cand, rel_of, ids,
                                erank, b, e, pb->num_neg, out->rows[r], out->cols[r]);
         } else {
