@@ -114,7 +114,8 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
         r.layer_offsets.emplace_back(n_seeds + ne, ne, n_seeds + ne); // neighbor_sampling.rs:193
         const int64_t m = frontier.numel();
         if (m == 0) continue;
-        if (k > 64) throw py::value_error("num_neighbors above 64 is not supported with a temporal filter or weights");
+        if (k > 64 && (weighted || filtered))
+            throw py::value_error("num_neighbors above 64 is not supported with a temporal filter or weights");
         Tensor cnt = at::empty({m}, i64(dev)), offsets = at::empty({m + 1}, i64(dev));
         Tensor nbr = at::empty({m * k}, i64(dev)), ep = at::empty({m * k}, i64(dev)), par = at::empty({m * k}, i64(dev));
         Tensor st_out = at::empty({m * k}, i64(dev));
@@ -134,7 +135,13 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
         tg_hop_out out{cnt.data_ptr<int64_t>(), offsets.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(),
                        ep.data_ptr<int64_t>(), par.data_ptr<int64_t>()};
         int64_t group_cap = std::max<int64_t>(1024, indices.numel() / 512 + 2 * m + 2), total = 0;
-        if (weighted) { // sampling.rs:28-55, one wavefront per frontier vertex all over the device
+        if (!weighted && !filtered) { // plain uniform samplers over a large frontier: the whole-device hop of ns_hop.hip
+            int64_t ws_bytes = 0;
+            check_rc(tg_ns_hop_workspace_bytes(m, &ws_bytes));
+            Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
+            check_rc(tg_ns_hop(&g, &in, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
+            total = read_scalar<int64_t>(offsets[m]);
+        } else if (weighted) { // sampling.rs:28-55, one wavefront per frontier vertex all over the device
             Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
             int64_t ws_bytes = 0;
             check_rc(tg_ns_hop_scan_workspace_bytes(m, (int32_t)k, 1, &ws_bytes));
@@ -183,7 +190,11 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
                 const Tensor &timestamps, const Tensor &seeds, const Tensor &seeds_state,
                 const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f, const tg_rng &rng,
                 uint32_t tag, int64_t id_base) {
-    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED) // whole-device flat hops (scan / weighted)
+    // whole-device flat hops: always for filters / weights (column scans), and for the plain samplers when ONE call
+    // brings more seeds than a workgroup should walk alone (the batched kernel gives a batch one workgroup)
+    int64_t max_k = 1;
+    for (int64_t k : fanout) max_k = std::max(max_k, k);
+    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || (seeds.numel() > 2048 && max_k <= 255))
         return run_ns_filtered_flat(dev, ptrs, indices, weights, timestamps, seeds, seeds_state, fanout, s, f, rng, tag,
                                     id_base);
     const int32_t H = (int32_t)fanout.size();

@@ -191,3 +191,20 @@ def test_out_of_range_node_ids_raise_instead_of_faulting(tg):
         tg.budget_sampling(["a"], [et], {k: P}, {k: I}, None, {"a": bad}, None, {"a": [2]}, 1, None, False, False)
     # and valid calls still work afterwards
     assert tg.neighbor_sampling_homogenous(P, I, torch.tensor([0, 1]).cuda(), [2])[0].numel() == 4
+
+
+def test_large_single_call_takes_the_whole_device_path(tg):
+    """more than 2048 seeds in ONE call: hop by hop over the whole device (tg_ns_hop), same results as the oracle"""
+    ptrs, idx, n = None, None, 1 << 13
+    rs = np.random.default_rng(12)
+    ei = np.stack([rs.integers(0, n, n * 8), rs.integers(0, n, n * 8)])
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    seeds = rs.integers(0, n, 20000)
+    P, I, S = (torch.from_numpy(a).cuda() for a in (ptrs, idx, seeds))
+    for sampler, kw in ((None, {}), (tg.UniformEdgeSampler(True), dict(sampler=orc.SAMPLER_UNIFORM_REPL))):
+        tg.seed(31)
+        s, r, c, e, lo = tg.neighbor_sampling_homogenous(P, I, S, [6, 4], sampler)
+        o = orc.ns_homo(ptrs, idx, seeds, [6, 4], orc.rng_philox(31, 0), **kw)
+        assert lo == o[4]
+        for a, b in zip((s, r, c, e), o[:4]):
+            assert np.array_equal(_np(a), b)
