@@ -401,6 +401,9 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                  num_hops >= 0 && num_hops <= TG_MAX_HOPS;
     for (const Rel &r : rels)
         for (int64_t h = 0; fused && r.active && h < num_hops; ++h) fused = r.fanout[(size_t)h] <= TG_MAX_FANOUT;
+    int64_t total_inputs = 0; // the fused kernel gives the call ONE workgroup: large calls go hop by hop over the device
+    for (size_t t = 0; t < T; ++t) total_inputs += frontier[t].numel();
+    fused = fused && total_inputs <= 4096;
     if (fused) {
         const int R = (int)rels.size(), H = (int)num_hops;
         std::vector<int32_t> rel_src((size_t)std::max(R, 1)), rel_dst((size_t)std::max(R, 1));

@@ -139,3 +139,24 @@ def test_hetero_negative_sampling_random(tg, case):
     _eq_dicts(r, o[1], rels, "rows")
     _eq_dicts(c, o[2], rels, "cols")
     assert {t: int(cnt[t]) for t in node_types} == {t: int(o[3][t]) for t in node_types}
+
+
+def test_large_hetero_call_leaves_the_fused_kernel(tg):
+    """more than 4096 inputs in one call: the host drives whole-device hops per relation; results unchanged"""
+    rs = np.random.default_rng(77)
+    node_types, edge_types, counts, edges = random_hetero(rs)
+    P, I = {}, {}
+    for et in edge_types:
+        P[rel_key(et)], I[rel_key(et)], _ = orc.to_csc(edges[et], (counts[et[0]], counts[et[2]]))
+    inputs = {t: rs.integers(0, counts[t], 3000) for t in node_types}
+    nn = {rel_key(et): [3, 2] for et in edge_types}
+    tg.seed(5)
+    s, r, c, e, lo = tg.neighbor_sampling_heterogenous(node_types, edge_types, _cuda(P), _cuda(I), _cuda(inputs), nn, 2)
+    o = orc.ns_hetero(node_types, edge_types, P, I, inputs, nn, 2, orc.rng_philox(5, 0))
+    _eq_dicts(s, o[0], node_types, "samples")
+    rels = [rel_key(et) for et in edge_types]
+    _eq_dicts(r, o[1], rels, "rows")
+    _eq_dicts(c, o[2], rels, "cols")
+    _eq_dicts(e, o[3], rels, "edge_index")
+    for k in rels:
+        assert [tuple(x) for x in lo[k]] == o[4][k]
