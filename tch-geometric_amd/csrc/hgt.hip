@@ -248,13 +248,15 @@ __global__ void hgt_live_list_kernel(HgtType ty, const int64_t *__restrict__ fla
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if (flag[i]) live[rank[i]] = i;
 }
+constexpr int64_t HGT_LDS_SLOTS = 8192; // samples per layer whose slot tables fit 64 KB of LDS
 // one wavefront: the reference's weighted reservoir over the live entries, weights score^2 (:110)
 __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int64_t *n_live_ptr,
                                                    const int64_t *__restrict__ live, int64_t k, uint64_t seed,
                                                    uint64_t call_id, uint64_t draw_id, int64_t *chosen, int64_t *n_chosen,
-                                                   int *panic, unsigned char *smem, double *pbuf) {
-    uint32_t *slot_pos = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *slot_rank = slot_pos + k;
+                                                   int *panic, unsigned char *smem, double *pbuf, uint32_t *slots_global) {
+    // slot tables: LDS up to 8192 samples per layer, the caller's global scratch beyond
+    uint32_t *slot_pos = (k > HGT_LDS_SLOTS) ? slots_global : reinterpret_cast<uint32_t *>(smem);
+    uint32_t *slot_rank = slot_pos + (k > 0 ? k : 0);
     const int lane = threadIdx.x & 63;
     const int64_t n = *n_live_ptr;
     if (k < 0) { // num_samples has no entry for this type: the reference panics once the budget exists (:202)
@@ -269,8 +271,18 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
         return;
     }
     const CallKey ck = call_key(seed, call_id, TAG_HGT);
+    const bool gslots = k > HGT_LDS_SLOTS;
+    auto slots_handoff = [&]() { // lanes of this wavefront hand slot-table entries to each other
+        if (gslots) {          // global scratch: make the stores / atomics visible before the reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        } else {
+            wave_lds_handoff();
+        }
+    };
     for (int64_t s = lane; s < k; s += 64) slot_rank[s] = 0;
-    wave_lds_handoff();
+    slots_handoff();
     double w_sum = 0.0;
     for (int64_t base = 0; base < n; base += 64) {
         const int64_t m = base + lane;
@@ -295,9 +307,9 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
         }
         if (ok && m < k) slot_pos[m] = (uint32_t)m;
         if (hit >= 0) atomicMax(&slot_rank[hit], (uint32_t)m);
-        wave_lds_handoff();
-        if (hit >= 0 && slot_rank[hit] == (uint32_t)m) slot_pos[hit] = (uint32_t)m;
-        wave_lds_handoff();
+        slots_handoff();
+        if (hit >= 0 && __atomic_load_n(&slot_rank[hit], __ATOMIC_RELAXED) == (uint32_t)m) slot_pos[hit] = (uint32_t)m;
+        slots_handoff();
     }
     const int64_t cnt = min(n, k);
     for (int64_t s = lane; s < cnt; s += 64) chosen[s] = (int64_t)slot_pos[s];
@@ -305,10 +317,10 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
 }
 __global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_ptr, const int64_t *__restrict__ live,
                                               int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
-                                              int64_t *chosen, int64_t *n_chosen, int *panic) {
+                                              int64_t *chosen, int64_t *n_chosen, int *panic, uint32_t *slots_global) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double pbuf[64]; // serial prefix scratch (one wavefront per launch)
-    hgt_reservoir_body(ty, n_live_ptr, live, k, seed, call_id, draw_id, chosen, n_chosen, panic, smem, pbuf);
+    hgt_reservoir_body(ty, n_live_ptr, live, k, seed, call_id, draw_id, chosen, n_chosen, panic, smem, pbuf, slots_global);
 }
 // The node types of a layer sample from their own budgets independently (:201-221), and each reservoir is one
 // wavefront bound by its running-sum chain: one workgroup per type runs them side by side.
@@ -320,6 +332,7 @@ struct HgtMultiArgs {
     int64_t *chosen[HGT_MULTI_TYPES];
     int64_t *n_chosen[HGT_MULTI_TYPES];
     int64_t k[HGT_MULTI_TYPES];
+    uint32_t *slots[HGT_MULTI_TYPES];
 };
 __global__ void hgt_weighted_reservoir_multi_kernel(const HgtMultiArgs a, uint64_t seed, uint64_t call_id, int64_t layer,
                                                     int n_types, int *panic) {
@@ -327,7 +340,7 @@ __global__ void hgt_weighted_reservoir_multi_kernel(const HgtMultiArgs a, uint64
     __shared__ double pbuf[64];
     const int t = blockIdx.x;
     hgt_reservoir_body(a.ty[t], a.n_live[t], a.live[t], a.k[t], seed, call_id, (uint64_t)(layer * n_types + t), a.chosen[t],
-                       a.n_chosen[t], panic, smem, pbuf);
+                       a.n_chosen[t], panic, smem, pbuf, a.slots[t]);
 }
 // :213-221 move the samples to the node list, give them local ids, erase them from the budget
 __global__ void hgt_append_kernel(HgtType ty, const int64_t *__restrict__ live, const int64_t *__restrict__ chosen,
@@ -500,7 +513,7 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     b += align16(8 * (size_t)pl.tmp_cap) * 2;    // tmp map
     b += align16(8 * (size_t)pl.scan_cap) * 2;   // flag, rank
     for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
-    b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T;                         // chosen, per type
+    b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T * 2;                     // chosen + slot tables, per type
     b += align16(16 * (size_t)pl.T);                                           // n_live, n_chosen per type
     b += align16(8 * (size_t)pl.edge_cap) * 2;   // cand_j, cand_ep
     b += align16(pl.sort_temp_bytes);
@@ -589,6 +602,8 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     std::vector<int64_t *> live_t((size_t)T), chosen_t((size_t)T);
     for (int t = 0; t < T; ++t) live_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
     for (int t = 0; t < T; ++t) chosen_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
+    std::vector<uint32_t *> slots_t((size_t)T);
+    for (int t = 0; t < T; ++t) slots_t[(size_t)t] = reinterpret_cast<uint32_t *>(take(8 * (size_t)pl.max_k));
     int64_t *n_live_t = reinterpret_cast<int64_t *>(take(16 * (size_t)T)), *n_chosen_t = n_live_t + T;
     int64_t *cand_j = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
     int64_t *cand_ep = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
@@ -665,8 +680,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             if (int rcs = device_scan(pl.cap_budget[t], n_live_t + t)) return rcs;
             hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], flag,
                                rank, live_t[(size_t)t]);
-            const size_t lds = (size_t)(k > 0 ? k : 1) * 8;
-            TG_REQUIRE(lds <= 64 * 1024, "tg_hgt_sample: num_samples %lld exceeds 8192 per layer", (long long)k);
+            const size_t lds = (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 8 : 8;
             if (lds > lds_max) lds_max = lds;
         }
         if (T <= HGT_MULTI_TYPES) { // the types' reservoirs side by side, one workgroup each
@@ -678,15 +692,17 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                 ma.chosen[t] = chosen_t[(size_t)t];
                 ma.n_chosen[t] = n_chosen_t + t;
                 ma.k[t] = pb->num_samples[(size_t)t * H + layer];
+                ma.slots[t] = slots_t[(size_t)t];
             }
             hipLaunchKernelGGL(hgt_weighted_reservoir_multi_kernel, dim3((unsigned)T), dim3(64), lds_max, stream, ma,
                                rng->seed, rng->call_id, (int64_t)layer, T, panic);
         } else {
             for (int t = 0; t < T; ++t) {
                 const int64_t k = pb->num_samples[(size_t)t * H + layer];
-                hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(64), (size_t)(k > 0 ? k : 1) * 8, stream,
-                                   ty[t], n_live_t + t, live_t[(size_t)t], k, rng->seed, rng->call_id,
-                                   (uint64_t)((int64_t)layer * T + t), chosen_t[(size_t)t], n_chosen_t + t, panic);
+                hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(64),
+                                   (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 8 : 8, stream, ty[t], n_live_t + t,
+                                   live_t[(size_t)t], k, rng->seed, rng->call_id, (uint64_t)((int64_t)layer * T + t),
+                                   chosen_t[(size_t)t], n_chosen_t + t, panic, slots_t[(size_t)t]);
             }
         }
         for (int t = 0; t < T; ++t)

@@ -82,3 +82,18 @@ def test_hgt_quota_above_budget_and_edge_cases(tg, graph):
     with pytest.raises(RuntimeError, match="reference panics"):                             # :202
         tg.hgt_sampling(graph[0], graph[1], _cuda(graph[2]), _cuda(graph[3]), None, _cuda({"v1": [3]}), None,
                         {"v1": [5, 5]}, 2)
+
+
+def test_hgt_more_than_8192_samples_per_layer(tg):
+    """quotas above what the LDS slot tables hold (8192) use global slot tables; results still equal the oracle"""
+    rs = np.random.default_rng(21)
+    nA, nB = 40000, 30000
+    e1 = np.stack([rs.integers(0, nA, 400000), rs.integers(0, nB, 400000)])     # A -> B
+    e2 = np.stack([rs.integers(0, nB, 300000), rs.integers(0, nA, 300000)])     # B -> A
+    node_types, edge_types = ["A", "B"], [("A", "x", "B"), ("B", "y", "A")]
+    P, I = {}, {}
+    P["A__x__B"], I["A__x__B"], _ = orc.to_csc(e1, (nA, nB))
+    P["B__y__A"], I["B__y__A"], _ = orc.to_csc(e2, (nB, nA))
+    g = (node_types, edge_types, P, I)
+    o = _compare(tg, g, {"B": rs.integers(0, nB, 3000)}, None, {"A": [9000, 12000], "B": [10000, 100]}, 2, 3)
+    assert len(o[0]["A"]) > 8192
