@@ -130,7 +130,8 @@ TG_API int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t
  * is not "one seed batch": the owner side of the range-partitioned sampler, relation-hops of the heterogeneous
  * sampler.  Vertex i of the frontier is sampled with draw id ids[i] (or id_base + i) and call id call_ids[i]
  * (or rng.call_id); vertices < 0 are empty slots.  Outputs are sized for the worst case m * fanout;
- * offsets[m] is the number of samples.  No synchronisation. */
+ * offsets[m] is the number of samples.  No synchronisation.  Fan-outs up to 4096: above 128 one wavefront per vertex
+ * runs the ticket chain with its displaced entries in LDS (the batched kernel stops at 255). */
 typedef struct {
     const int64_t *vertices; /* [m] */
     const int64_t *ids;      /* [m] or NULL */

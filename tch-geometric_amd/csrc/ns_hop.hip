@@ -119,6 +119,70 @@ __global__ void hop_emit_kernel(const HopParams p) {
     }
 }
 
+// Fan-outs above 255: one WAVEFRONT per frontier vertex.  The ticket chain is inherently
+// slot-after-slot; here the shuffle's displaced entries (keys, vals) live in LDS and all 64 lanes search them for
+// the latest entry of the two keys a slot needs, so a slot costs ceil(s / 64) LDS probes per lane.  Same draws and
+// the same positions as sample_tickets / the oracle.  Columns with deg <= k (the usual case at such fan-outs) are
+// copied whole.
+constexpr int HOP_BIGK_MAX = 4096;
+__global__ void hop_emit_bigk_kernel(const HopParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int k = p.k;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem), *vals = keys + k, *pos = vals + k;
+    const CallKey ck0 = call_key(p.seed, p.call_id, p.tag);
+    for (int64_t i = blockIdx.x; i < p.m; i += gridDim.x) {
+        const int64_t w = p.vertices[i];
+        if (w < 0) continue;
+        int64_t e0, deg;
+        hop_range(p, w, e0, deg);
+        if (deg <= 0) continue;
+        const int64_t o = p.offsets[i];
+        const uint32_t n = (uint32_t)deg;
+        const uint32_t cnt = p.replace ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k);
+        const uint64_t did = p.ids ? (uint64_t)p.ids[i] : (uint64_t)(p.id_base + i);
+        const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[i], p.tag) : ck0;
+        if (p.replace) { // sampling.rs:57-69: slot s draws its own position
+            for (uint32_t s = lane; s < cnt; s += 64) pos[s] = bounded32(draw(ck, did, s >> 1, D1_REPLACE).half(s & 1), n);
+        } else if (deg <= k) { // sampling.rs:12-15
+            for (uint32_t s = lane; s < cnt; s += 64) pos[s] = s;
+        } else {
+            Draw d;
+            for (int s = 0; s < k; ++s) {
+                const uint32_t m = (n - 1u) - (uint32_t)s;
+                if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
+                const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                int jr = -1, jl = -1; // latest displaced entry of r / of last
+                for (int j = lane; j < s; j += 64) {
+                    const uint32_t key = keys[j];
+                    jr = (key == r) ? j : jr;
+                    jl = (key == last) ? j : jl;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    jr = max(jr, __shfl_xor(jr, off, 64));
+                    jl = max(jl, __shfl_xor(jl, off, 64));
+                }
+                const uint32_t tr = jr >= 0 ? vals[jr] : r, tl = jl >= 0 ? vals[jl] : last;
+                if (lane == 0) {
+                    keys[s] = r;
+                    vals[s] = tl;
+                    pos[s] = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+                }
+                wave_lds_handoff();
+            }
+        }
+        wave_lds_handoff();
+        for (uint32_t q = lane; q < cnt; q += 64) {
+            const int64_t ep = e0 + (int64_t)pos[q];
+            p.neighbors[o + q] = p.indices32 ? (int64_t)p.indices32[ep] : p.indices[ep];
+            p.edge_ptrs[o + q] = ep;
+            p.parents[o + q] = i;
+        }
+        wave_lds_handoff();
+    }
+}
+
 template <int KMAX>
 static int launch_hop_emit(const HopParams &p, hipStream_t stream) {
     const int k = p.k;
@@ -155,7 +219,8 @@ extern "C" int tg_ns_hop(const tg_graph *csc, const tg_hop_in *in, const tg_rng 
                          void *workspace, int64_t workspace_bytes, void *stream_) {
     using namespace tg;
     TG_REQUIRE(csc && csc->ptrs && in && rng && out, "tg_ns_hop: null argument");
-    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= 255, "tg_ns_hop: bad frontier size or fan-out");
+    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= HOP_BIGK_MAX, "tg_ns_hop: frontier size or fan-out (1..%d)",
+               HOP_BIGK_MAX);
     TG_REQUIRE(in->sampler == TG_SAMPLER_UNIFORM || in->sampler == TG_SAMPLER_UNIFORM_REPL,
                "tg_ns_hop: only the unweighted samplers");
     TG_REQUIRE(out->cnt && out->offsets, "tg_ns_hop: null outputs");
@@ -198,5 +263,9 @@ extern "C" int tg_ns_hop(const tg_graph *csc, const tg_hop_in *in, const tg_rng 
                                    false));
     if (p.k <= 16) return launch_hop_emit<16>(p, stream);
     if (p.k <= TG_MAX_FANOUT) return launch_hop_emit<32>(p, stream);
-    return launch_hop_emit<0>(p, stream);
+    if (p.k <= 128) return launch_hop_emit<0>(p, stream); // LDS ticket strips, lane per vertex
+    int64_t blocks = p.m < 256 * 32 ? p.m : 256 * 32;      // wavefront per vertex
+    hipLaunchKernelGGL(hop_emit_bigk_kernel, dim3((unsigned)blocks), dim3(64), (size_t)p.k * 12, stream, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
 }

@@ -191,10 +191,11 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
                 const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f, const tg_rng &rng,
                 uint32_t tag, int64_t id_base) {
     // whole-device flat hops: always for filters / weights (column scans), and for the plain samplers when ONE call
-    // brings more seeds than a workgroup should walk alone (the batched kernel gives a batch one workgroup)
+    // brings more seeds than a workgroup should walk alone (the batched kernel gives a batch one workgroup) or a
+    // fan-out above 128 (the batched kernel keeps its ticket strips in LDS; tg_ns_hop takes up to 4096)
     int64_t max_k = 1;
     for (int64_t k : fanout) max_k = std::max(max_k, k);
-    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || (seeds.numel() > 2048 && max_k <= 255))
+    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || seeds.numel() > 2048 || max_k > 128)
         return run_ns_filtered_flat(dev, ptrs, indices, weights, timestamps, seeds, seeds_state, fanout, s, f, rng, tag,
                                     id_base);
     const int32_t H = (int32_t)fanout.size();

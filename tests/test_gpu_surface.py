@@ -208,3 +208,26 @@ def test_large_single_call_takes_the_whole_device_path(tg):
         assert lo == o[4]
         for a, b in zip((s, r, c, e), o[:4]):
             assert np.array_equal(_np(a), b)
+
+
+@pytest.mark.parametrize("fan", [[200], [300, 2], [1000], [4096]])
+def test_fanouts_above_255_take_the_wavefront_per_vertex_path(tg, fan):
+    rs = np.random.default_rng(14)
+    n, e = 3000, 400000                                   # mean degree 133, hubs above 5000
+    ei = np.stack([rs.integers(0, n, e), rs.integers(0, n, e)])
+    ei[1, rs.integers(0, e, e // 10)] = 7
+    ei[1, rs.integers(0, e, e // 20)] = 8
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    seeds = np.concatenate([[7, 8, 7], rs.integers(0, n, 20)])
+    P, I, S = (torch.from_numpy(a).cuda() for a in (ptrs, idx, seeds))
+    for sampler, kw in ((None, {}), (tg.UniformEdgeSampler(True), dict(sampler=orc.SAMPLER_UNIFORM_REPL))):
+        if fan[0] > 1000 and sampler is not None:
+            continue
+        tg.seed(41)
+        s, r, c, e_, lo = tg.neighbor_sampling_homogenous(P, I, S, fan, sampler)
+        o = orc.ns_homo(ptrs, idx, seeds, fan, orc.rng_philox(41, 0), **kw)
+        assert lo == o[4]
+        for a, b in zip((s, r, c, e_), o[:4]):
+            assert np.array_equal(_np(a), b), fan
+    with pytest.raises(ValueError):
+        tg.neighbor_sampling_homogenous(P, I, S, [5000])
