@@ -47,7 +47,6 @@ struct NsHomoParams {
     uint64_t seed, call_id;
     uint32_t tag;
     int64_t id_base;
-    int32_t flags; // tuning knobs
     const int64_t *seed_ids, *seed_call_ids; // remote-frontier mode (n_hops == 1)
 };
 
@@ -233,20 +232,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 }
                 wave_lds_handoff();
                 const int64_t e_chunk = ne + (int64_t)chunk_off[c];
-                if (p.flags & 2) { // A/B knob: one gather in flight per lane
-#pragma unroll 4
-                    for (uint32_t q = lane; q < total; q += 64) {
-                        const int l = slane[q];
-                        const int64_t ep = ebase[l] + (int64_t)spos[q];
-                        const int64_t v = p.indices32 ? (int64_t)__builtin_nontemporal_load(&p.indices32[ep])
-                                                      : __builtin_nontemporal_load(&p.indices[ep]);
-                        const int64_t e = e_chunk + q;
-                        samples[n_seeds + e] = v;
-                        __builtin_nontemporal_store(n_seeds + e, &rows[e]);
-                        __builtin_nontemporal_store(i0 + l, &cols[e]);
-                        __builtin_nontemporal_store(ep, &eidx[e]);
-                    }
-                } else if (p.indices32)
+                if (p.indices32)
                     emit_chunk<uint32_t, NT>(p.indices32, total, lane, slane, spos, ebase, e_chunk, i0, n_seeds, samples,
                                              rows, cols, eidx);
                 else
@@ -376,7 +362,6 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     p.call_id = rng->call_id;
     p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
     p.id_base = cfg ? cfg->id_base : 0;
-    p.flags = tg::env_int("TG_NS_EMIT_SIMPLE", 0) ? 2 : 0;
     p.seed_ids = cfg ? cfg->seed_ids : nullptr;
     p.seed_call_ids = cfg ? cfg->seed_call_ids : nullptr;
     TG_REQUIRE((p.seed_ids == nullptr) == (p.seed_call_ids == nullptr),
