@@ -76,8 +76,9 @@ def main():
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     t_build = time.time() - t_build
-    idx32 = indices.to(torch.int32) if args.idx32 else None  # bit pattern of u32 for ids < 2^31
-    ptr32 = ptrs.to(torch.int32) if args.ptr32 else None    # offsets < 2^31 at scale 24 (2^28 edges)
+    # u32 shadows (int32 tensors carrying the u32 bit pattern): only while ids / offsets fit 32 bits
+    idx32 = indices.to(torch.int32) if args.idx32 and n_nodes <= 2 ** 32 else None
+    ptr32 = ptrs.to(torch.int32) if args.ptr32 and n_edges < 2 ** 32 else None
     graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32)
 
     # ---- this rank's batches: global batch ids [rank*(W+K), (rank+1)*(W+K))
