@@ -54,3 +54,9 @@ def roots_of(cols, n_inputs, n_samples):
 
 def rel_key(et):
     return "%s__%s__%s" % tuple(et)
+
+
+def load_fake_dataset():
+    """the reference's tests/fakedataset.npz (edge list only): 1144 nodes, 22648 edges"""
+    d = np.load(os.path.join(GOLDEN, "fakedataset_edges.npz"), allow_pickle=False)
+    return d["edge_index"].astype(np.int64), int(d["num_nodes"])
