@@ -204,3 +204,16 @@ def test_empty_inputs_and_isolated_vertices():
     s, r, c, e, lo = orc.ns_homo(ptrs, idx, [0, 1, 2, 1], [3, 3], orc.rng_philox(1))
     assert s.tolist() == [0, 1, 2, 1, 0, 2, 0, 2] and c.tolist() == [1, 1, 3, 3]
     assert lo == [(4, 0, 4), (8, 4, 8)]
+
+
+def test_fakedataset_fixture_invariants_in_both_modes():
+    """the reference's third data file (tests/fakedataset.npz): validate_neighbor_samples in ref- and philox-mode"""
+    from helpers import load_fake_dataset
+    ei, n = load_fake_dataset()
+    assert ei.shape == (2, 22648) and n == 1144
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    seeds = np.tile(np.arange(8), 4)
+    for rng in (orc.rng_ref(), orc.rng_philox(1, 0)):
+        s, r, c, e, lo = orc.ns_homo(ptrs, idx, seeds, [4, 3], rng)
+        validate_neighbor_samples(ptrs, idx, r, c, s, s, lo, [4, 3])
+        assert np.array_equal(s[:len(seeds)], seeds) and np.array_equal(idx[e], s[r])
