@@ -166,7 +166,8 @@ typedef struct {
     int32_t filter_mode; /* TG_FILTER_STATIC / RELATIVE / DYNAMIC */
     int32_t forward;
     int64_t win_lo, win_hi; /* inclusive window */
-    const int64_t *states;  /* [m] */
+    const int64_t *states;  /* [m]  Fan-outs up to 1024 (above 64 the ticket chain keeps its displaced
+ * entries in LDS). */
 } tg_hop_filter;
 
 TG_API int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t group_cap, int64_t *bytes);

@@ -109,15 +109,19 @@ __global__ void hs_count_kernel(const HopScanParams p) {
     }
 }
 
-// wavefront per frontier vertex
+// wavefront per frontier vertex.  Per wavefront in LDS: ranks[k] (the ranks to fetch, slot order) and, for fan-outs
+// above 64, the ticket chain's displaced entries keys[k] / vals[k].
+constexpr int HS_MAX_FANOUT = 1024;
 __global__ void hs_select_kernel(const HopScanParams p) {
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool overflow = p.vgroups[p.m] >= p.group_cap;
     const CallKey ck0 = call_key(p.seed, p.call_id, p.tag);
     const int k = p.k;
+    uint32_t *ranks = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * 3 * k, *keys = ranks + k, *vals = keys + k;
     for (int64_t v = wave_id; v < p.m; v += n_waves) {
         const int64_t w = p.vertices[v];
         const int64_t gfirst = p.vgroups[v], glast = p.vgroups[v + 1];
@@ -129,17 +133,16 @@ __global__ void hs_select_kernel(const HopScanParams p) {
         }
         const uint32_t cnt_sel = p.replace ? (n > 0 ? (uint32_t)k : 0u) : min(n, (uint32_t)k);
         if (lane == 0) p.cnt[v] = cnt_sel;
-        uint32_t myrank = (uint32_t)lane;
         if (cnt_sel > 0) {
             const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
             const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[v], p.tag) : ck0;
             if (p.replace) { // sampling.rs:57-69
-                if (lane < k) {
-                    const Draw d = draw(ck, did, (uint32_t)(lane >> 1), D1_REPLACE);
-                    myrank = bounded32(d.half(lane & 1), n);
-                }
-            } else if (n > (uint32_t)k) { // reservoir by tickets, lane s owns slot s
-                uint32_t myK = 0xffffffffu, myV = 0;
+                for (uint32_t s = lane; s < (uint32_t)k; s += 64)
+                    ranks[s] = bounded32(draw(ck, did, s >> 1, D1_REPLACE).half(s & 1), n);
+            } else if (n <= (uint32_t)k) { // every candidate, in order
+                for (uint32_t s = lane; s < cnt_sel; s += 64) ranks[s] = s;
+            } else if (k <= 64) { // reservoir by tickets, lane s owns slot s
+                uint32_t myK = 0xffffffffu, myV = 0, myrank = 0;
                 Draw d;
                 for (int s = 0; s < k; ++s) {
                     const uint32_t mm = (n - 1u) - (uint32_t)s;
@@ -156,15 +159,41 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                         myrank = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
                     }
                 }
+                if (lane < k) ranks[lane] = myrank;
+            } else { // the same chain with its displaced entries in LDS, searched by all lanes
+                Draw d;
+                for (int s = 0; s < k; ++s) {
+                    const uint32_t mm = (n - 1u) - (uint32_t)s;
+                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
+                    const uint32_t r = bounded32(d.half(s & 1), mm), last = mm - 1u;
+                    int jr = -1, jl = -1;
+                    for (int j = lane; j < s; j += 64) {
+                        const uint32_t key = keys[j];
+                        jr = (key == r) ? j : jr;
+                        jl = (key == last) ? j : jl;
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        jr = max(jr, __shfl_xor(jr, off, 64));
+                        jl = max(jl, __shfl_xor(jl, off, 64));
+                    }
+                    const uint32_t tr = jr >= 0 ? vals[jr] : r, tl = jl >= 0 ? vals[jl] : last;
+                    if (lane == 0) {
+                        keys[s] = r;
+                        vals[s] = tl;
+                        ranks[s] = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+                    }
+                    wave_lds_handoff();
+                }
             }
         }
+        wave_lds_handoff();
         // locate every kept rank: binary search over the vertex's groups, then re-read that group
-        int64_t my_ep = -1;
         if (cnt_sel > 0) {
             const int64_t st = p.states[v];
             const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
             for (uint32_t s = 0; s < cnt_sel; ++s) {
-                const int64_t target = base_rank + (int64_t)__shfl(myrank, (int)s, 64);
+                const int64_t target = base_rank + (int64_t)ranks[s];
                 int64_t lo = gfirst, hi = glast - 1; // last group g with gpref[g] <= target
                 while (lo < hi) {
                     const int64_t mid = (lo + hi + 1) >> 1;
@@ -189,16 +218,15 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                     const uint64_t mask = __ballot(ok);
                     const int64_t c = __popcll(mask);
                     if (!found && target - seen < c) {
-                        const uint64_t owner = __ballot(ok && seen + (int64_t)__popcll(mask & lt_mask) == target);
-                        const int64_t ep = __shfl(e, __ffsll((long long)owner) - 1, 64);
-                        if (lane == (int)s) my_ep = ep;
+                        if (ok && seen + (int64_t)__popcll(mask & lt_mask) == target) p.park[v * k + s] = e;
                         found = true;
                     }
                     seen += c;
                 }
             }
         }
-        if (lane < k) p.park[v * k + lane] = ((uint32_t)lane < cnt_sel) ? my_ep : -1;
+        for (uint32_t s = cnt_sel + lane; s < (uint32_t)k; s += 64) p.park[v * k + s] = -1;
+        wave_lds_handoff();
     }
 }
 
@@ -220,7 +248,7 @@ __global__ void hw_select_kernel(const HopScanParams p) {
     for (int64_t v = wave_id; v < p.m; v += n_waves) {
         const int64_t w = p.vertices[v];
         uint32_t n = 0;
-        if (lane < k) slot_rank[lane] = 0;
+        for (int sl = lane; sl < k; sl += 64) slot_rank[sl] = 0;
         wave_lds_handoff();
         if (w >= 0) {
             const int64_t st = p.states ? p.states[v] : 0;
@@ -274,7 +302,7 @@ __global__ void hw_select_kernel(const HopScanParams p) {
         wave_lds_handoff();
         const uint32_t cnt_sel = min(n, (uint32_t)k);
         if (lane == 0) p.cnt[v] = cnt_sel;
-        if (lane < k) p.park[v * k + lane] = ((uint32_t)lane < cnt_sel) ? slot_ptr[lane] : -1;
+        for (int sl = lane; sl < k; sl += 64) p.park[v * k + sl] = ((uint32_t)sl < cnt_sel) ? slot_ptr[sl] : -1;
         wave_lds_handoff();
     }
 }
@@ -328,7 +356,8 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
     using namespace tg;
     TG_REQUIRE(csc && csc->ptrs && in && flt && rng && out && status, "tg_ns_hop_scan: null argument");
     TG_REQUIRE(csc->timestamps, "tg_ns_hop_scan: the graph has no edge timestamps");
-    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= 64, "tg_ns_hop_scan: bad frontier size or fan-out (<= 64)");
+    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= HS_MAX_FANOUT, "tg_ns_hop_scan: bad frontier size or fan-out (<= %d)",
+               HS_MAX_FANOUT);
     TG_REQUIRE(in->sampler == TG_SAMPLER_UNIFORM || in->sampler == TG_SAMPLER_UNIFORM_REPL,
                "tg_ns_hop_scan: only the unweighted samplers");
     TG_REQUIRE(flt->filter_mode >= TG_FILTER_STATIC && flt->filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_scan: bad filter");
@@ -403,7 +432,7 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
     TG_HIP(rocprim::exclusive_scan(temp, st, p.gcount, p.gpref, (int64_t)0, (size_t)group_cap, rocprim::plus<int64_t>(),
                                    stream, false));
     // the frontier uses fewer than group_cap groups (else status = 1), so gpref[n_groups] is inside the scanned range
-    hipLaunchKernelGGL(hs_select_kernel, grid(p.m * 64, 256), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(hs_select_kernel, grid(p.m * 64, 256), dim3(256), (size_t)4 * 3 * p.k * sizeof(uint32_t), stream, p);
     TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
     st = temp_bytes;
     TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
@@ -417,7 +446,8 @@ extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, cons
                                   int64_t workspace_bytes, void *stream_) {
     using namespace tg;
     TG_REQUIRE(csc && csc->ptrs && csc->weights && in && rng && out && status, "tg_ns_hop_weighted: null argument");
-    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= 64, "tg_ns_hop_weighted: bad frontier size or fan-out (<= 64)");
+    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= HS_MAX_FANOUT,
+               "tg_ns_hop_weighted: bad frontier size or fan-out (<= %d)", HS_MAX_FANOUT);
     const int filter_mode = flt ? flt->filter_mode : TG_FILTER_NONE;
     TG_REQUIRE(filter_mode >= TG_FILTER_NONE && filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_weighted: bad filter");
     TG_REQUIRE(filter_mode == TG_FILTER_NONE || (csc->timestamps && flt->states && states_out),
@@ -473,7 +503,8 @@ extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, cons
     p.edge_ptrs = out->edge_ptrs;
     p.parents = out->parents;
     p.states_out = states_out;
-    const int n_waves = 4;
+    int n_waves = 4;
+    while (n_waves > 1 && (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t) > 60 * 1024) n_waves >>= 1;
     const size_t lds = (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t);
     int64_t blocks = (p.m + n_waves - 1) / n_waves;
     if (blocks > 256 * 32) blocks = 256 * 32;

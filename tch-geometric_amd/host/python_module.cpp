@@ -114,8 +114,8 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
         r.layer_offsets.emplace_back(n_seeds + ne, ne, n_seeds + ne); // neighbor_sampling.rs:193
         const int64_t m = frontier.numel();
         if (m == 0) continue;
-        if (k > 64 && (weighted || filtered))
-            throw py::value_error("num_neighbors above 64 is not supported with a temporal filter or weights");
+        if (k > 1024 && (weighted || filtered))
+            throw py::value_error("num_neighbors above 1024 is not supported with a temporal filter or weights");
         Tensor cnt = at::empty({m}, i64(dev)), offsets = at::empty({m + 1}, i64(dev));
         Tensor nbr = at::empty({m * k}, i64(dev)), ep = at::empty({m * k}, i64(dev)), par = at::empty({m * k}, i64(dev));
         Tensor st_out = at::empty({m * k}, i64(dev));

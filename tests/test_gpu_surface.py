@@ -231,3 +231,30 @@ def test_fanouts_above_255_take_the_wavefront_per_vertex_path(tg, fan):
             assert np.array_equal(_np(a), b), fan
     with pytest.raises(ValueError):
         tg.neighbor_sampling_homogenous(P, I, S, [5000])
+
+
+@pytest.mark.parametrize("k", [65, 200, 1024])
+def test_filtered_and_weighted_fanouts_above_64(tg, k):
+    rs = np.random.default_rng(15)
+    n, e = 2000, 300000
+    ei = np.stack([rs.integers(0, n, e), rs.integers(0, n, e)])
+    ei[1, rs.integers(0, e, e // 8)] = 3                      # a hub column of ~37 K edges
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    seeds = np.concatenate([[3, 3], rs.integers(0, n, 12)])
+    ts, w = rs.integers(0, 10, len(idx)), rs.uniform(0.1, 3.0, len(idx))
+    st = rs.integers(0, 10, len(seeds))
+    P, I, S = (torch.from_numpy(a).cuda() for a in (ptrs, idx, seeds))
+    flt = (tg.TemporalEdgeFilter((0, 6), torch.from_numpy(ts).cuda(), True, tg.TEMPORAL_SAMPLE_DYNAMIC), torch.from_numpy(st).cuda())
+    fkw = dict(filter_mode=orc.FILTER_DYNAMIC, forward=True, window=(0, 6), timestamps=ts, inputs_state=st)
+    cases = [(None, flt, fkw), (tg.UniformEdgeSampler(True), flt, dict(sampler=orc.SAMPLER_UNIFORM_REPL, **fkw))]
+    if k <= 200:
+        cases.append((tg.WeightedEdgeSampler(torch.from_numpy(w).cuda()), None, dict(sampler=orc.SAMPLER_WEIGHTED, weights=w)))
+    for sampler, f, kw in cases:
+        tg.seed(51)
+        s, r, c, e_, lo = tg.neighbor_sampling_homogenous(P, I, S, [k], sampler, f)
+        o = orc.ns_homo(ptrs, idx, seeds, [k], orc.rng_philox(51, 0), **kw)
+        assert lo == o[4]
+        for a, b in zip((s, r, c, e_), o[:4]):
+            assert np.array_equal(_np(a), b), (k, kw.get("sampler"))
+    with pytest.raises(ValueError):
+        tg.neighbor_sampling_homogenous(P, I, S, [1025], None, flt)
