@@ -2,9 +2,10 @@
 """Headline benchmark: sampled edges/sec of neighbor_sampling_homogenous, fanout [15,10], batch 1024,
 on a synthetic RMAT scale-24 graph (BASELINE.json configs[1]), HIP path through the C ABI.
 
-A "step" is one 1024-seed batch.  Steps are submitted `--batches-per-launch` at a time (one kernel
-launch covers that many independent batches; seeds, CSC and output slabs are resident in HBM).
-N > 1: one process per GPU (torchrun), CSC replicated, every rank samples its own K batches with no
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch of tg_ns_homo_batched over
+`--batches-per-step` independent 1024-seed mini-batches (seeds, CSC and output slabs resident in HBM).  The
+throughput therefore does not depend on how many steps the caller asks for.
+N > 1: one process per GPU (torchrun), CSC replicated, every rank samples its own K steps with no
 data-path collective (weak scaling); the only collectives are the barrier / MAX / SUM of the timing
 protocol.  Prints ONE JSON line on rank 0.
 """
@@ -23,13 +24,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16384)
-    ap.add_argument("--warmup", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--scale", type=int, default=24)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanout", type=str, default="15,10")
-    ap.add_argument("--batches-per-launch", type=int, default=4096)
+    ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int, default=4096,
+                    help="independent 1024-seed mini-batches sampled by the one launch of a step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")
@@ -66,7 +68,7 @@ def main():
     fanout = [int(x) for x in args.fanout.split(",")]
     n_nodes = 1 << args.scale
     n_edges = n_nodes * args.edge_factor
-    K, W, G, B = args.steps, args.warmup, args.batches_per_launch, args.batch
+    K, W, G, B = args.steps, args.warmup, args.batches_per_step, args.batch
 
     # ---- graph: R-MAT edges -> CSC with the reference's sort key (storage.rs:118-123); resident in HBM
     t_build = time.time()
@@ -81,27 +83,28 @@ def main():
     ptr32 = ptrs.to(torch.int32) if args.ptr32 and n_edges < 2 ** 32 else None
     graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32)
 
-    # ---- this rank's batches: global batch ids [rank*(W+K), (rank+1)*(W+K))
-    first, _ = sharding.rank_batch_range(rank, world, W + K)
-    seeds = _cabi.seed_batches(0xBA7C4, first, W + K, B, n_nodes, dev)
-    out = _cabi.NsBatchedOut(min(G, max(W, K)), B, fanout, dev)
+    # ---- this rank's mini-batches: global batch ids [rank*(W+K)*G, (rank+1)*(W+K)*G); step i samples G of them with
+    # call ids first + i*G ...  Seeds of up to 32 steps are kept resident (268 MB each); longer runs cycle through them
+    # with fresh call ids, i.e. fresh draws.
+    first, _ = sharding.rank_batch_range(rank, world, (W + K) * G)
+    n_pool = max(1, min(W + K, 32))
+    seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
+    out = _cabi.NsBatchedOut(G, B, fanout, dev)
     acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
 
     def run(lo, hi, events=None):
-        for s in range(lo, hi, G):
-            e = min(hi, s + G)
+        for i in range(lo, hi):
+            s0 = (i % n_pool) * G
             if events is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            _cabi.ns_homo_batched(graph, seeds[s:e], fanout, 0, first + s, out)
+            _cabi.ns_homo_batched(graph, seeds[s0:s0 + G], fanout, 0, first + i * G, out)
             if events is not None:
                 ev1.record()
                 events.append((ev0, ev1))
-            nb = e - s
-            ne = out.counts[:nb, 1].sum()
+            ne = out.counts[:, 1].sum()
             # frontier slots expanded = seeds + samples that existed when the last hop started
-            nf = out.layer_offsets[:nb, len(fanout) - 1, 0].sum() if fanout else torch.zeros((), dtype=torch.int64,
-                                                                                             device=dev)
+            nf = out.layer_offsets[:, len(fanout) - 1, 0].sum() if fanout else torch.zeros((), dtype=torch.int64, device=dev)
             acc.add_(torch.stack([ne, nf, torch.ones((), dtype=torch.int64, device=dev)]))
 
     def fence():
@@ -125,7 +128,7 @@ def main():
     my_edges, my_frontier, my_launches = (int(x) for x in acc.tolist())
     # per hop: 24 B per frontier slot (8 id + 16 ptrs pair) + 40 B per sampled edge (8 gather + 32 written);
     # per batch: 16 B per seed (read + copy into `samples`)            -- SURVEY.md 8(d)
-    alg_bytes = 24 * my_frontier + 40 * my_edges + 16 * B * K
+    alg_bytes = 24 * my_frontier + 40 * my_edges + 16 * B * G * K
     bytes_per_launch = alg_bytes / my_launches
     achieved = bytes_per_launch / avg_kernel_s / 1e9
     traffic = None
@@ -156,12 +159,14 @@ def main():
             "workload": "neighbor_sampling_homogenous, RMAT scale-%d (%d nodes / %d edges, CSC i64), fanout %s, "
                         "batch %d, default sampler (uniform w/o replacement), no filter" %
                         (args.scale, n_nodes, n_edges, fanout, B),
+            "step": "one launch over %d independent %d-seed mini-batches" % (G, B),
             "batches_per_launch": G,
             "hbm_layout": "CSC int64 ptrs/indices%s%s" % (" + u32 shadow of indices for the gathers" if args.idx32 else "",
                                                           " + u32 shadow of ptrs" if args.ptr32 else ""),
             "rng": "philox4x32-10 counter-addressed, seed 0, call_id = global batch id",
             "parallelism": "replicated CSC, %d x independent seed batches" % world,
             "sampled_edges_per_step": edges_all / (K * world),
+            "sampled_edges_per_mini_batch": edges_all / (K * world * G),
             "graph_build_s": round(t_build, 2),
         },
         "roofline": {
@@ -179,7 +184,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[W:], fanout)
+        result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -206,7 +211,7 @@ def cpu_baseline(args, ptrs, indices, seeds, fanout):
         "unit": "edges/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d of the timed 1024-seed batches, oracle ref-mode (rand-0.8.5 Xoshiro256++ stream, "
+        "sample": "%d of the 1024-seed mini-batches of the timed steps, oracle ref-mode (rand-0.8.5 Xoshiro256++ stream, "
                   "reservoir loop of sampling.rs), %d threads each owning whole batches, %.1f s wall; "
                   "single thread: %.3g edges/s over %d batches" %
                   (n, threads, sec, edges1 / sec1, max(1, n // threads)),
