@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libtchgeo_hip.so")
+LIB_PATH = os.environ.get("TCHGEO_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libtchgeo_hip.so")  # TCHGEO_LIB: A/B builds
 
 TG_OK = 0
 TG_MAX_HOPS = 8
