@@ -41,6 +41,7 @@ def parse_args():
 
 def main():
     args = parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
     import torch
     import torch.distributed as dist
 
