@@ -225,14 +225,26 @@ __global__ void hgt_accumulate_kernel(HgtType src, const int64_t *__restrict__ s
         if (entry == SORT_PAD) continue;
         if (q > 0 && skey[q - 1] == entry) continue; // not the head of its run
         double score = src.bscore[entry];
-        int64_t ts = src.bts[entry];
-        for (int64_t r = q; r < cap && skey[r] == entry; ++r) {
-            const int64_t p = sval[r];
-            score = score + cinv[p];
-            ts = cts[p];
+        int64_t lo = q, hi = cap; // the run is [q, end): keys are sorted, so its end is found by bisection
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (skey[mid] == entry)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int64_t end = lo + 1;
+        // the sum keeps the contribution order, but the gathers of 8 contributions are issued together
+        for (int64_t r = q; r < end; r += 8) {
+            double c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c[u] = cinv[sval[min(r + u, end - 1)]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + u < end) score = score + c[u];
         }
         src.bscore[entry] = score;
-        src.bts[entry] = ts;
+        src.bts[entry] = cts[sval[end - 1]];
     }
 }
 
