@@ -359,6 +359,41 @@ typedef struct {
 
 TG_API int tg_budget_layer(const tg_budget_layer_in *in, const tg_rng *rng, const tg_budget_layer_out *out, void *stream);
 
+/* budget_sampling as ONE stream-ordered call without host bookkeeping: sample lists, their lengths and the frontier
+ * bounds live on the device (workspace); per (layer, node type) step the per-node selection is followed by a stable
+ * multi-way partition that appends every chosen candidate to its source type's list and its relation's edge lists in
+ * (node, slot) order (budget_sampling.rs:223-257).  Node types / relations are indexed in the caller's order.
+ * Up to 8 node types, 16 relations, num_neighbors <= 64 (tg_budget_layer is the per-step form without these
+ * limits on types / relations).  counts [n_types + n_rels] = list lengths.  Quirk kept: edge_index holds the
+ * neighbour's index inside its column (budget_sampling.rs:116). */
+typedef struct {
+    int32_t n_types, n_rels, n_hops;
+    int32_t filter_on, forward, relative;
+    int64_t win_lo, win_hi;          /* half-open window (python.rs:541-548) */
+    const int32_t *rel_src, *rel_dst; /* host [n_rels] */
+    const tg_graph *graphs;           /* host [n_rels] CSC, timestamps optional */
+    const int64_t *num_neighbors;     /* host [n_types * n_hops] */
+    const int64_t *const *inputs;     /* host [n_types] device pointers (NULL where n_inputs[t] == 0) */
+    const int64_t *const *input_ts;   /* host [n_types] device pointers or NULL (timestamp -1) */
+    const int64_t *n_inputs;          /* host [n_types] */
+} tg_budget_problem;
+
+typedef struct {
+    int64_t *const *samples;    /* [n_types] device slabs [cap_nodes[t]] */
+    int64_t *const *sample_ts;
+    const int64_t *cap_nodes;
+    int64_t *const *rows;       /* [n_rels] device slabs [cap_edges[r]] */
+    int64_t *const *cols;
+    int64_t *const *edge_index;
+    const int64_t *cap_edges;
+    int64_t *counts;            /* device [n_types + n_rels] */
+} tg_budget_out;
+
+TG_API int tg_budget_capacity(const tg_budget_problem *problem, int64_t *cap_nodes, int64_t *cap_edges);
+TG_API int tg_budget_workspace_bytes(const tg_budget_problem *problem, int64_t *bytes);
+TG_API int tg_budget_sample(const tg_budget_problem *problem, const tg_rng *rng, const tg_budget_out *out, void *workspace,
+                            int64_t workspace_bytes, void *stream);
+
 /* ---- synthetic inputs of the measurement harness ---- */
 
 /* R-MAT edge list: n_edges edges over 2^scale vertices, (a,b,c,d) =

@@ -93,6 +93,110 @@ py::tuple budget_sampling(const std::vector<std::string> &node_types,
         in.win_lo = w.first;
         in.win_hi = w.second;
     }
+    // ---- the whole operator in one stream-ordered call (tg_budget_sample): no host bookkeeping, one read-back
+    bool fused = T <= 8 && R <= 16 && H <= TG_MAX_HOPS;
+    std::vector<int64_t> quota((size_t)std::max(T * H, 1), 0);
+    for (int t = 0; t < T && H > 0; ++t) {
+        const std::string &name = node_types[(size_t)t];
+        if (!num_neighbors.contains(py::str(name)))
+            throw std::runtime_error("budget_sampling: num_neighbors has no entry for node type " + name +
+                                     " (the reference panics here, budget_sampling.rs:226)");
+        auto q = num_neighbors[py::str(name)].cast<std::vector<int64_t>>();
+        if ((int64_t)q.size() < H) throw py::index_error("num_neighbors[" + name + "] is shorter than num_hops");
+        for (int h = 0; h < H; ++h) {
+            quota[(size_t)(t * H + h)] = q[(size_t)h];
+            if (q[(size_t)h] < 0 || q[(size_t)h] > 64) fused = false;
+        }
+    }
+    if (fused) {
+        std::vector<int32_t> rs((size_t)std::max(R, 1)), rd((size_t)std::max(R, 1));
+        std::vector<tg_graph> graphs((size_t)std::max(R, 1));
+        for (int r = 0; r < R; ++r) {
+            const Rel &rl = rels[(size_t)r];
+            rs[(size_t)r] = rl.src;
+            rd[(size_t)r] = rl.dst;
+            tg_graph g{};
+            g.ptrs = rl.ptrs.data_ptr<int64_t>();
+            g.indices = rl.idx.numel() ? rl.idx.data_ptr<int64_t>() : nullptr;
+            g.timestamps = rl.ts.defined() ? rl.ts.data_ptr<int64_t>() : nullptr;
+            g.n_major = rl.ptrs.numel() - 1;
+            g.n_edges = rl.idx.numel();
+            graphs[(size_t)r] = g;
+        }
+        std::vector<const int64_t *> in_ptr((size_t)T, nullptr), in_ts_ptr((size_t)T, nullptr);
+        std::vector<int64_t> n_in((size_t)T, 0), cap_n((size_t)T, 0), cap_e((size_t)std::max(R, 1), 0);
+        for (int t = 0; t < T; ++t) {
+            n_in[(size_t)t] = frontier[(size_t)t].numel();
+            if (n_in[(size_t)t]) {
+                in_ptr[(size_t)t] = frontier[(size_t)t].data_ptr<int64_t>();
+                in_ts_ptr[(size_t)t] = frontier_ts[(size_t)t].data_ptr<int64_t>();
+            }
+        }
+        tg_budget_problem pb{};
+        pb.n_types = T;
+        pb.n_rels = R;
+        pb.n_hops = H;
+        pb.filter_on = in.filter_on;
+        pb.forward = in.forward;
+        pb.relative = in.relative;
+        pb.win_lo = in.win_lo;
+        pb.win_hi = in.win_hi;
+        pb.rel_src = rs.data();
+        pb.rel_dst = rd.data();
+        pb.graphs = graphs.data();
+        pb.num_neighbors = quota.data();
+        pb.inputs = in_ptr.data();
+        pb.input_ts = in_ts_ptr.data();
+        pb.n_inputs = n_in.data();
+        check_rc(tg_budget_capacity(&pb, cap_n.data(), cap_e.data()));
+        int64_t ws_bytes = 0;
+        check_rc(tg_budget_workspace_bytes(&pb, &ws_bytes));
+        Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
+        std::vector<Tensor> S((size_t)T), TS((size_t)T), RW((size_t)R), CL((size_t)R), EI((size_t)R);
+        std::vector<int64_t *> s_ptr((size_t)T), ts_ptr((size_t)T), r_ptr((size_t)std::max(R, 1)), c_ptr((size_t)std::max(R, 1)),
+            e_ptr((size_t)std::max(R, 1));
+        for (int t = 0; t < T; ++t) {
+            S[(size_t)t] = at::empty({std::max<int64_t>(cap_n[(size_t)t], 1)}, i64(dev));
+            TS[(size_t)t] = at::empty({std::max<int64_t>(cap_n[(size_t)t], 1)}, i64(dev));
+            s_ptr[(size_t)t] = S[(size_t)t].data_ptr<int64_t>();
+            ts_ptr[(size_t)t] = TS[(size_t)t].data_ptr<int64_t>();
+        }
+        for (int r = 0; r < R; ++r) {
+            const int64_t c = std::max<int64_t>(cap_e[(size_t)r], 1);
+            RW[(size_t)r] = at::empty({c}, i64(dev));
+            CL[(size_t)r] = at::empty({c}, i64(dev));
+            EI[(size_t)r] = at::empty({c}, i64(dev));
+            r_ptr[(size_t)r] = RW[(size_t)r].data_ptr<int64_t>();
+            c_ptr[(size_t)r] = CL[(size_t)r].data_ptr<int64_t>();
+            e_ptr[(size_t)r] = EI[(size_t)r].data_ptr<int64_t>();
+        }
+        Tensor counts = at::zeros({T + R + 1}, i64(dev));
+        tg_budget_out o{};
+        o.samples = s_ptr.data();
+        o.sample_ts = ts_ptr.data();
+        o.cap_nodes = cap_n.data();
+        o.rows = r_ptr.data();
+        o.cols = c_ptr.data();
+        o.edge_index = e_ptr.data();
+        o.cap_edges = cap_e.data();
+        o.counts = counts.data_ptr<int64_t>();
+        check_rc(tg_budget_sample(&pb, &rng, &o, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
+        Tensor c = to_host(counts); // the call's only synchronisation
+        const int64_t *ch = c.data_ptr<int64_t>();
+        py::dict d_samples, d_ts, d_rows, d_cols, d_eidx;
+        for (int t = 0; t < T; ++t) {
+            d_samples[py::str(node_types[(size_t)t])] = back(S[(size_t)t].narrow(0, 0, ch[t]), out_dev);
+            d_ts[py::str(node_types[(size_t)t])] = back(TS[(size_t)t].narrow(0, 0, ch[t]), out_dev);
+        }
+        for (int r = 0; r < R; ++r) {
+            const int64_t ne = ch[T + r];
+            d_rows[py::str(rels[(size_t)r].key)] = back(RW[(size_t)r].narrow(0, 0, ne), out_dev);
+            d_cols[py::str(rels[(size_t)r].key)] = back(CL[(size_t)r].narrow(0, 0, ne), out_dev);
+            d_eidx[py::str(rels[(size_t)r].key)] = back(EI[(size_t)r].narrow(0, 0, ne), out_dev);
+        }
+        return py::make_tuple(d_samples, d_ts, d_rows, d_cols, d_eidx);
+    }
+
     for (int layer = 0; layer < H; ++layer) { // :223
         for (int t = 0; t < T; ++t) {
             new_chunks[(size_t)t].clear();
