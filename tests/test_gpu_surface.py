@@ -258,3 +258,47 @@ def test_filtered_and_weighted_fanouts_above_64(tg, k):
             assert np.array_equal(_np(a), b), (k, kw.get("sampler"))
     with pytest.raises(ValueError):
         tg.neighbor_sampling_homogenous(P, I, S, [1025], None, flt)
+
+
+def test_concurrent_callers_on_their_own_streams(tg):
+    """worker threads (each with its own HIP stream) call the surface at once: every result is a valid sample of some
+    call id of the shared counter, and every call id is used exactly once"""
+    import threading
+    ei, n = load_karate()
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    P, I = torch.from_numpy(ptrs).cuda(), torch.from_numpy(idx).cuda()
+    seeds = np.array([0, 1, 4, 5])
+    S = torch.from_numpy(seeds).cuda()
+    tg.seed(123)
+    n_threads, per = 4, 15
+    results, errors = [[] for _ in range(n_threads)], []
+
+    def work(t):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(per):
+                    o = tg.neighbor_sampling_homogenous(P, I, S, [4, 3])
+                    st.synchronize()
+                    results[t].append(tuple(x.cpu().numpy() for x in o[:4]) + (o[4],))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    expected = {}
+    for c in range(n_threads * per):
+        o = orc.ns_homo(ptrs, idx, seeds, [4, 3], orc.rng_philox(123, c))
+        expected[c] = o
+    used = set()
+    for t in range(n_threads):
+        for s, r, c_, e, lo in results[t]:
+            match = [c for c, o in expected.items() if c not in used and np.array_equal(o[0], s) and np.array_equal(o[3], e)
+                     and np.array_equal(o[1], r) and np.array_equal(o[2], c_) and o[4] == lo]
+            assert match, "a concurrent call returned something no call id of the counter produces"
+            used.add(match[0])
+    assert len(used) == n_threads * per and tg.rng_state()[1] == n_threads * per
