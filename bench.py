@@ -34,6 +34,7 @@ def parse_args():
                     help="independent 1024-seed mini-batches sampled by the one launch of a step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE cfg3 / cfg4")
     ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")
     ap.add_argument("--ptr32", type=int, default=1, help="also keep a u32 shadow of `ptrs`")
     return ap.parse_args()
@@ -184,12 +185,67 @@ def main():
         },
     }
 
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del out
+        torch.cuda.empty_cache()
+        result["secondary"] = secondary_configs(torch, _cabi, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary_configs(torch, _cabi, dev):
+    """Short runs of the other BASELINE.json configurations on this box (reported beside the headline, never part of
+    `value`): cfg3 random_walk 1 M x 80 on RMAT-24, cfg4 heterogeneous sampling (3 node types / 5 relations)."""
+    sec = {}
+
+    def timed(fn, reps=3):
+        fn(0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(reps):
+            o = fn(r + 1)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, o
+
+    try:  # cfg3
+        n = 1 << 24
+        row, col = _cabi.rmat_edges(24, n * 16, 0x5EED0000 + 24, dev)
+        ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, False)
+        del row, col
+        start = _cabi.seed_batches(0x57A27, 0, 1, 1 << 20, n, dev)[0].contiguous()
+        g = _cabi.graph_view(ptrs, idx)
+        ms, w = timed(lambda c: _cabi.random_walk(g, start, 80, 1.0, 1.0, 0, c))
+        steps = int((w[:, 1:] >= 0).sum().item())
+        sec["cfg3_random_walk_1M_x_80_p1_q1"] = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3}
+        del ptrs, idx, w, g
+    except Exception as e:  # noqa: BLE001  (a secondary run must never cost the headline line)
+        sec["cfg3_random_walk_1M_x_80_p1_q1"] = {"error": repr(e)}
+    try:  # cfg4
+        torch.cuda.empty_cache()
+        scales = {"A": 23, "B": 22, "C": 22}
+        ets = [("A", "A"), ("A", "B"), ("B", "A"), ("B", "C"), ("C", "A")]
+        tix = {"A": 0, "B": 1, "C": 2}
+        rels = []
+        for r, (s_, d_) in enumerate(ets):
+            rw, cl = _cabi.rmat_edges_rect(scales[s_], scales[d_], 20_000_000, 0xC0F4 + r, dev)
+            p_, i_, _ = _cabi.coo_to_csx(rw, cl, 1 << scales[s_], 1 << scales[d_], True)
+            rels.append((tix[s_], tix[d_], p_, i_, [15, 10]))
+        nb = 512
+        sd = _cabi.seed_batches(0xBA7C4, 5000, nb, 1024, 1 << 23, dev)
+        hb = _cabi.NsHeteroBatched(3, rels, [sd, None, None], 2, nb, dev)
+        ms, _ = timed(lambda c: hb.run(0, c * nb))
+        ne = int(hb.counts[:, 3:].sum().item())
+        sec["cfg4_neighbor_sampling_heterogenous_512_batches"] = {"ms_per_launch": ms, "sampled_edges": ne,
+                                                                  "edges_per_s": ne / ms * 1e3}
+    except Exception as e:  # noqa: BLE001
+        sec["cfg4_neighbor_sampling_heterogenous_512_batches"] = {"error": repr(e)}
+    return sec
 
 
 def cpu_baseline(args, ptrs, indices, seeds, fanout):
