@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE cfg3 / cfg4")
     ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")
     ap.add_argument("--ptr32", type=int, default=1, help="also keep a u32 shadow of `ptrs`")
+    ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
+                    help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
     return ap.parse_args()
 
 
@@ -92,6 +94,8 @@ def main():
     n_pool = max(1, min(W + K, 32))
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
     out = _cabi.NsBatchedOut(G, B, fanout, dev)
+    form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
+    ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
     acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
 
     def run(lo, hi, events=None):
@@ -100,7 +104,7 @@ def main():
             if events is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            _cabi.ns_homo_batched(graph, seeds[s0:s0 + G], fanout, 0, first + i * G, out)
+            _cabi.ns_homo_batched(graph, seeds[s0:s0 + G], fanout, 0, first + i * G, out, ws=ws, form=form)
             if events is not None:
                 ev1.record()
                 events.append((ev0, ev1))

@@ -125,6 +125,24 @@ TG_API int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t
                        const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                        const tg_ns_out *out, void *stream);
 
+/* The same operator with a caller-provided workspace (tg_ns_homo_workspace_bytes; 256-byte aligned).  With it, a
+ * launch of many batches (unweighted, unfiltered samplers, fan-outs <= TG_MAX_FANOUT) runs hop by hop over the whole
+ * device and issues the `indices[edge_ptr]` gathers of a hop in ADDRESS order (items of the hop's frontier
+ * counting-sorted by window of their column start, windows dealt to XCDs), so that each 128-byte line of `indices` is
+ * fetched about once per hop instead of once per sampled neighbour.  Outputs are identical to tg_ns_homo_batched
+ * (output positions are fixed by per-batch prefix sums, neighbor_sampling.rs:212-217); launches that do not qualify
+ * fall through to it.  workspace == NULL is tg_ns_homo_batched.  `mode`: TG_NS_FORM_AUTO picks the form by launch size
+ * (many batches against a graph far larger than the L2s), _WINDOWED takes it whenever the launch qualifies, _FUSED never. */
+#define TG_NS_FORM_AUTO 0
+#define TG_NS_FORM_WINDOWED 1
+#define TG_NS_FORM_FUSED 2
+#define TG_NS_FORM_WINDOWED_WIDE 3 /* _WINDOWED with the 24-byte work items that launches beyond 32-bit offsets use */
+TG_API int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
+                               int64_t *n_bytes);
+TG_API int tg_ns_homo_batched_ws(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                          const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                          const tg_ns_out *out, void *workspace, int64_t workspace_bytes, int32_t mode, void *stream);
+
 /* One hop of the unweighted, unfiltered sampler over a flat frontier, spread over the whole device (the
  * per-vertex work of neighbor_sampling.rs:195-218 without the per-batch bookkeeping).  Used where the frontier
  * is not "one seed batch": the owner side of the range-partitioned sampler, relation-hops of the heterogeneous

@@ -262,9 +262,11 @@ template <int KMAX, bool REPLACE, bool NT>
 static int launch_uniform_nt(const NsHomoParams &p, int64_t n_batches, hipStream_t stream) {
     // few batches: wide workgroups for latency; many batches: narrow ones for occupancy
     int threads = (n_batches < 512) ? 1024 : 512;
-    const int forced = env_int("TG_NS_THREADS", 0); // tuning knob
+    static const int forced = env_int("TG_NS_THREADS", 0); // tuning knob, read once
     if (forced >= 64 && forced <= 1024 && forced % 64 == 0) threads = forced;
-    while (threads > 64 && ns_block_lds_bytes(p.kmax, threads / 64, KMAX == 0) > 64 * 1024) threads >>= 1; // LDS limit
+    while (threads > 64 && ns_block_lds_bytes(p.kmax, threads / 64, KMAX == 0) > 64 * 1024) // LDS limit
+        threads = ((threads >> 1) + 63) & ~63; // stays a whole number of wavefronts (n_waves = blockDim.x >> 6)
+    if (threads % 64 != 0) return fail(TG_ERR_INVALID, "tg_ns_homo_batched: %d threads is not a multiple of 64", threads);
     const size_t lds = ns_block_lds_bytes(p.kmax, threads / 64, KMAX == 0);
     if (lds > 160 * 1024)
         return fail(TG_ERR_UNSUPPORTED, "tg_ns_homo_batched: fan-out %d needs %zu B of LDS per wavefront", p.kmax, lds);
@@ -278,8 +280,9 @@ static int launch_uniform_nt(const NsHomoParams &p, int64_t n_batches, hipStream
 }
 template <int KMAX, bool REPLACE>
 static int launch_uniform(const NsHomoParams &p, int64_t n_batches, hipStream_t stream) {
-    return env_int("TG_NS_NT", 1) ? launch_uniform_nt<KMAX, REPLACE, true>(p, n_batches, stream)
-                                  : launch_uniform_nt<KMAX, REPLACE, false>(p, n_batches, stream);
+    static const int nt = env_int("TG_NS_NT", 1); // read once
+    return nt ? launch_uniform_nt<KMAX, REPLACE, true>(p, n_batches, stream)
+              : launch_uniform_nt<KMAX, REPLACE, false>(p, n_batches, stream);
 }
 
 } // namespace tg
@@ -304,9 +307,16 @@ int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_
                                const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                                const tg_ns_out *out, hipStream_t stream); // ns_homo_scan.hip
 
-extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
-                                  const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
-                                  const tg_ns_out *out, void *stream) {
+int tg_ns_homo_windowed_applicable(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                   int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out,
+                                   int32_t mode); // ns_homo_win.hip
+int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                               const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                               const tg_ns_out *out, void *ws, int64_t ws_bytes, int32_t mode, hipStream_t stream);
+
+static int ns_homo_batched_impl(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                                const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                                const tg_ns_out *out, void *ws, int64_t ws_bytes, int32_t mode, void *stream) {
     TG_REQUIRE(csc && csc->ptrs && (csc->indices || csc->n_edges == 0), "tg_ns_homo_batched: null graph");
     TG_REQUIRE(rng && out, "tg_ns_homo_batched: null rng/out");
     TG_REQUIRE(n_batches >= 0 && n_seeds >= 0, "tg_ns_homo_batched: negative sizes");
@@ -334,6 +344,10 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
     if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE)
         return tg_ns_homo_filtered_launch(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out,
                                           (hipStream_t)stream);
+
+    if (ws && tg_ns_homo_windowed_applicable(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, mode))
+        return tg_ns_homo_windowed_launch(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out, ws, ws_bytes,
+                                          mode, (hipStream_t)stream);
 
     tg::NsHomoParams p;
     p.ptrs = csc->ptrs;
@@ -375,4 +389,20 @@ extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int
         return repl ? tg::launch_uniform<32, true>(p, n_batches, s) : tg::launch_uniform<32, false>(p, n_batches, s);
     // above the register-resident sampler: ticket strips in LDS (any fan-out the LDS can hold)
     return repl ? tg::launch_uniform<0, true>(p, n_batches, s) : tg::launch_uniform<0, false>(p, n_batches, s);
+}
+
+extern "C" int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                                  const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                                  const tg_ns_out *out, void *stream) {
+    return ns_homo_batched_impl(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out, nullptr, 0, 0, stream);
+}
+
+extern "C" int tg_ns_homo_batched_ws(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                                     const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                                     const tg_ns_out *out, void *workspace, int64_t workspace_bytes, int32_t mode,
+                                     void *stream) {
+    TG_REQUIRE(workspace || workspace_bytes == 0, "tg_ns_homo_batched_ws: null workspace");
+    TG_REQUIRE(mode >= TG_NS_FORM_AUTO && mode <= TG_NS_FORM_WINDOWED_WIDE, "tg_ns_homo_batched_ws: bad mode %d", mode);
+    return ns_homo_batched_impl(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out, workspace,
+                                workspace_bytes, mode, stream);
 }

@@ -1,0 +1,638 @@
+// neighbor_sampling_homogenous, window-ordered form of the launch-wide gather (gfx950).
+//
+// Same outputs as ns_homo.hip (the fused per-batch kernel), for launches of MANY seed batches.  The fused kernel
+// issues `indices[edge_ptr]` in batch order: on RMAT-24 a 4 096-batch launch makes 120.8 M 4-byte gathers into 8.3 M
+// distinct 128-byte lines (~14.6 touches per line) in an order no cache holds, so ~12 of its 13 GB of reads are
+// re-fetches (a random 4-byte gather costs a whole line request whether HBM or the Infinity Cache serves it: 55 G
+// requests/s; only an L2 hit is cheaper, 258 G/s -- tools/probe_gather_sizes.py).  Here the gathers of a hop are
+// brought into ADDRESS order instead, hop by hop over the whole device:
+//
+//   K1  win_count_kernel   (one workgroup per batch): per frontier vertex the column bounds and sample count, LDS scan
+//                          -> every vertex's output offset; writes rows / cols -- which need neither draws nor
+//                          gathers -- as coalesced streams and one ITEM per frontier vertex (column start, degree,
+//                          batch, slot, output offset: 16 bytes, 24 for graphs / launches beyond 32-bit offsets).
+//   P1-3 win_hist / win_colscan / win_basescan / win_scatter: one counting-sort pass of the hop's items by WINDOW of
+//                          the column start (window = 2^shift edge pointers = a few hundred KB of `indices`), laid
+//                          out XCD-major (windows x, x+8, x+16 ... form queue x); no global atomics.
+//   K4  win_gather_kernel  (persistent; the blocks of one XCD sweep that XCD's queue in order, a block reserving the
+//                          next slice with one atomic): draws the item's positions (counter-addressed Philox, the
+//                          same draws as the fused kernel), gathers `indices[e0 + pos]` -- now L2 hits, every line
+//                          of a window is fetched by ONE XCD about once -- and writes samples[n_seeds + e ...] and
+//                          edge_index[e ...] in the reference's slot order.
+//
+// neighbor_sampling.rs:188-223 is unchanged in meaning: the output position of every edge is fixed by the per-batch
+// prefix sums of K1, so the ORDER in which items are gathered cannot change a single output word (tests compare this
+// path with the fused kernel and the oracle bit for bit).
+#include <stdlib.h>
+
+#include "ns_tickets.h"
+#include "tg_device.h"
+#include "tg_host.h"
+
+namespace tg {
+
+constexpr int WIN_PART_BLOCKS = 512;  // blocks of the partition kernels = rows of the histogram matrix
+constexpr int WIN_PART_THREADS = 512;
+constexpr int WIN_TILE = 4096;        // items per partition tile
+constexpr int WIN_MAX_BUCKETS = 8192; // windows per hop (LDS: 32 KB of counters)
+constexpr int WIN_CHUNKS_PER_ROUND = 1024;
+
+struct WinState { // per batch, lives in the workspace
+    int64_t begin, end, ne, fbase;
+};
+
+struct WinQueues { // items of XCD-group x in the sorted array: [head, end); one 256-byte line per group
+    struct alignas(256) Q {
+        unsigned long long head, end;
+    } q[8];
+};
+
+struct WinParams {
+    const int64_t *ptrs;
+    const int64_t *indices;
+    const uint32_t *indices32;
+    const uint32_t *ptrs32;
+    const int64_t *seeds;
+    int64_t n_seeds;
+    int32_t n_hops, hop, k, kmax;
+    int64_t cap_nodes, cap_edges;
+    int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts;
+    uint64_t seed, call_id;
+    uint32_t tag;
+    int64_t id_base;
+    // workspace
+    WinState *state;
+    CallKey *call_keys;          // [n_batches] Philox key of batch b's draws
+    unsigned long long *n_items; // [TG_MAX_HOPS] items written by K1 of each hop
+    void *items_in, *items_sorted;
+    uint32_t *hist; // [WIN_PART_BLOCKS][n_buckets]
+    uint32_t *base; // [n_buckets + 1]
+    WinQueues *queues;
+    int32_t n_buckets, shift; // bucket count (multiple of 8), window = e0 >> shift
+    int32_t slot_bits;        // narrow items: slot in the low bits, batch above
+};
+
+// One frontier vertex with something to sample.  Narrow form: launches whose edge pointers and per-batch offsets fit 32
+// bits and whose (batch, slot) pair packs into one word.
+struct WinItemN {
+    uint32_t e0, deg, bs, e;
+    __device__ __forceinline__ static WinItemN make(uint64_t e0, uint32_t deg, uint32_t b, uint32_t slot, uint32_t e,
+                                                    int slot_bits) {
+        return WinItemN{(uint32_t)e0, deg, (b << slot_bits) | slot, e};
+    }
+    __device__ __forceinline__ uint64_t col() const { return e0; }
+    __device__ __forceinline__ uint32_t batch(int slot_bits) const { return bs >> slot_bits; }
+    __device__ __forceinline__ uint32_t slot(int slot_bits) const { return bs & ((1u << slot_bits) - 1u); }
+};
+struct WinItemW {
+    uint64_t e0;
+    uint32_t deg, b, s, e;
+    __device__ __forceinline__ static WinItemW make(uint64_t e0, uint32_t deg, uint32_t b, uint32_t slot, uint32_t e,
+                                                    int) {
+        return WinItemW{e0, deg, b, slot, e};
+    }
+    __device__ __forceinline__ uint64_t col() const { return e0; }
+    __device__ __forceinline__ uint32_t batch(int) const { return b; }
+    __device__ __forceinline__ uint32_t slot(int) const { return s; }
+};
+static_assert(sizeof(WinItemN) == 16 && sizeof(WinItemW) == 24, "item layouts");
+
+__device__ __forceinline__ uint32_t win_bucket(uint64_t e0, int shift, int n_buckets) {
+    const uint32_t w = (uint32_t)(e0 >> shift);
+    return (w & 7u) * (uint32_t)(n_buckets >> 3) + (w >> 3); // XCD-major
+}
+
+// ---------------------------------------------------------------- init: seeds -> samples, per-batch state and keys
+__global__ void win_init_kernel(const WinParams p, int64_t n_batches) {
+    const int64_t b = blockIdx.x;
+    int64_t *samples = p.samples + b * p.cap_nodes;
+    for (int64_t i = threadIdx.x; i < p.n_seeds; i += blockDim.x) samples[i] = p.seeds[b * p.n_seeds + i]; // :184
+    if (threadIdx.x == 0) {
+        p.state[b] = WinState{0, p.n_seeds, 0, 0};
+        p.call_keys[b] = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
+        if (p.n_hops == 0) {
+            p.counts[b * 2 + 0] = p.n_seeds;
+            p.counts[b * 2 + 1] = 0;
+        }
+        if (b == 0)
+            for (int h = 0; h < TG_MAX_HOPS; ++h) p.n_items[h] = 0ull;
+    }
+}
+
+// K1's LDS: chunk offsets | fbase | per wave: the lane of every output of the chunk [64*k] u8
+__host__ __device__ inline size_t win_count_lds_bytes(int kmax, int n_waves) {
+    return (((size_t)(WIN_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
+           (size_t)n_waves * (((size_t)64 * kmax + 15) & ~(size_t)15);
+}
+
+// ---------------------------------------------------------------- K1: counts, offsets, rows / cols streams, items
+template <typename Item, bool REPLACE>
+__global__ void win_count_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int64_t b = blockIdx.x;
+    uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
+    const size_t head_bytes = (((size_t)(WIN_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    int64_t *shared_fbase = reinterpret_cast<int64_t *>(smem + head_bytes);
+    uint8_t *slane = smem + head_bytes + 16 + (size_t)wave * (((size_t)64 * p.kmax + 15) & ~(size_t)15);
+    Item *items = static_cast<Item *>(p.items_in);
+
+    const int64_t *samples = p.samples + b * p.cap_nodes;
+    int64_t *rows = p.rows + b * p.cap_edges;
+    int64_t *cols = p.cols + b * p.cap_edges;
+    const int64_t n_seeds = p.n_seeds;
+    const int k = p.k;
+    const WinState st = p.state[b];
+    const int64_t begin = st.begin, end = st.end;
+    int64_t ne = st.ne;
+
+    if (tid == 0) {
+        int64_t *lo = p.layer_offsets + (b * p.n_hops + p.hop) * 3; // :193
+        lo[0] = n_seeds + ne;
+        lo[1] = ne;
+        lo[2] = n_seeds + ne;
+        // this batch's range of the hop's flat item array (order between batches does not matter)
+        *shared_fbase = (int64_t)atomicAdd(&p.n_items[p.hop], (unsigned long long)(end - begin));
+    }
+    __syncthreads();
+    const int64_t fbase = *shared_fbase;
+
+    for (int64_t round_begin = begin; round_begin < end; round_begin += (int64_t)WIN_CHUNKS_PER_ROUND * 64) {
+        const int64_t round_end = min(end, round_begin + (int64_t)WIN_CHUNKS_PER_ROUND * 64);
+        const int nc = (int)((round_end - round_begin + 63) >> 6);
+        for (int c = wave; c < nc; c += n_waves) { // pass A: per-chunk sample counts
+            const int64_t i = round_begin + (int64_t)c * 64 + lane;
+            uint32_t cnt = 0;
+            if (i < round_end) {
+                const int64_t w = samples[i];
+                const int64_t deg = p.ptrs32 ? (int64_t)(p.ptrs32[w + 1] - p.ptrs32[w]) : p.ptrs[w + 1] - p.ptrs[w];
+                cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+            }
+            const uint32_t tot = wave_sum(cnt);
+            if (lane == 0) chunk_off[c] = tot;
+        }
+        __syncthreads();
+        if (wave == 0) { // scan of chunk totals
+            uint32_t carry = 0;
+            for (int c0 = 0; c0 < nc; c0 += 64) {
+                const uint32_t v = (c0 + lane < nc) ? chunk_off[c0 + lane] : 0u;
+                const uint32_t incl = wave_inclusive_scan(v);
+                if (c0 + lane < nc) chunk_off[c0 + lane] = carry + incl - v;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) chunk_off[nc] = carry;
+        }
+        __syncthreads();
+        for (int c = wave; c < nc; c += n_waves) { // pass B: offsets, items, the two streams
+            const int64_t i0 = round_begin + (int64_t)c * 64;
+            const int64_t i = i0 + lane;
+            int64_t e0 = 0, deg = 0;
+            if (i < round_end) {
+                const int64_t w = samples[i];
+                if (p.ptrs32) {
+                    e0 = (int64_t)p.ptrs32[w];
+                    deg = (int64_t)p.ptrs32[w + 1] - e0;
+                } else {
+                    e0 = p.ptrs[w];
+                    deg = p.ptrs[w + 1] - e0;
+                }
+            }
+            const uint32_t cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+            const uint32_t incl = wave_inclusive_scan(cnt);
+            const uint32_t excl = incl - cnt;
+            const uint32_t total = __shfl(incl, 63, 64);
+            const int64_t e_chunk = ne + (int64_t)chunk_off[c];
+            if (i < round_end)
+                items[fbase + (i - begin)] = Item::make((uint64_t)e0, cnt ? (uint32_t)deg : 0u, (uint32_t)b,
+                                                        (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
+            for (uint32_t s = 0; s < cnt; ++s) slane[excl + s] = (uint8_t)lane;
+            wave_lds_handoff();
+            for (uint32_t q = lane; q < total; q += 64) { // two write-once streams, coalesced (:217)
+                const int64_t e = e_chunk + q;
+                __builtin_nontemporal_store(n_seeds + e, &rows[e]);
+                __builtin_nontemporal_store(i0 + (int64_t)slane[q], &cols[e]);
+            }
+            wave_lds_handoff();
+        }
+        __syncthreads();
+        ne += chunk_off[nc];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.state[b] = WinState{end, n_seeds + ne, ne, fbase}; // :221-222
+        if (p.hop == p.n_hops - 1) {
+            p.counts[b * 2 + 0] = n_seeds + ne;
+            p.counts[b * 2 + 1] = ne;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- P1: per-block bucket histogram of the hop's items
+template <typename Item>
+__global__ void __launch_bounds__(WIN_PART_THREADS) win_hist_kernel(const WinParams p) {
+    __shared__ uint32_t h[WIN_MAX_BUCKETS];
+    const int nb = p.n_buckets;
+    const Item *items = static_cast<const Item *>(p.items_in);
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint64_t n = p.n_items[p.hop];
+    for (uint64_t t0 = (uint64_t)blockIdx.x * WIN_TILE; t0 < n; t0 += (uint64_t)gridDim.x * WIN_TILE) {
+        for (uint64_t j = t0 + threadIdx.x; j < min(n, t0 + WIN_TILE); j += blockDim.x) {
+            const Item it = items[j];
+            if (it.deg) atomicAdd(&h[win_bucket(it.col(), p.shift, nb)], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *row = p.hist + (size_t)blockIdx.x * nb;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) row[i] = h[i];
+}
+
+// ---------------------------------------------------------------- P2a: per bucket, exclusive running sum over the blocks
+// block = 64 buckets x 16 row groups: a thread sums its 32 rows, the 16 partial sums of a bucket are scanned through LDS,
+// then the thread rewrites its rows as running offsets (depth 32 instead of 512 dependent steps)
+constexpr int WIN_SCAN_GROUPS = 16;
+__global__ void __launch_bounds__(64 * WIN_SCAN_GROUPS) win_colscan_kernel(const WinParams p, int n_rows) {
+    __shared__ uint32_t part[WIN_SCAN_GROUPS][64];
+    const int bl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int bkt = blockIdx.x * 64 + bl;
+    const int rows_per = (n_rows + WIN_SCAN_GROUPS - 1) / WIN_SCAN_GROUPS;
+    const int r0 = g * rows_per, r1 = min(n_rows, r0 + rows_per);
+    uint32_t sum = 0;
+    if (bkt < p.n_buckets)
+        for (int r = r0; r < r1; ++r) sum += p.hist[(size_t)r * p.n_buckets + bkt];
+    part[g][bl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int gg = 0; gg < g; ++gg) run += part[gg][bl];
+    if (bkt < p.n_buckets) {
+        for (int r = r0; r < r1; ++r) {
+            uint32_t *cell = p.hist + (size_t)r * p.n_buckets + bkt;
+            const uint32_t v = *cell;
+            *cell = run;
+            run += v;
+        }
+        if (g == WIN_SCAN_GROUPS - 1) p.base[bkt] = run; // column total (scanned in place by P2b)
+    }
+}
+
+// ---------------------------------------------------------------- P2b: bucket bases + the per-XCD queues (one block)
+__global__ void win_basescan_kernel(const WinParams p) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < p.n_buckets; c0 += blockDim.x) {
+        const int i = c0 + tid;
+        const uint32_t v = i < p.n_buckets ? p.base[i] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (i < p.n_buckets) p.base[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = carry_s;
+            for (int w = 0; w < nw; ++w) t += wave_tot[w];
+            carry_s = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) p.base[p.n_buckets] = carry_s;
+    __syncthreads();
+    if (tid < 8) { // queue x = buckets [x*nb/8, (x+1)*nb/8)
+        const int per = p.n_buckets >> 3;
+        p.queues->q[tid].head = p.base[tid * per];
+        p.queues->q[tid].end = p.base[(tid + 1) * per];
+    }
+}
+
+// ---------------------------------------------------------------- P3: scatter the items into window order
+template <typename Item>
+__global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter_kernel(const WinParams p) {
+    __shared__ uint32_t cur[WIN_MAX_BUCKETS];
+    const int nb = p.n_buckets;
+    const Item *items = static_cast<const Item *>(p.items_in);
+    Item *sorted = static_cast<Item *>(p.items_sorted);
+    const uint32_t *row = p.hist + (size_t)blockIdx.x * nb;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) cur[i] = p.base[i] + row[i];
+    __syncthreads();
+    const uint64_t n = p.n_items[p.hop];
+    constexpr int U = WIN_TILE / WIN_PART_THREADS; // items per thread and tile, all loads in flight together
+    for (uint64_t t0 = (uint64_t)blockIdx.x * WIN_TILE; t0 < n; t0 += (uint64_t)gridDim.x * WIN_TILE) {
+        Item it[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t j = t0 + (uint64_t)u * WIN_PART_THREADS + threadIdx.x;
+            it[u].deg = 0;
+            if (j < n) it[u] = items[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (it[u].deg) sorted[atomicAdd(&cur[win_bucket(it[u].col(), p.shift, nb)], 1u)] = it[u];
+    }
+}
+
+// ---------------------------------------------------------------- K4: window-ordered gather
+constexpr int WIN_EMIT = 4;
+
+// per wave: column start [64] i64 | samples base [64] i64 | edge base [64] i64 | staged positions [64*k] u32 | lanes u8
+__host__ __device__ inline size_t win_gather_wave_lds_bytes(int kmax) {
+    return 3 * 64 * sizeof(int64_t) + (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
+}
+
+// The staged (lane, position) pairs of one round are walked by consecutive lanes: gather the neighbour id, write it
+// and its edge pointer (neighbor_sampling.rs:211-217).  WIN_EMIT gathers per lane and batch, two batches in flight;
+// unconditional loads (lanes past the end re-read element 0's address and skip the stores).
+template <typename IDX>
+__device__ __forceinline__ void win_gather_chunk(const IDX *__restrict__ idx, uint32_t total, int lane,
+                                                 const uint8_t *slane, const uint32_t *spos, const int64_t *ebase,
+                                                 const int64_t *obase, const int64_t *xbase, int64_t *samples,
+                                                 int64_t *eidx) {
+    if (total == 0) return;
+    struct Batch {
+        int64_t o[WIN_EMIT], x[WIN_EMIT], ep[WIN_EMIT];
+        IDX v[WIN_EMIT];
+    };
+    auto issue = [&](Batch &t, uint32_t q0) {
+#pragma unroll
+        for (int u = 0; u < WIN_EMIT; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+            const uint32_t qq = q < total ? q : 0u;
+            const int l = slane[qq];
+            t.ep[u] = ebase[l] + (int64_t)spos[qq];
+            t.o[u] = obase[l] + (int64_t)qq; // bases already hold "minus the item's first q"
+            t.x[u] = xbase[l] + (int64_t)qq;
+        }
+#pragma unroll
+        for (int u = 0; u < WIN_EMIT; ++u) t.v[u] = idx[t.ep[u]];
+    };
+    auto store = [&](const Batch &t, uint32_t q0) {
+#pragma unroll
+        for (int u = 0; u < WIN_EMIT; ++u) {
+            const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+            if (q < total) {
+                samples[t.o[u]] = (int64_t)t.v[u];                   // :215 (the next hop's frontier)
+                __builtin_nontemporal_store(t.ep[u], &eidx[t.x[u]]); // :217 edge_ptr, write-once
+            }
+        }
+    };
+    Batch a, b;
+    issue(a, 0u);
+    for (uint32_t q0 = 0; q0 < total; q0 += 2u * 64u * WIN_EMIT) {
+        issue(b, q0 + 64u * WIN_EMIT);
+        store(a, q0);
+        issue(a, q0 + 2u * 64u * WIN_EMIT);
+        store(b, q0 + 64u * WIN_EMIT);
+    }
+}
+
+// Work split: blocks with equal blockIdx % 8 are observed to share an XCD (dispatch is round-robin; a speed matter
+// only), so group x = blockIdx % 8 sweeps queue x -- the windows w with w % 8 == x -- IN ORDER: a block takes the
+// queue's next slice of 64 items per wave with ONE agent-scope atomic (the following slice is reserved while the
+// current one is processed, so the atomic's latency is hidden), i.e. a few thousand atomics per queue, each queue head
+// on a line of its own.  At any time the group works inside a front of (blocks x 2 slices) items = a few windows,
+// which its XCD's 4 MB L2 holds: every line of `indices` is fetched from HBM about once per hop.  Every slice of
+// every queue goes to exactly one block whatever the placement.
+template <typename Item, int KMAX, bool REPLACE>
+__global__ void win_gather_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned long long slice_lo[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char *wbase = smem + (size_t)wave * win_gather_wave_lds_bytes(p.kmax);
+    int64_t *ebase = reinterpret_cast<int64_t *>(wbase);
+    int64_t *obase = ebase + 64, *xbase = ebase + 128;
+    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 192 * sizeof(int64_t));
+    uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 192 * sizeof(int64_t) + (size_t)64 * p.kmax * sizeof(uint32_t));
+    const Item *items = static_cast<const Item *>(p.items_sorted);
+    const int k = p.k;
+    WinQueues::Q *Q = &p.queues->q[blockIdx.x & 7];
+    const unsigned long long qend = Q->end;
+    const unsigned long long slice = blockDim.x; // 64 items per wave
+
+    if (tid == 0) slice_lo[0] = atomicAdd(&Q->head, slice);
+    __syncthreads();
+    for (int buf = 0;; buf ^= 1) {
+        const unsigned long long lo = slice_lo[buf];
+        if (lo >= qend) break; // uniform: every wave reads the same word
+        unsigned long long nxt = 0;
+        if (tid == 0) nxt = atomicAdd(&Q->head, slice); // used at the end of this slice
+        const unsigned long long j = lo + (unsigned long long)wave * 64 + lane;
+        Item it;
+        it.deg = 0;
+        if (j < qend) it = items[j];
+        const uint32_t n = it.deg;
+        const uint32_t cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        const uint32_t excl = incl - cnt;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (cnt > 0) {
+            const uint32_t b = it.batch(p.slot_bits);
+            const CallKey ck = p.call_keys[b];
+            const uint64_t did = (uint64_t)(p.id_base + (int64_t)it.slot(p.slot_bits));
+            ebase[lane] = (int64_t)it.col();
+            obase[lane] = (int64_t)b * p.cap_nodes + p.n_seeds + (int64_t)it.e - (int64_t)excl;
+            xbase[lane] = (int64_t)b * p.cap_edges + (int64_t)it.e - (int64_t)excl;
+            if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
+                Draw d;
+                for (int s = 0; s < k; ++s) {
+                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
+                    spos[excl + s] = bounded32(d.half(s & 1), n);
+                    slane[excl + s] = (uint8_t)lane;
+                }
+            } else if (n <= (uint32_t)k) { // sampling.rs:12-15: the reservoir is just filled
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    spos[excl + s] = s;
+                    slane[excl + s] = (uint8_t)lane;
+                }
+            } else {
+                sample_tickets<KMAX>(ck, did, n, k, spos, slane, excl, lane);
+            }
+        }
+        wave_lds_handoff();
+        if (p.indices32)
+            win_gather_chunk<uint32_t>(p.indices32, total, lane, slane, spos, ebase, obase, xbase, p.samples,
+                                       p.edge_index);
+        else
+            win_gather_chunk<int64_t>(p.indices, total, lane, slane, spos, ebase, obase, xbase, p.samples,
+                                      p.edge_index);
+        if (tid == 0) slice_lo[buf ^ 1] = nxt;
+        __syncthreads(); // the next slice's start is published; also fences this wave's LDS staging
+    }
+}
+
+static int win_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+struct WinLayout {
+    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, total;
+    int64_t max_items;
+};
+
+static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops) {
+    WinLayout L;
+    int64_t layer = n_seeds, widest = n_seeds;
+    for (int h = 0; h + 1 < n_hops; ++h) {
+        layer *= fanout[h];
+        if (layer > widest) widest = layer;
+    }
+    L.max_items = n_batches * widest;
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) & ~(size_t)255;
+        return here;
+    };
+    L.state = take((size_t)n_batches * sizeof(WinState));
+    L.call_keys = take((size_t)n_batches * sizeof(CallKey));
+    L.n_items = take(TG_MAX_HOPS * sizeof(unsigned long long));
+    L.queues = take(sizeof(WinQueues));
+    L.hist = take((size_t)WIN_PART_BLOCKS * WIN_MAX_BUCKETS * sizeof(uint32_t));
+    L.base = take((size_t)(WIN_MAX_BUCKETS + 1) * sizeof(uint32_t));
+    L.items_in = take((size_t)L.max_items * sizeof(WinItemW)); // sized for the wide form
+    L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
+    L.total = at;
+    return L;
+}
+
+template <typename Item, int KMAX, bool REPLACE>
+static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
+    static const int count_threads = win_env_int("TG_WIN_COUNT_THREADS", 512);
+    static const int gather_threads = win_env_int("TG_WIN_GATHER_THREADS", 512);
+    static const int gather_blocks = (win_env_int("TG_WIN_GATHER_BLOCKS", 256) + 7) & ~7; // 8 groups of equal size
+    hipLaunchKernelGGL(win_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, stream, p, n_batches);
+    TG_LAUNCH_CHECK();
+    for (int h = 0; h < n_hops; ++h) {
+        p.hop = h;
+        p.k = (int32_t)fanout[h];
+        int threads = count_threads;
+        while (threads > 64 && win_count_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
+        hipLaunchKernelGGL((win_count_kernel<Item, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
+                           win_count_lds_bytes(p.kmax, threads / 64), stream, p);
+        TG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(win_hist_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
+        TG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
+                           WIN_PART_BLOCKS);
+        TG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        TG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(win_scatter_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
+        TG_LAUNCH_CHECK();
+        int gthreads = gather_threads;
+        while (gthreads > 64 && (size_t)(gthreads / 64) * win_gather_wave_lds_bytes(p.kmax) > 64 * 1024)
+            gthreads = ((gthreads >> 1) + 63) & ~63;
+        hipLaunchKernelGGL((win_gather_kernel<Item, KMAX, REPLACE>), dim3(gather_blocks), dim3(gthreads),
+                           (size_t)(gthreads / 64) * win_gather_wave_lds_bytes(p.kmax), stream, p);
+        TG_LAUNCH_CHECK();
+    }
+    return TG_OK;
+}
+
+template <typename Item>
+static int win_dispatch(const WinParams &p, bool repl, int64_t n_batches, const int64_t *fanout, int32_t n_hops,
+                        hipStream_t stream) {
+    if (p.kmax <= 16)
+        return repl ? win_run<Item, 16, true>(p, n_batches, fanout, n_hops, stream)
+                    : win_run<Item, 16, false>(p, n_batches, fanout, n_hops, stream);
+    return repl ? win_run<Item, 32, true>(p, n_batches, fanout, n_hops, stream)
+                : win_run<Item, 32, false>(p, n_batches, fanout, n_hops, stream);
+}
+
+} // namespace tg
+
+extern "C" int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
+                                          int64_t *n_bytes) {
+    TG_REQUIRE(n_batches >= 0 && n_seeds >= 0 && n_hops >= 0 && n_hops <= TG_MAX_HOPS && (fanout || n_hops == 0) &&
+                   n_bytes,
+               "tg_ns_homo_workspace_bytes: bad arguments");
+    for (int h = 0; h < n_hops; ++h)
+        TG_REQUIRE(fanout[h] >= 1 && fanout[h] <= 255, "tg_ns_homo_workspace_bytes: fanout[%d] outside [1, 255]", h);
+    *n_bytes = (int64_t)tg::win_layout(n_batches, n_seeds, fanout, n_hops).total;
+    return TG_OK;
+}
+
+// Is the window-ordered form applicable / worth it for this launch?  (Same outputs either way.)
+int tg_ns_homo_windowed_applicable(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                   int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out, int32_t mode) {
+    if (mode == TG_NS_FORM_FUSED) return 0;
+    const int sampler = cfg ? cfg->sampler : TG_SAMPLER_UNIFORM;
+    const int filter = cfg ? cfg->filter_mode : TG_FILTER_NONE;
+    if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE) return 0;
+    if (cfg && (cfg->seed_ids || cfg->seed_call_ids)) return 0;
+    if (n_hops < 1 || n_batches < 1 || n_seeds < 1) return 0;
+    int kmax = 1;
+    for (int h = 0; h < n_hops; ++h) kmax = fanout[h] > kmax ? (int)fanout[h] : kmax;
+    if (kmax > TG_MAX_FANOUT) return 0;
+    const tg::WinLayout L = tg::win_layout(n_batches, n_seeds, fanout, n_hops);
+    if (L.max_items >= ((int64_t)1 << 32) || out->cap_nodes >= ((int64_t)1 << 32) || n_batches >= ((int64_t)1 << 32))
+        return 0;
+    if (mode == TG_NS_FORM_WINDOWED || mode == TG_NS_FORM_WINDOWED_WIDE) return 1;
+    // worth it when the launch's gathers revisit lines: many batches against a graph larger than the L2s
+    return n_batches * n_seeds >= ((int64_t)1 << 20) && csc->n_edges >= ((int64_t)1 << 24);
+}
+
+int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                               const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                               const tg_ns_out *out, void *ws, int64_t ws_bytes, int32_t mode, hipStream_t stream) {
+    using namespace tg;
+    const WinLayout L = win_layout(n_batches, n_seeds, fanout, n_hops);
+    TG_REQUIRE(ws && ws_bytes >= (int64_t)L.total, "tg_ns_homo_batched_ws: workspace too small (%lld < %lld bytes)",
+               (long long)ws_bytes, (long long)L.total);
+    TG_REQUIRE(((uintptr_t)ws & 255) == 0, "tg_ns_homo_batched_ws: workspace must be 256-byte aligned");
+    WinParams p;
+    p.ptrs = csc->ptrs;
+    p.indices = csc->indices;
+    p.indices32 = csc->indices32;
+    p.ptrs32 = csc->ptrs32;
+    p.seeds = seeds;
+    p.n_seeds = n_seeds;
+    p.n_hops = n_hops;
+    p.hop = 0;
+    p.k = 0;
+    p.kmax = 1;
+    for (int h = 0; h < n_hops; ++h) p.kmax = fanout[h] > p.kmax ? (int32_t)fanout[h] : p.kmax;
+    p.cap_nodes = out->cap_nodes;
+    p.cap_edges = out->cap_edges;
+    p.samples = out->samples;
+    p.rows = out->rows;
+    p.cols = out->cols;
+    p.edge_index = out->edge_index;
+    p.layer_offsets = out->layer_offsets;
+    p.counts = out->counts;
+    p.seed = rng->seed;
+    p.call_id = rng->call_id;
+    p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
+    p.id_base = cfg ? cfg->id_base : 0;
+    unsigned char *w = static_cast<unsigned char *>(ws);
+    p.state = reinterpret_cast<WinState *>(w + L.state);
+    p.call_keys = reinterpret_cast<CallKey *>(w + L.call_keys);
+    p.n_items = reinterpret_cast<unsigned long long *>(w + L.n_items);
+    p.queues = reinterpret_cast<WinQueues *>(w + L.queues);
+    p.hist = reinterpret_cast<uint32_t *>(w + L.hist);
+    p.base = reinterpret_cast<uint32_t *>(w + L.base);
+    p.items_in = w + L.items_in;
+    p.items_sorted = w + L.items_sorted;
+    // window size: a few hundred KB of the gathered array, at most WIN_MAX_BUCKETS windows
+    static const int window_kib = win_env_int("TG_WIN_KIB", 512);
+    const int elem = csc->indices32 ? 4 : 8;
+    int shift = 0;
+    while (((int64_t)elem << shift) < (int64_t)window_kib * 1024) ++shift;
+    while (((csc->n_edges >> shift) + 1) > WIN_MAX_BUCKETS - 8) ++shift;
+    p.shift = shift;
+    p.n_buckets = (int32_t)((((csc->n_edges >> shift) + 1) + 7) & ~(int64_t)7);
+    if (p.n_buckets < 8) p.n_buckets = 8;
+    // narrow items: 32-bit edge pointers and offsets, (batch, slot) in one word
+    int slot_bits = 1;
+    while (((int64_t)1 << slot_bits) < out->cap_nodes) ++slot_bits;
+    const bool narrow = csc->n_edges < ((int64_t)1 << 32) && out->cap_edges < ((int64_t)1 << 32) && slot_bits < 32 &&
+                        n_batches <= ((int64_t)1 << (32 - slot_bits));
+    const bool force_wide = mode == TG_NS_FORM_WINDOWED_WIDE;
+    p.slot_bits = slot_bits;
+    const bool repl = (cfg ? cfg->sampler : TG_SAMPLER_UNIFORM) == TG_SAMPLER_UNIFORM_REPL;
+    if (narrow && !force_wide) return win_dispatch<WinItemN>(p, repl, n_batches, fanout, n_hops, stream);
+    return win_dispatch<WinItemW>(p, repl, n_batches, fanout, n_hops, stream);
+}

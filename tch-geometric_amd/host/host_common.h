@@ -122,6 +122,32 @@ struct RangeCheck {
     }
 };
 
+// The values of an adjacency's `indices` become `ptrs[w]` look-ups one hop later (neighbor_sampling.rs:197-198,
+// random_walk.rs:41), where the reference panics on an id beyond the table and an unchecked kernel would read out of
+// bounds.  One pass over `indices` per graph, remembered by (address, length, bound) so that calls on a resident
+// graph pay nothing; a graph rebuilt at the same address with the same length is taken as already checked.
+inline void check_graph_ids(const Tensor &indices, int64_t hi, const c10::Device &dev, const char *what) {
+    struct Key {
+        const void *p;
+        int64_t n, hi;
+    };
+    static std::mutex mu;
+    static std::vector<Key> seen;
+    if (indices.numel() == 0) return;
+    const Key k{indices.data_ptr(), indices.numel(), hi};
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Key &s : seen)
+            if (s.p == k.p && s.n == k.n && s.hi == k.hi) return;
+    }
+    RangeCheck rc(dev);
+    rc.add(indices, hi);
+    rc.verify(what);
+    std::lock_guard<std::mutex> lock(mu);
+    if (seen.size() >= 64) seen.erase(seen.begin());
+    seen.push_back(k);
+}
+
 inline std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257
     return std::get<0>(e) + "__" + std::get<1>(e) + "__" + std::get<2>(e);
 }

@@ -272,6 +272,13 @@ std::tuple<Tensor, Tensor, Tensor> to_csx(const Tensor &row_col, const py::objec
     Tensor row = rc.select(0, 0).contiguous(), col = rc.select(0, 1).contiguous();
     const int64_t nnz = row.numel(), m = csc ? size1 : size0;
     if (size0 < 1 || size1 < 1) throw py::value_error("graph size must be positive");
+    {   // an id outside the graph would be mis-sorted silently (the sort keys only the bits a valid key needs); the
+        // reference's ind2ptr writes out of bounds and panics there (storage.rs:67-101)
+        RangeCheck rc(dev);
+        rc.add(row, size0);
+        rc.add(col, size1);
+        rc.verify("to_csc/to_csr row_col");
+    }
     Tensor ptrs = at::empty({m + 1}, i64(dev)), indices = at::empty({nnz}, i64(dev)), perm = at::empty({nnz}, i64(dev));
     int64_t ws_bytes = 0;
     check_rc(tg_coo_to_csx_workspace_bytes(nnz, size0, size1, &ws_bytes));
@@ -305,6 +312,7 @@ py::tuple neighbor_sampling_homogenous(const Tensor &col_ptrs, const Tensor &row
     RangeCheck rc(dev);
     rc.add(seeds, ptrs.numel() - 1);
     rc.verify("neighbor_sampling_homogenous inputs");
+    if (num_neighbors.size() > 1) check_graph_ids(idx, ptrs.numel() - 1, dev, "neighbor_sampling_homogenous row_indices");
     NsResult r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0);
     const c10::Device out_dev = inputs.device();
     return py::make_tuple(back(r.samples.narrow(0, 0, r.n_samples), out_dev),
@@ -395,6 +403,11 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
         for (const Rel &r : rels) rc.add(frontier[r.dst], r.ptrs.numel() - 1);
         rc.verify("neighbor_sampling_heterogenous inputs");
+        if (num_hops > 1) // samples of relation a (src type s) are the next hop's frontier of every relation into s
+            for (const Rel &a : rels)
+                for (const Rel &b : rels)
+                    if (b.dst == a.src)
+                        check_graph_ids(a.idx, b.ptrs.numel() - 1, dev, "neighbor_sampling_heterogenous row_indices");
     }
 
     // ---- default samplers without a filter: all hops and relations in ONE launch (tg_ns_hetero_batched), one read-back
@@ -545,6 +558,7 @@ Tensor random_walk(const Tensor &row_ptrs, const Tensor &col_indices, const Tens
     RangeCheck rc(dev);
     rc.add(st, ptrs.numel() - 1);
     rc.verify("random_walk start");
+    if (walk_length > 1) check_graph_ids(idx, ptrs.numel() - 1, dev, "random_walk col_indices");
     Tensor walks = at::empty({st.numel(), walk_length + 1}, i64(dev));
     tg_graph g{};
     g.ptrs = ptrs.data_ptr<int64_t>();
@@ -574,6 +588,7 @@ std::tuple<Tensor, Tensor> tempo_random_walk(const Tensor &row_ptrs, const Tenso
     RangeCheck rc(dev);
     rc.add(st, ptrs.numel() - 1);
     rc.verify("tempo_random_walk start");
+    if (walk_length > 1) check_graph_ids(idx, ptrs.numel() - 1, dev, "tempo_random_walk col_indices");
     Tensor walks = at::full({st.numel(), walk_length}, -1, i64(dev));
     Tensor wts = at::full({st.numel(), walk_length}, -1, i64(dev));
     tg_graph g{};
@@ -614,6 +629,7 @@ std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, cons
     RangeCheck rc(dev);
     rc.add(st, ptrs.numel() - 1);
     rc.verify("biased_tempo_random_walk start");
+    if (walk_length > 1) check_graph_ids(idx, ptrs.numel() - 1, dev, "biased_tempo_random_walk col_indices");
     Tensor walks = at::empty({st.numel(), walk_length}, i64(dev));
     Tensor wts = at::empty({st.numel(), walk_length}, i64(dev));
     if (st.numel() == 0) return {back(walks, start.device()), back(wts, start.device())};

@@ -25,7 +25,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
            "tg_ns_hetero_batched", "tg_ns_homo_compact", "tg_part_workspace_bytes", "tg_part_begin",
            "tg_part_requests", "tg_part_sample", "tg_part_emit", "tg_compact_rows", "tg_budget_capacity",
-           "tg_budget_workspace_bytes", "tg_budget_sample"]
+           "tg_budget_workspace_bytes", "tg_budget_sample", "tg_ns_homo_workspace_bytes", "tg_ns_homo_batched_ws"]
 
 
 class TgGraph(C.Structure):
@@ -141,10 +141,20 @@ class NsBatchedOut:
         return self.samples[b, :ns], self.rows[b, :ne], self.cols[b, :ne], self.edge_index[b, :ne], lo
 
 
+def ns_homo_workspace(n_batches, n_seeds, fanout, device):
+    """Workspace of tg_ns_homo_batched_ws (the window-ordered gather of many-batch launches), as an int64 tensor."""
+    nbytes = C.c_int64(0)
+    fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
+    check(lib.tg_ns_homo_workspace_bytes(C.c_int64(n_batches), C.c_int64(n_seeds), fan, C.c_int32(len(fanout)),
+                                         C.byref(nbytes)))
+    return torch.empty(nbytes.value // 8 + 1, dtype=torch.int64, device=device)
+
+
 def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UNIFORM, filter_mode=FILTER_NONE,
                     forward=False, window=(0, 0), seeds_state=None, rng_tag=0, id_base=0, seed_ids=None,
-                    seed_call_ids=None):
-    """seeds: [n_batches, n_seeds] int64 on the graph's device; `out` an NsBatchedOut."""
+                    seed_call_ids=None, ws=None, form=0):
+    """seeds: [n_batches, n_seeds] int64 on the graph's device; `out` an NsBatchedOut; `ws` (ns_homo_workspace) lets a
+    many-batch launch take the window-ordered form (same outputs); form: 0 auto, 1 windowed when applicable, 2 fused."""
     assert seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.dim() == 2
     cfg = TgNsConfig()
     cfg.sampler, cfg.filter_mode, cfg.forward = sampler, filter_mode, int(bool(forward))
@@ -156,6 +166,12 @@ def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UN
     rng = TgRng(seed, call_id)
     fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
     so = out.struct()
+    if ws is not None:
+        check(lib.tg_ns_homo_batched_ws(C.byref(graph), ptr(seeds), C.c_int64(seeds.shape[0]),
+                                        C.c_int64(seeds.shape[1]), fan, C.c_int32(len(fanout)), C.byref(cfg),
+                                        C.byref(rng), C.byref(so), ptr(ws), C.c_int64(ws.numel() * 8), C.c_int32(form),
+                                        stream_ptr(seeds.device)))
+        return out
     check(lib.tg_ns_homo_batched(C.byref(graph), ptr(seeds), C.c_int64(seeds.shape[0]), C.c_int64(seeds.shape[1]),
                                  fan, C.c_int32(len(fanout)), C.byref(cfg), C.byref(rng), C.byref(so),
                                  stream_ptr(seeds.device)))

@@ -16,6 +16,15 @@ from . import _cabi
 from .transforms import Graph, HeteroGraph, _attr_kind, _num_nodes, _tensor_items, rel_key, to_csc, to_hetero_csc
 
 
+def _checked_inputs(nodes: Tensor, n_nodes: int) -> Tensor:
+    """int64, flat, and inside [0, n_nodes): the kernels index `ptrs[w]` unchecked (the reference panics on such
+    an id, neighbor_sampling.rs:197)."""
+    nodes = nodes.reshape(-1).to(torch.int64)
+    if nodes.numel() and (int(nodes.min()) < 0 or int(nodes.max()) >= n_nodes):
+        raise IndexError("input_nodes outside [0, %d)" % n_nodes)
+    return nodes
+
+
 class NeighborLoader:
     def __init__(self, data, num_neighbors: List[int], input_nodes: Optional[Tensor] = None, batch_size: int = 1024,
                  prefetch: int = 16, replace: bool = False, shuffle: bool = False, drop_last: bool = False,
@@ -33,7 +42,7 @@ class NeighborLoader:
         self._ptr32 = self.col_ptrs.to(torch.int32) if small else None
         self._graph = _cabi.graph_view(self.col_ptrs, self.row_indices, indices32=self._idx32, ptrs32=self._ptr32)
         nodes = torch.arange(self.n_nodes, device=self.device) if input_nodes is None else input_nodes.to(self.device)
-        self.input_nodes = nodes.reshape(-1).to(torch.int64)
+        self.input_nodes = _checked_inputs(nodes, self.n_nodes)
         self._n_edges = int(data.edge_index.shape[1])
         self._node_attrs, self._edge_attrs = [], []
         for key, value in _tensor_items(data):
@@ -79,14 +88,17 @@ class NeighborLoader:
 
     def __iter__(self) -> Iterator[Graph]:
         nodes = self.input_nodes
+        epoch = self.epoch                                      # captured: a second iterator is the next epoch
+        self.epoch += 1
         if self.shuffle:
             gen = torch.Generator(device=self.device)
-            gen.manual_seed(self.seed * 1000003 + self.epoch)
+            gen.manual_seed(self.seed * 1000003 + epoch)
             nodes = nodes[torch.randperm(nodes.numel(), device=self.device, generator=gen)]
-        self.epoch += 1
         B, n = self.batch_size, nodes.numel()
         n_full = n // B
-        batch0 = 0
+        # every epoch draws afresh, as the reference's global stream does (utils/random.rs:19-22): mini-batch j of
+        # epoch e uses call id call_id0 + e * len(self) + j -- reproducible for a fixed (seed, epoch)
+        batch0 = epoch * len(self)
         for start in range(0, n_full, self.prefetch):
             G = min(self.prefetch, n_full - start)
             yield from self._emit(nodes[start * B:(start + G) * B].reshape(G, B), batch0 + start)
@@ -115,7 +127,8 @@ class HeteroNeighborLoader:
                       for et in self.edge_types]
         n_in = _num_nodes(data[input_type])
         nodes = torch.arange(n_in, device=self.device) if input_nodes is None else input_nodes.to(self.device)
-        self.input_nodes = nodes.reshape(-1).to(torch.int64)
+        self.input_nodes = _checked_inputs(nodes, n_in)
+        self.epoch = 0
         self._node_attrs = {t: [(k, v.to(self.device)) for k, v in _tensor_items(data[t])
                                 if v.dim() > 0 and v.shape[0] == _num_nodes(data[t])] for t in self.node_types}
         self._edge_attrs = {}
@@ -172,9 +185,11 @@ class HeteroNeighborLoader:
 
     def __iter__(self) -> Iterator[HeteroGraph]:
         nodes, B = self.input_nodes, self.batch_size
+        batch0 = self.epoch * len(self)                         # fresh draws every epoch (see NeighborLoader)
+        self.epoch += 1
         n_full = nodes.numel() // B
         for start in range(0, n_full, self.prefetch):
             G = min(self.prefetch, n_full - start)
-            yield from self._emit(nodes[start * B:(start + G) * B].reshape(G, B), start)
+            yield from self._emit(nodes[start * B:(start + G) * B].reshape(G, B), batch0 + start)
         if not self.drop_last and n_full * B < nodes.numel():
-            yield from self._emit(nodes[n_full * B:].reshape(1, -1), n_full)
+            yield from self._emit(nodes[n_full * B:].reshape(1, -1), batch0 + n_full)

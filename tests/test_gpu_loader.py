@@ -98,3 +98,34 @@ def test_hetero_loader_equals_oracle_and_carries_attributes():
         assert b[nt0].batch_size == len(seeds) and b.call_id == 40 + j
         n_seen += 1
     assert n_seen == 5
+
+
+def test_epochs_draw_afresh_and_reproducibly():
+    """mini-batch j of epoch e draws with call id call_id0 + e*len(loader) + j: a second epoch over the same seeds
+    samples other neighbours (the reference's global stream advances on every call, utils/random.rs:19-22), and a
+    fresh loader replays epoch by epoch"""
+    from tch_geometric.loader import NeighborLoader
+    g, ei, x, y, ea = _graph(seed=3)
+    ptrs, idx, perm = orc.to_csc(ei, 500)
+    mk = lambda: NeighborLoader(g, [5, 4], batch_size=64, prefetch=3, seed=9, call_id0=100)
+    a = mk()
+    e0 = [(b.call_id, b.n_id.cpu()) for b in a]
+    e1 = [(b.call_id, b.n_id.cpu()) for b in a]
+    assert [c for c, _ in e0] == list(range(100, 108)) and [c for c, _ in e1] == list(range(108, 116))
+    assert any(not torch.equal(u, v) for (_, u), (_, v) in zip(e0, e1))
+    for j, (c, s) in enumerate(e1):                                          # epoch 1 equals the oracle at its call ids
+        seeds = np.arange(j * 64, min((j + 1) * 64, 500))
+        o = orc.ns_homo(ptrs, idx, seeds, [5, 4], orc.rng_philox(9, c))
+        assert np.array_equal(s.numpy(), o[0])
+    b2 = mk()
+    r0 = [b.n_id.cpu() for b in b2]
+    r1 = [b.n_id.cpu() for b in b2]
+    assert all(torch.equal(u, v) for (_, u), v in zip(e0, r0)) and all(torch.equal(u, v) for (_, u), v in zip(e1, r1))
+
+
+def test_out_of_range_input_nodes_raise():
+    from tch_geometric.loader import NeighborLoader
+    g, *_ = _graph()
+    for bad in ([0, 500], [-1, 3]):
+        with pytest.raises(IndexError):
+            NeighborLoader(g, [3], input_nodes=torch.tensor(bad), batch_size=2)

@@ -129,46 +129,14 @@ def test_two_ranks_on_one_gpu_over_gloo():
 def test_device_kernels_with_an_emulated_world(world):
     """The request bucketing / owner sampling / emit kernels for world > 2, with the all-to-alls emulated in one
     process: bucket p of the requests is sampled against shard p, replies are concatenated in bucket order."""
-    import ctypes as C
+    from helpers_part import emulated_world_sample
     from tch_geometric import _cabi, partitioned
-    lib, ptr = _cabi.lib, _cabi.ptr
     dev = torch.device("cuda:0")
     ptrs, idx, n = _graph(dev)
     nb, fan = 6, [7, 5]
     seeds = _cabi.seed_batches(13, 500, nb, B, n, dev)
     shards = [partitioned.CscShard.from_full(ptrs, idx, r, world) for r in range(world)]
-    out = _cabi.NsBatchedOut(nb, B, fan, dev)
-    so, stream = out.struct(), _cabi.stream_ptr(dev)
-    nbytes = C.c_int64(0)
-    _cabi.check(lib.tg_part_workspace_bytes(C.c_int64(nb), C.c_int32(world), C.byref(nbytes)))
-    ws = torch.zeros(nbytes.value // 8, dtype=torch.int64, device=dev)
-    _cabi.check(lib.tg_part_begin(ptr(seeds), C.c_int64(nb), C.c_int64(B), C.byref(so), ptr(ws), stream))
-    cap, crossed = nb * B, 0
-    for h, k in enumerate(fan):
-        req = torch.empty(cap * 3, dtype=torch.int64, device=dev)
-        req_pos = torch.empty(cap, dtype=torch.int64, device=dev)
-        _cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(cap), C.c_int64(shards[0].shard_size),
-                                         C.c_int32(world), C.c_uint64(500), ptr(ws), ptr(req), ptr(req_pos), stream))
-        sizes = ws[5 * nb + 1:5 * nb + 1 + world].tolist()
-        assert sum(sizes) == int(ws[5 * nb])                # batch_off[n_batches] = number of requests
-        r3 = req[:sum(sizes) * 3].reshape(-1, 3)
-        replies, lo = [], 0
-        for p, m in enumerate(sizes):                       # "all-to-all": bucket p goes to the owner of shard p
-            mine = r3[lo:lo + m].contiguous()
-            if m:
-                owner = torch.clamp(mine[:, 0] // shards[0].shard_size, max=world - 1)
-                assert bool((owner == p).all())
-                crossed += m if p else 0
-            rep = torch.empty(max(m, 1) * k * 2, dtype=torch.int64, device=dev)
-            g = shards[p].graph_view()
-            _cabi.check(lib.tg_part_sample(C.byref(g), C.c_int64(shards[p].v_lo), C.c_int64(shards[p].e_lo), ptr(mine),
-                                           C.c_int64(m), C.c_int32(k), C.c_int32(0), C.c_uint64(SEED), ptr(rep), stream))
-            replies.append(rep[:m * k * 2])
-            lo += m
-        back = torch.cat(replies).contiguous()
-        _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int32(k), C.c_int32(h), C.c_int32(len(fan)),
-                                     ptr(ws), ptr(req_pos), ptr(back), stream))
-        cap *= k
+    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 500)
     ref = _cabi.NsBatchedOut(nb, B, fan, dev)
     _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED, 500, ref)
     torch.cuda.synchronize()
