@@ -93,8 +93,8 @@ def main():
     first, _ = sharding.rank_batch_range(rank, world, (W + K) * G)
     n_pool = max(1, min(W + K, 32))
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
-    out = _cabi.NsBatchedOut(G, B, fanout, dev)
     form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
+    out = _cabi.NsBatchedOut(G, B, fanout, dev)
     ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
     acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
 
@@ -190,7 +190,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_secondary:
-        del out
+        del out, ws
         torch.cuda.empty_cache()
         result["secondary"] = secondary_configs(torch, _cabi, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

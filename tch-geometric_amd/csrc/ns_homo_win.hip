@@ -7,18 +7,19 @@
 // requests/s; only an L2 hit is cheaper, 258 G/s -- tools/probe_gather_sizes.py).  Here the gathers of a hop are
 // brought into ADDRESS order instead, hop by hop over the whole device:
 //
-//   K1  win_count_kernel   (one workgroup per batch): per frontier vertex the column bounds and sample count, LDS scan
-//                          -> every vertex's output offset; writes rows / cols -- which need neither draws nor
-//                          gathers -- as coalesced streams and one ITEM per frontier vertex (column start, degree,
+//   K1  win_emit_kernel    (one workgroup per batch): per frontier vertex the column bounds and sample count, LDS scan
+//                          -> every vertex's output offset, draws; writes rows / cols / edge_index -- which need no
+//                          gather -- as coalesced streams and one ITEM per frontier vertex (column start, degree,
 //                          batch, slot, output offset: 16 bytes, 24 for graphs / launches beyond 32-bit offsets).
 //   P1-3 win_hist / win_colscan / win_basescan / win_scatter: one counting-sort pass of the hop's items by WINDOW of
 //                          the column start (window = 2^shift edge pointers = a few hundred KB of `indices`), laid
 //                          out XCD-major (windows x, x+8, x+16 ... form queue x); no global atomics.
 //   K4  win_gather_kernel  (persistent; the blocks of one XCD sweep that XCD's queue in order, a block reserving the
-//                          next slice with one atomic): draws the item's positions (counter-addressed Philox, the
-//                          same draws as the fused kernel), gathers `indices[e0 + pos]` -- now L2 hits, every line
-//                          of a window is fetched by ONE XCD about once -- and writes samples[n_seeds + e ...] and
-//                          edge_index[e ...] in the reference's slot order.
+//                          next slice with one atomic): re-derives the item's positions (counter-addressed Philox:
+//                          the same draws as K1 and the fused kernel), gathers `indices[e0 + pos]` -- now L2 hits,
+//                          every line of a window is fetched by ONE XCD about once -- and writes
+//                          samples[n_seeds + e ...] in the reference's slot order.  (Scattered 8-byte-granular runs
+//                          are the expensive kind of write, so only the one array that needs the gather goes here.)
 //
 // neighbor_sampling.rs:188-223 is unchanged in meaning: the output position of every edge is fixed by the per-batch
 // prefix sums of K1, so the ORDER in which items are gathered cannot change a single output word (tests compare this
@@ -35,7 +36,6 @@ constexpr int WIN_PART_BLOCKS = 512;  // blocks of the partition kernels = rows 
 constexpr int WIN_PART_THREADS = 512;
 constexpr int WIN_TILE = 4096;        // items per partition tile
 constexpr int WIN_MAX_BUCKETS = 8192; // windows per hop (LDS: 32 KB of counters)
-constexpr int WIN_CHUNKS_PER_ROUND = 1024;
 
 struct WinState { // per batch, lives in the workspace
     int64_t begin, end, ne, fbase;
@@ -119,32 +119,50 @@ __global__ void win_init_kernel(const WinParams p, int64_t n_batches) {
     }
 }
 
-// K1's LDS: chunk offsets | fbase | per wave: the lane of every output of the chunk [64*k] u8
-__host__ __device__ inline size_t win_count_lds_bytes(int kmax, int n_waves) {
-    return (((size_t)(WIN_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
-           (size_t)n_waves * (((size_t)64 * kmax + 15) & ~(size_t)15);
+// K1 works through a batch's frontier in rounds of WIN_ROUND_CHUNKS 64-vertex chunks whose column bounds stay in LDS
+// between the counting pass and the emitting pass (one `ptrs` look-up per frontier vertex and hop).
+constexpr int WIN_ROUND_CHUNKS = 32;
+constexpr int WIN_ROUND_SLOTS = WIN_ROUND_CHUNKS * 64;
+
+// K1's LDS: chunk offsets | fbase | column starts [slots] i64 | degrees [slots] u32 | per wave: staged positions
+// [64*k] u32, staged lanes [64*k] u8
+__host__ __device__ inline size_t win_emit_wave_lds_bytes(int kmax) {
+    return (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
+}
+__host__ __device__ inline size_t win_emit_head_bytes() {
+    return (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
+           (size_t)WIN_ROUND_SLOTS * (sizeof(int64_t) + sizeof(uint32_t));
+}
+__host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
+    return win_emit_head_bytes() + (size_t)n_waves * win_emit_wave_lds_bytes(kmax);
 }
 
-// ---------------------------------------------------------------- K1: counts, offsets, rows / cols streams, items
-template <typename Item, bool REPLACE>
-__global__ void win_count_kernel(const WinParams p) {
+// ---------------------------------------------------------------- K1: counts, offsets, draws, the three streams, items
+template <typename Item, int KMAX, bool REPLACE>
+__global__ void win_emit_kernel(const WinParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int64_t b = blockIdx.x;
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
-    const size_t head_bytes = (((size_t)(WIN_CHUNKS_PER_ROUND + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
-    int64_t *shared_fbase = reinterpret_cast<int64_t *>(smem + head_bytes);
-    uint8_t *slane = smem + head_bytes + 16 + (size_t)wave * (((size_t)64 * p.kmax + 15) & ~(size_t)15);
+    const size_t off_bytes = (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    int64_t *shared_fbase = reinterpret_cast<int64_t *>(smem + off_bytes);
+    int64_t *col0 = reinterpret_cast<int64_t *>(smem + off_bytes + 16);
+    uint32_t *cdeg = reinterpret_cast<uint32_t *>(smem + off_bytes + 16 + (size_t)WIN_ROUND_SLOTS * sizeof(int64_t));
+    unsigned char *wbase = smem + win_emit_head_bytes() + (size_t)wave * win_emit_wave_lds_bytes(p.kmax);
+    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase);
+    uint8_t *slane = wbase + (size_t)64 * p.kmax * sizeof(uint32_t);
     Item *items = static_cast<Item *>(p.items_in);
 
     const int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges;
     int64_t *cols = p.cols + b * p.cap_edges;
+    int64_t *eidx = p.edge_index + b * p.cap_edges;
     const int64_t n_seeds = p.n_seeds;
     const int k = p.k;
     const WinState st = p.state[b];
     const int64_t begin = st.begin, end = st.end;
     int64_t ne = st.ne;
+    const CallKey ck = p.call_keys[b];
 
     if (tid == 0) {
         int64_t *lo = p.layer_offsets + (b * p.n_hops + p.hop) * 3; // :193
@@ -157,35 +175,11 @@ __global__ void win_count_kernel(const WinParams p) {
     __syncthreads();
     const int64_t fbase = *shared_fbase;
 
-    for (int64_t round_begin = begin; round_begin < end; round_begin += (int64_t)WIN_CHUNKS_PER_ROUND * 64) {
-        const int64_t round_end = min(end, round_begin + (int64_t)WIN_CHUNKS_PER_ROUND * 64);
+    for (int64_t round_begin = begin; round_begin < end; round_begin += WIN_ROUND_SLOTS) {
+        const int64_t round_end = min(end, round_begin + (int64_t)WIN_ROUND_SLOTS);
         const int nc = (int)((round_end - round_begin + 63) >> 6);
-        for (int c = wave; c < nc; c += n_waves) { // pass A: per-chunk sample counts
+        for (int c = wave; c < nc; c += n_waves) { // pass A: column bounds -> LDS, per-chunk sample counts
             const int64_t i = round_begin + (int64_t)c * 64 + lane;
-            uint32_t cnt = 0;
-            if (i < round_end) {
-                const int64_t w = samples[i];
-                const int64_t deg = p.ptrs32 ? (int64_t)(p.ptrs32[w + 1] - p.ptrs32[w]) : p.ptrs[w + 1] - p.ptrs[w];
-                cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
-            }
-            const uint32_t tot = wave_sum(cnt);
-            if (lane == 0) chunk_off[c] = tot;
-        }
-        __syncthreads();
-        if (wave == 0) { // scan of chunk totals
-            uint32_t carry = 0;
-            for (int c0 = 0; c0 < nc; c0 += 64) {
-                const uint32_t v = (c0 + lane < nc) ? chunk_off[c0 + lane] : 0u;
-                const uint32_t incl = wave_inclusive_scan(v);
-                if (c0 + lane < nc) chunk_off[c0 + lane] = carry + incl - v;
-                carry += __shfl(incl, 63, 64);
-            }
-            if (lane == 0) chunk_off[nc] = carry;
-        }
-        __syncthreads();
-        for (int c = wave; c < nc; c += n_waves) { // pass B: offsets, items, the two streams
-            const int64_t i0 = round_begin + (int64_t)c * 64;
-            const int64_t i = i0 + lane;
             int64_t e0 = 0, deg = 0;
             if (i < round_end) {
                 const int64_t w = samples[i];
@@ -197,20 +191,58 @@ __global__ void win_count_kernel(const WinParams p) {
                     deg = p.ptrs[w + 1] - e0;
                 }
             }
+            col0[c * 64 + lane] = e0;
+            cdeg[c * 64 + lane] = deg > 0 ? (uint32_t)deg : 0u;
             const uint32_t cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+            const uint32_t tot = wave_sum(cnt);
+            if (lane == 0) chunk_off[c] = tot;
+        }
+        __syncthreads();
+        if (wave == 0) { // scan of chunk totals (nc <= 64)
+            const uint32_t v = lane < nc ? chunk_off[lane] : 0u;
+            const uint32_t incl = wave_inclusive_scan(v);
+            if (lane < nc) chunk_off[lane] = incl - v;
+            if (lane == 63) chunk_off[nc] = incl;
+        }
+        __syncthreads();
+        for (int c = wave; c < nc; c += n_waves) { // pass B: draws, items, the three streams
+            const int64_t i0 = round_begin + (int64_t)c * 64;
+            const int64_t i = i0 + lane;
+            const int64_t e0 = col0[c * 64 + lane];
+            const uint32_t n = cdeg[c * 64 + lane];
+            const uint32_t cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
+            const uint64_t did = (uint64_t)(p.id_base + i);
             const uint32_t incl = wave_inclusive_scan(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = __shfl(incl, 63, 64);
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
             if (i < round_end)
-                items[fbase + (i - begin)] = Item::make((uint64_t)e0, cnt ? (uint32_t)deg : 0u, (uint32_t)b,
-                                                        (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
-            for (uint32_t s = 0; s < cnt; ++s) slane[excl + s] = (uint8_t)lane;
+                items[fbase + (i - begin)] =
+                    Item::make((uint64_t)e0, n, (uint32_t)b, (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
+            if (cnt > 0) {
+                if (REPLACE) { // sampling.rs:57-69
+                    Draw d;
+                    for (int s = 0; s < k; ++s) {
+                        if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
+                        spos[excl + s] = bounded32(d.half(s & 1), n);
+                        slane[excl + s] = (uint8_t)lane;
+                    }
+                } else if (n <= (uint32_t)k) { // sampling.rs:12-15
+                    for (uint32_t s = 0; s < cnt; ++s) {
+                        spos[excl + s] = s;
+                        slane[excl + s] = (uint8_t)lane;
+                    }
+                } else {
+                    sample_tickets<KMAX>(ck, did, n, k, spos, slane, excl, lane);
+                }
+            }
             wave_lds_handoff();
-            for (uint32_t q = lane; q < total; q += 64) { // two write-once streams, coalesced (:217)
+            for (uint32_t q = lane; q < total; q += 64) { // three write-once streams, coalesced (:217)
+                const int l = slane[q];
                 const int64_t e = e_chunk + q;
                 __builtin_nontemporal_store(n_seeds + e, &rows[e]);
-                __builtin_nontemporal_store(i0 + (int64_t)slane[q], &cols[e]);
+                __builtin_nontemporal_store(i0 + (int64_t)l, &cols[e]);
+                __builtin_nontemporal_store(col0[c * 64 + l] + (int64_t)spos[q], &eidx[e]);
             }
             wave_lds_handoff();
         }
@@ -337,45 +369,42 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter_kernel(const Win
 // ---------------------------------------------------------------- K4: window-ordered gather
 constexpr int WIN_EMIT = 4;
 
-// per wave: column start [64] i64 | samples base [64] i64 | edge base [64] i64 | staged positions [64*k] u32 | lanes u8
+// per wave: column start [64] i64 | samples base [64] i64 | staged positions [64*k] u32 | lanes u8
 __host__ __device__ inline size_t win_gather_wave_lds_bytes(int kmax) {
-    return 3 * 64 * sizeof(int64_t) + (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
+    return 2 * 64 * sizeof(int64_t) + (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
 }
 
-// The staged (lane, position) pairs of one round are walked by consecutive lanes: gather the neighbour id, write it
-// and its edge pointer (neighbor_sampling.rs:211-217).  WIN_EMIT gathers per lane and batch, two batches in flight;
+// The staged (lane, position) pairs of one round are walked by consecutive lanes: gather the neighbour id and write it
+// (neighbor_sampling.rs:211-215; edge_index was written by K1).  WIN_EMIT gathers per lane and batch, two batches in flight;
 // unconditional loads (lanes past the end re-read element 0's address and skip the stores).
 template <typename IDX>
 __device__ __forceinline__ void win_gather_chunk(const IDX *__restrict__ idx, uint32_t total, int lane,
                                                  const uint8_t *slane, const uint32_t *spos, const int64_t *ebase,
-                                                 const int64_t *obase, const int64_t *xbase, int64_t *samples,
-                                                 int64_t *eidx) {
+                                                 const int64_t *obase, int64_t *samples) {
     if (total == 0) return;
     struct Batch {
-        int64_t o[WIN_EMIT], x[WIN_EMIT], ep[WIN_EMIT];
+        int64_t o[WIN_EMIT];
         IDX v[WIN_EMIT];
     };
     auto issue = [&](Batch &t, uint32_t q0) {
+        int64_t ep[WIN_EMIT];
 #pragma unroll
         for (int u = 0; u < WIN_EMIT; ++u) {
             const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
             const uint32_t qq = q < total ? q : 0u;
             const int l = slane[qq];
-            t.ep[u] = ebase[l] + (int64_t)spos[qq];
-            t.o[u] = obase[l] + (int64_t)qq; // bases already hold "minus the item's first q"
-            t.x[u] = xbase[l] + (int64_t)qq;
+            ep[u] = ebase[l] + (int64_t)spos[qq];
+            t.o[u] = obase[l] + (int64_t)qq; // the base already holds "minus the item's first q"
         }
 #pragma unroll
-        for (int u = 0; u < WIN_EMIT; ++u) t.v[u] = idx[t.ep[u]];
+        for (int u = 0; u < WIN_EMIT; ++u) t.v[u] = idx[ep[u]];
     };
     auto store = [&](const Batch &t, uint32_t q0) {
 #pragma unroll
         for (int u = 0; u < WIN_EMIT; ++u) {
             const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
-            if (q < total) {
-                samples[t.o[u]] = (int64_t)t.v[u];                   // :215 (the next hop's frontier)
-                __builtin_nontemporal_store(t.ep[u], &eidx[t.x[u]]); // :217 edge_ptr, write-once
-            }
+            // :215  plain stores: the partial lines of neighbouring runs merge in L2 (streaming them was slower)
+            if (q < total) samples[t.o[u]] = (int64_t)t.v[u];
         }
     };
     Batch a, b;
@@ -402,15 +431,17 @@ __global__ void win_gather_kernel(const WinParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *wbase = smem + (size_t)wave * win_gather_wave_lds_bytes(p.kmax);
     int64_t *ebase = reinterpret_cast<int64_t *>(wbase);
-    int64_t *obase = ebase + 64, *xbase = ebase + 128;
-    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 192 * sizeof(int64_t));
-    uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 192 * sizeof(int64_t) + (size_t)64 * p.kmax * sizeof(uint32_t));
+    int64_t *obase = ebase + 64;
+    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 128 * sizeof(int64_t));
+    uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 128 * sizeof(int64_t) + (size_t)64 * p.kmax * sizeof(uint32_t));
     const Item *items = static_cast<const Item *>(p.items_sorted);
     const int k = p.k;
     WinQueues::Q *Q = &p.queues->q[blockIdx.x & 7];
     const unsigned long long qend = Q->end;
     const unsigned long long slice = blockDim.x; // 64 items per wave
 
+    // (reserving two slices ahead to prefetch the next slice's items, and half-filled wavefronts with twice the
+    // blocks, were both measured: each widens the front or thins the arithmetic and neither was faster)
     if (tid == 0) slice_lo[0] = atomicAdd(&Q->head, slice);
     __syncthreads();
     for (int buf = 0;; buf ^= 1) {
@@ -433,7 +464,6 @@ __global__ void win_gather_kernel(const WinParams p) {
             const uint64_t did = (uint64_t)(p.id_base + (int64_t)it.slot(p.slot_bits));
             ebase[lane] = (int64_t)it.col();
             obase[lane] = (int64_t)b * p.cap_nodes + p.n_seeds + (int64_t)it.e - (int64_t)excl;
-            xbase[lane] = (int64_t)b * p.cap_edges + (int64_t)it.e - (int64_t)excl;
             if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
                 Draw d;
                 for (int s = 0; s < k; ++s) {
@@ -452,11 +482,9 @@ __global__ void win_gather_kernel(const WinParams p) {
         }
         wave_lds_handoff();
         if (p.indices32)
-            win_gather_chunk<uint32_t>(p.indices32, total, lane, slane, spos, ebase, obase, xbase, p.samples,
-                                       p.edge_index);
+            win_gather_chunk<uint32_t>(p.indices32, total, lane, slane, spos, ebase, obase, p.samples);
         else
-            win_gather_chunk<int64_t>(p.indices, total, lane, slane, spos, ebase, obase, xbase, p.samples,
-                                      p.edge_index);
+            win_gather_chunk<int64_t>(p.indices, total, lane, slane, spos, ebase, obase, p.samples);
         if (tid == 0) slice_lo[buf ^ 1] = nxt;
         __syncthreads(); // the next slice's start is published; also fences this wave's LDS staging
     }
@@ -500,7 +528,7 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
 
 template <typename Item, int KMAX, bool REPLACE>
 static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
-    static const int count_threads = win_env_int("TG_WIN_COUNT_THREADS", 512);
+    static const int emit_threads = win_env_int("TG_WIN_EMIT_THREADS", 256);
     static const int gather_threads = win_env_int("TG_WIN_GATHER_THREADS", 512);
     static const int gather_blocks = (win_env_int("TG_WIN_GATHER_BLOCKS", 256) + 7) & ~7; // 8 groups of equal size
     hipLaunchKernelGGL(win_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, stream, p, n_batches);
@@ -508,10 +536,10 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
     for (int h = 0; h < n_hops; ++h) {
         p.hop = h;
         p.k = (int32_t)fanout[h];
-        int threads = count_threads;
-        while (threads > 64 && win_count_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
-        hipLaunchKernelGGL((win_count_kernel<Item, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
-                           win_count_lds_bytes(p.kmax, threads / 64), stream, p);
+        int threads = emit_threads;
+        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
+        hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
+                           win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
         TG_LAUNCH_CHECK();
         hipLaunchKernelGGL(win_hist_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
         TG_LAUNCH_CHECK();
