@@ -30,7 +30,7 @@ def parse_args():
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanout", type=str, default="15,10")
-    ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int, default=4096,
+    ap.add_argument("--batches-per-step", "--batches-per-launch", dest="batches_per_step", type=int, default=16384,
                     help="independent 1024-seed mini-batches sampled by the one launch of a step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,10 +120,12 @@ def main():
     acc.zero_()
     events = []
     fence()
+    gpu_state0 = gpu_state(local_rank if not rehearse else 0)
     t0 = time.perf_counter()
     run(W, W + K, events)
     fence()
     dt = time.perf_counter() - t0
+    gpu_state1 = gpu_state(local_rank if not rehearse else 0)
 
     dt_max, tot = sharding.reduce_measurement(dt, acc)
     edges_all = int(tot.tolist()[0])
@@ -137,14 +139,16 @@ def main():
     alg_bytes = 24 * my_frontier + 40 * my_edges + 16 * B * G * K
     bytes_per_launch = alg_bytes / my_launches
     achieved = bytes_per_launch / avg_kernel_s / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            tj = json.load(open(tpath))  # PMC passes of an identical launch (profiles/r01/pmc_summary.json)
+            tj = json.load(open(tpath))  # PMC passes of an identical launch, collected by tools/pmc_win.sh
+            form_ran = "fused" if args.form == "fused" else "windowed"
             if (tj.get("batches_per_launch") == G and args.scale == 24 and B == 1024 and fanout == [15, 10]
-                    and tj.get("idx32") == args.idx32 and tj.get("ptr32") == args.ptr32):
+                    and tj.get("idx32") == args.idx32 and tj.get("ptr32") == args.ptr32 and tj.get("form") == form_ran):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of the same launch; NOT this run)"
         except Exception:
             traffic = None
 
@@ -174,6 +178,9 @@ def main():
             "sampled_edges_per_step": edges_all / (K * world),
             "sampled_edges_per_mini_batch": edges_all / (K * world * G),
             "graph_build_s": round(t_build, 2),
+            "form": args.form,
+            "gpu_state_before_timed_region": gpu_state0,
+            "gpu_state_after_timed_region": gpu_state1,
         },
         "roofline": {
             "bound": "hbm",
@@ -182,7 +189,10 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel": "ns_homo_uniform_kernel",
+            "traffic_source": traffic_source,
+            "kernel": ("ns_homo_uniform_kernel (fused per-batch form)" if args.form == "fused" else
+                       "tg_ns_homo_batched_ws launch = per hop win_emit + counting sort of the frontier by window + "
+                       "win_gather (window-ordered form); duration = the whole launch"),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": avg_kernel_s * 1e3,
             "launches": my_launches,
@@ -192,7 +202,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         del out, ws
         torch.cuda.empty_cache()
-        result["secondary"] = secondary_configs(torch, _cabi, dev)
+        result["secondary"] = secondary_configs(torch, _cabi, dev, args.cpu_seconds)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
     if rank == 0:
@@ -201,10 +211,53 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_configs(torch, _cabi, dev):
+def gpu_state(index):
+    """sclk / mclk / power of this rank's GPU from sysfs (so that box-to-box spread can be attributed); never fails."""
+    st = {}
+    try:
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if not cards:
+            return {"unavailable": "no amdgpu sysfs"}
+        base = os.path.dirname(cards[min(index, len(cards) - 1)])
+
+        def active(name):
+            for line in open(os.path.join(base, name)).read().splitlines():
+                if line.rstrip().endswith("*"):
+                    return line.split(":", 1)[1].strip().rstrip("*").strip()
+            return None
+
+        st["sclk"], st["mclk"] = active("pp_dpm_sclk"), active("pp_dpm_mclk")
+        for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+            for key, fn in (("power_w", "power1_average"), ("power_w", "power1_input"), ("power_cap_w", "power1_cap")):
+                f = os.path.join(hw, fn)
+                if os.path.exists(f) and key not in st:
+                    try:
+                        st[key] = int(open(f).read()) / 1e6
+                    except Exception:
+                        pass
+    except Exception as e:  # noqa: BLE001
+        st["unavailable"] = repr(e)
+    return st
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def secondary_configs(torch, _cabi, dev, cpu_seconds):
     """Short runs of the other BASELINE.json configurations on this box (reported beside the headline, never part of
-    `value`): cfg3 random_walk 1 M x 80 on RMAT-24, cfg4 heterogeneous sampling (3 node types / 5 relations)."""
+    `value`): cfg3 random_walk 1 M x 80 on RMAT-24, cfg4 heterogeneous sampling + hgt_sampling (3 node types / 5
+    relations) -- each with the CPU port (oracle ref-mode, one thread, bounded sample) timed beside it."""
     sec = {}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc  # the checker, used here only as the timed CPU baseline
 
     def timed(fn, reps=3):
         fn(0)
@@ -217,6 +270,7 @@ def secondary_configs(torch, _cabi, dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps, o
 
+    budget = max(1.0, cpu_seconds / 3)
     try:  # cfg3
         n = 1 << 24
         row, col = _cabi.rmat_edges(24, n * 16, 0x5EED0000 + 24, dev)
@@ -226,56 +280,128 @@ def secondary_configs(torch, _cabi, dev):
         g = _cabi.graph_view(ptrs, idx)
         ms, w = timed(lambda c: _cabi.random_walk(g, start, 80, 1.0, 1.0, 0, c))
         steps = int((w[:, 1:] >= 0).sum().item())
-        sec["cfg3_random_walk_1M_x_80_p1_q1"] = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3}
-        del ptrs, idx, w, g
+        entry = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3}
+        hp, hi, hs = ptrs.cpu().numpy(), idx.cpu().numpy(), start.cpu().numpy()
+        nw, t0 = 4096, time.perf_counter()
+        ref = orc.random_walk(hp, hi, hs[:nw], 80, 1.0, 1.0, orc.rng_ref_child(orc.rng_ref()))
+        dt = time.perf_counter() - t0
+        nw2 = int(min(len(hs), max(nw, nw * budget / max(dt, 1e-4))))
+        t0 = time.perf_counter()
+        ref = orc.random_walk(hp, hi, hs[:nw2], 80, 1.0, 1.0, orc.rng_ref_child(orc.rng_ref()))
+        dt = time.perf_counter() - t0
+        cs = int((ref[:, 1:] >= 0).sum())
+        entry["cpu_baseline"] = {"value": cs / dt, "unit": "steps/s", "cores": 1, "kind": "port",
+                                 "sample": "first %d of the 1 M walkers, oracle ref-mode, %.1f s" % (nw2, dt)}
+        sec["cfg3_random_walk_1M_x_80_p1_q1"] = entry
+        del ptrs, idx, w, g, hp, hi
     except Exception as e:  # noqa: BLE001  (a secondary run must never cost the headline line)
         sec["cfg3_random_walk_1M_x_80_p1_q1"] = {"error": repr(e)}
     try:  # cfg4
         torch.cuda.empty_cache()
         scales = {"A": 23, "B": 22, "C": 22}
-        ets = [("A", "A"), ("A", "B"), ("B", "A"), ("B", "C"), ("C", "A")]
+        node_types = ["A", "B", "C"]
+        edge_types = [("A", "e0", "A"), ("A", "e1", "B"), ("B", "e2", "A"), ("B", "e3", "C"), ("C", "e4", "A")]
         tix = {"A": 0, "B": 1, "C": 2}
-        rels = []
-        for r, (s_, d_) in enumerate(ets):
+        rels, P, I = [], {}, {}
+        for r, (s_, _, d_) in enumerate(edge_types):
             rw, cl = _cabi.rmat_edges_rect(scales[s_], scales[d_], 20_000_000, 0xC0F4 + r, dev)
             p_, i_, _ = _cabi.coo_to_csx(rw, cl, 1 << scales[s_], 1 << scales[d_], True)
             rels.append((tix[s_], tix[d_], p_, i_, [15, 10]))
+            P["%s__%s__%s" % edge_types[r]], I["%s__%s__%s" % edge_types[r]] = p_, i_
         nb = 512
         sd = _cabi.seed_batches(0xBA7C4, 5000, nb, 1024, 1 << 23, dev)
         hb = _cabi.NsHeteroBatched(3, rels, [sd, None, None], 2, nb, dev)
         ms, _ = timed(lambda c: hb.run(0, c * nb))
         ne = int(hb.counts[:, 3:].sum().item())
-        sec["cfg4_neighbor_sampling_heterogenous_512_batches"] = {"ms_per_launch": ms, "sampled_edges": ne,
-                                                                  "edges_per_s": ne / ms * 1e3}
+        entry = {"ms_per_launch": ms, "sampled_edges": ne, "edges_per_s": ne / ms * 1e3}
+        hP = {k: v.cpu().numpy() for k, v in P.items()}
+        hI = {k: v.cpu().numpy() for k, v in I.items()}
+        hs = sd.cpu().numpy()
+        nn = {k: [15, 10] for k in hP}
+        t0, done, ce = time.perf_counter(), 0, 0
+        parent = orc.rng_ref()
+        while done < nb and time.perf_counter() - t0 < budget:
+            o = orc.ns_hetero(node_types, edge_types, hP, hI, {"A": hs[done]}, nn, 2, orc.rng_ref_child(parent))
+            ce += sum(len(v) for v in o[1].values())
+            done += 1
+        dt = time.perf_counter() - t0
+        entry["cpu_baseline"] = {"value": ce / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+                                 "sample": "%d of the 512 mini-batches, oracle ref-mode, %.1f s" % (done, dt)}
+        sec["cfg4_neighbor_sampling_heterogenous_512_batches"] = entry
+        # hgt_sampling through the operator surface, as a DataLoader worker calls it
+        import tch_geometric as tg
+        seeds = sd[0].contiguous()
+        ns = {t: [512, 512] for t in node_types}
+        tg.seed(1)
+
+        def hgt_call(c):
+            return tg.hgt_sampling(node_types, edge_types, P, I, None, {"A": seeds}, None, ns, 2)
+
+        ms, out = timed(hgt_call, reps=5)
+        nodes = sum(int(v.numel()) for v in out[0].values())
+        edges = sum(int(v.numel()) for v in out[2].values())
+        entry = {"ms_per_call": ms, "sampled_nodes": nodes, "sampled_edges": edges,
+                 "nodes_plus_edges_per_s": (nodes + edges) / ms * 1e3}
+        t0, done = time.perf_counter(), 0
+        while done < 64 and time.perf_counter() - t0 < budget:
+            orc.hgt(node_types, edge_types, hP, hI, None, {"A": hs[done]}, None, ns, 2, orc.rng_ref_child(parent))
+            done += 1
+        dt = time.perf_counter() - t0
+        entry["cpu_baseline"] = {"value": done / dt, "unit": "calls/s", "gpu_calls_per_s": 1e3 / ms, "cores": 1,
+                                 "kind": "port", "sample": "%d calls, oracle ref-mode, %.1f s" % (done, dt)}
+        sec["cfg4_hgt_sampling_1024_seeds_512x2_per_type"] = entry
     except Exception as e:  # noqa: BLE001
-        sec["cfg4_neighbor_sampling_heterogenous_512_batches"] = {"error": repr(e)}
+        sec.setdefault("cfg4_neighbor_sampling_heterogenous_512_batches", {"error": repr(e)})
+        sec.setdefault("cfg4_hgt_sampling_1024_seeds_512x2_per_type", {"error": repr(e)})
     return sec
 
 
 def cpu_baseline(args, ptrs, indices, seeds, fanout):
     """The oracle's ref-mode (sequential Xoshiro256++, the reference's algorithm draw for draw) timed on
-    this box's host cores over a bounded sample of the same batches; threads own whole batches."""
+    this box's host cores over a bounded sample of the same batches; threads own whole batches (how PyG's
+    `num_workers` would scale the reference).  ALL host cores are used; the one-core figure is kept beside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc  # the checker, used here only as the timed CPU baseline
 
     hp, hi = ptrs.cpu().numpy(), indices.cpu().numpy()
     hs = seeds.cpu().numpy()
-    threads = max(1, min(16, os.cpu_count() or 1))
+    nproc = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = nproc
+    try:  # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) bounds the cores that really run
+        quota = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else int(q) / int(per)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        if quota:
+            usable = max(1, min(usable, int(round(quota))))
+    except Exception:
+        pass
+    threads = max(1, usable)
     n0 = min(threads, hs.shape[0])
     sec0, _ = orc.bench_ns_homo(hp, hi, hs[:n0], fanout, threads)          # calibration: one batch per thread
     per_round = max(sec0, 1e-4)
     n = int(min(hs.shape[0], max(n0, threads * max(1, round(args.cpu_seconds / per_round)))))
     sec, edges = orc.bench_ns_homo(hp, hi, hs[:n], fanout, threads)
-    sec1, edges1 = orc.bench_ns_homo(hp, hi, hs[:max(1, n // threads)], fanout, 1)
+    n1 = max(1, min(n // threads, 64))
+    sec1, edges1 = orc.bench_ns_homo(hp, hi, hs[:n1], fanout, 1)
     return {
         "value": edges / sec,
         "unit": "edges/s",
         "cores": threads,
+        "nproc": nproc,
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": "%d of the 1024-seed mini-batches of the timed steps, oracle ref-mode (rand-0.8.5 Xoshiro256++ stream, "
-                  "reservoir loop of sampling.rs), %d threads each owning whole batches, %.1f s wall; "
-                  "single thread: %.3g edges/s over %d batches" %
-                  (n, threads, sec, edges1 / sec1, max(1, n // threads)),
+                  "reservoir loop of sampling.rs), %d threads (every core this process may use: affinity and cgroup quota; nproc %d) each owning "
+                  "whole batches, %.1f s wall; single thread: %.3g edges/s over %d batches" %
+                  (n, threads, nproc, sec, edges1 / sec1, n1),
         "single_thread_value": edges1 / sec1,
     }
 
