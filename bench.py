@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE cfg3 / cfg4")
     ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")
     ap.add_argument("--ptr32", type=int, default=1, help="also keep a u32 shadow of `ptrs`")
+    ap.add_argument("--mode", choices=["replicated", "partitioned"], default="replicated",
+                    help="replicated: CSC on every rank, seed batches sharded (the headline).  partitioned: every rank owns "
+                         "the columns of a contiguous vertex range; remote neighbours are fetched by all-to-all (cfg5 shape)")
     ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
                     help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
     return ap.parse_args()
@@ -73,6 +76,8 @@ def main():
     n_nodes = 1 << args.scale
     n_edges = n_nodes * args.edge_factor
     K, W, G, B = args.steps, args.warmup, args.batches_per_step, args.batch
+    if args.mode == "partitioned":
+        return partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanout)
 
     # ---- graph: R-MAT edges -> CSC with the reference's sort key (storage.rs:118-123); resident in HBM
     t_build = time.time()
@@ -205,6 +210,78 @@ def main():
         result["secondary"] = secondary_configs(torch, _cabi, dev, args.cpu_seconds)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanout):
+    """Mode 2 (BASELINE cfg5 shape): rank r owns the columns of vertices [r*S, (r+1)*S); a step = one
+    PartitionedSampler.sample() over G seed batches per rank (requests / replies all-to-all per hop over RCCL; with one
+    rank the exchange is skipped and nothing is read back).  Same JSON line as the replicated mode."""
+    from tch_geometric import partitioned
+    n = 1 << args.scale
+    K, W, B = args.steps, args.warmup, args.batch
+    G = min(args.batches_per_step, 4096)
+    size = partitioned.CscShard.shard_size_for(n, world)
+    v_lo, v_hi = min(rank * size, n), min((rank + 1) * size, n)
+    t_build = time.time()
+    row, col = _cabi.rmat_edges(args.scale, n * args.edge_factor, 0x5EED0000 + args.scale, dev)
+    below = int((col < v_lo).sum())         # global edge offset of the shard = edges of the columns before v_lo
+    keep = (col >= v_lo) & (col < v_hi)
+    row, col = row[keep], col[keep] - v_lo
+    del keep
+    ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, v_hi - v_lo, True)
+    del row, col
+    shard = partitioned.CscShard(ptrs, idx, v_lo, v_hi, below, n, size)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+    ps = partitioned.PartitionedSampler(shard, G, B, fanout, group=None)
+    firsts = [sharding.rank_batch_range(r, world, (W + K) * G)[0] for r in range(world)]
+    first = firsts[rank]
+    acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    events = []
+
+    def run(lo, hi, timed):
+        for i in range(lo, hi):
+            seeds = _cabi.seed_batches(0xBA7C4, first + i * G, G, B, n, dev)
+            if timed:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            out = ps.sample(seeds, 0, first + i * G, first_call_ids=[f + i * G for f in firsts])
+            if timed:
+                ev1.record()
+                events.append((ev0, ev1))
+            acc.add_(out.counts[:, 1].sum())
+
+    run(0, W, False)
+    acc.zero_()
+    sharding.fence(dev)
+    t0 = time.perf_counter()
+    run(W, W + K, True)
+    sharding.fence(dev)
+    dt = time.perf_counter() - t0
+    dt_max, tot = sharding.reduce_measurement(dt, torch.cat([acc, torch.zeros(2, dtype=torch.int64, device=dev)]))
+    edges_all = int(tot.tolist()[0])
+    ms = [a.elapsed_time(b) for a, b in events]
+    result = {
+        "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [%s] on RMAT-%d" % (args.fanout, args.scale),
+        "value": edges_all / dt_max, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": dt_max / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int64", "data": "synthetic",
+        "config": {
+            "workload": "neighbor_sampling_homogenous, RMAT scale-%d, fanout %s, batch %d, default sampler, no filter; "
+                        "CSC RANGE-PARTITIONED over %d rank(s)" % (args.scale, fanout, B, world),
+            "step": "one PartitionedSampler.sample() over %d seed batches per rank" % G,
+            "batches_per_step_per_rank": G,
+            "parallelism": "range-partitioned CSC (contiguous vertex ranges) over %d rank(s); per hop requests and compact "
+                           "replies travel by all_to_all_single (RCCL)%s" %
+                           (world, "" if world > 1 else "; one rank: no exchange, no host read-back"),
+            "avg_call_ms_this_rank": sum(ms) / len(ms),
+            "shard_build_s": round(t_build, 2),
+        },
+    }
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

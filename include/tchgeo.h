@@ -240,29 +240,44 @@ TG_API int tg_ns_hetero_batched(const tg_het_problem *problem, int64_t n_batches
                                 void *stream);
 
 /* neighbor_sampling_homogenous over a RANGE-PARTITIONED CSC (graphs beyond one GPU's HBM; host protocol in
- * tch_geometric/partitioned.py).  The origin rank keeps ordinary tg_ns_out slabs; per hop:
- * tg_part_requests (origin) -> all-to-all -> tg_part_sample (owner) -> all-to-all -> tg_part_emit (origin).  Results
- * equal tg_ns_homo_batched on the replicated graph bit for bit (requests carry the requester's draw address).
- * workspace: tg_part_workspace_bytes(n_batches, world) bytes, int64 words laid out as
- *   state[4 * n_batches] | batch_off[n_batches + 1] | bucket_sizes[world] | cursors[world];
- * after tg_part_requests, batch_off[n_batches] = number of requests M and bucket_sizes[p] = requests owned by rank p
- * (the all-to-all split sizes -- the only values the host reads per hop).
+ * tch_geometric/partitioned.py; SURVEY.md 8(e) mode 2).  The origin rank keeps ordinary
+ * tg_ns_out slabs; per hop: tg_part_requests (origin) -> all-to-all -> tg_part_count + tg_part_sample (owner) ->
+ * all-to-all -> tg_part_emit (origin).  Results equal tg_ns_homo_batched on the replicated graph bit for bit (requests
+ * carry the requester's draw address).  EVERY size stays on the device (kernels read the number of requests from
+ * device memory): with world == 1 nothing is read back; with world > 1 the host reads only the all-to-all split sizes.
+ *  - request: 16 bytes {int64 vertex; uint32 batch; uint32 slot}; the requester's call id = its first call id + batch.
+ *  - request_cap = n_batches * the widest frontier (< 2^32); workspace: tg_part_workspace_bytes, 256-byte aligned.
  *  - tg_part_begin: copies the seeds into the slabs, frontier = the seeds.
- *  - tg_part_requests: requests [M][3] = (vertex, call id, slot) grouped by owner = min(vertex / shard_size, world-1);
- *    req_pos[M]: frontier slot (batch-major) -> position of its request.  request_cap = capacity of both arrays.
- *  - tg_part_sample: owner of columns [v_lo, v_lo + shard.n_major): reply [m][fanout][2] = (neighbour id, global edge
- *    pointer = local pointer + e_lo), -1 padded; unweighted samplers, fanout <= TG_MAX_FANOUT.
- *  - tg_part_emit: compacts the replies (in request order) into the slabs in slot order and advances the frontier;
- *    writes layer_offsets[hop] and counts. */
-TG_API int tg_part_workspace_bytes(int64_t n_batches, int32_t world, int64_t *bytes);
-TG_API int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, const tg_ns_out *out, void *workspace,
-                         void *stream);
+ *  - tg_part_requests: `requests` [<= request_cap] grouped by owner = min(vertex / shard_size, world-1);
+ *    send_counts[world + 1] (device): requests per owner, then their total.
+ *  - tg_part_count: owner of columns [v_lo, v_lo + shard.n_major).  m_dev: number of received requests (device);
+ *    m_cap: host-known upper bound of it (sizes the launches and the prefix sum); seg_off[world + 1] (host): requests of
+ *    requesting rank p are [seg_off[p], seg_off[p+1]); seg_call0[world] (host): that rank's first call id.
+ *    -> cnt[m] u32 samples per request, off[m + 1] their exclusive prefix (off[m] = total), reply_counts[world + 1] (device): reply entries
+ *    per requesting rank, then their total.  scan_tmp: tg_part_scan_workspace_bytes(m_cap).
+ *  - tg_part_sample: reply [sum cnt][2] = (neighbour id, global edge pointer = local pointer + e_lo), compact, in
+ *    request order; unweighted samplers, fanout <= TG_MAX_FANOUT.
+ *  - tg_part_emit: cnt / reply as returned to the origin (request order); cnt_prefix: the exclusive prefix of cnt if
+ *    the caller already holds it (world == 1: tg_part_count's `off`), else NULL; hop_cap = n_batches * this hop's
+ *    widest frontier; compacts the replies into the slabs in slot order, advances the frontier, writes layer_offsets[hop],
+ *    counts. */
+TG_API int tg_part_workspace_bytes(int64_t n_batches, int64_t request_cap, int32_t world, int64_t *bytes);
+TG_API int tg_part_scan_workspace_bytes(int64_t n, int64_t *bytes);
+TG_API int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, int32_t n_hops, const tg_ns_out *out,
+                         int64_t request_cap, int32_t world, void *workspace, void *stream);
 TG_API int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t request_cap, int64_t shard_size, int32_t world,
-                            uint64_t first_call_id, void *workspace, int64_t *requests, int64_t *req_pos, void *stream);
-TG_API int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const int64_t *requests, int64_t m,
-                          int32_t fanout, int32_t sampler, uint64_t seed, int64_t *reply, void *stream);
-TG_API int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int32_t fanout, int32_t hop, int32_t n_hops,
-                        void *workspace, const int64_t *req_pos, const int64_t *reply, void *stream);
+                            void *workspace, void *requests, int64_t *send_counts, void *stream);
+TG_API int tg_part_count(const tg_graph *shard, int64_t v_lo, const void *requests, const int64_t *m_dev, int64_t m_cap,
+                         int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout, int32_t sampler,
+                         uint32_t *cnt, int64_t *off, int64_t *reply_counts, void *scan_tmp, int64_t scan_tmp_bytes,
+                         void *stream);
+TG_API int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests, const int64_t *m_dev,
+                          int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout,
+                          int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off, int64_t *reply,
+                          void *stream);
+TG_API int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int64_t hop_cap,
+                        int32_t world, int32_t fanout, int32_t hop, int32_t n_hops, void *workspace, const uint32_t *cnt,
+                        const int64_t *cnt_prefix, const int64_t *reply, void *stream);
 
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */

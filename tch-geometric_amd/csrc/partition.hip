@@ -1,20 +1,27 @@
 // Device side of neighbor_sampling_homogenous over a RANGE-PARTITIONED CSC (SURVEY.md 8(e) mode 2, BASELINE cfg5).
-// The origin rank keeps the ordinary per-batch output slabs of tg_ns_homo_batched (samples | rows | cols |
-// edge_index | layer_offsets | counts) plus a small per-batch state; per hop
 //
-//   tg_part_requests   origin: every frontier slot of every batch becomes a request (vertex, call id, slot), bucketed
-//                      by the rank that owns the vertex's column (histogram + wave-aggregated scatter); req_pos
-//                      remembers where each frontier slot's request went.
-//   [all-to-all]       requests travel to their owners (host: torch.distributed / RCCL).
-//   tg_part_sample     owner: each request is sampled with the REQUESTER's draws (tag NS_HOMO, id = slot, call id =
-//                      the requester's batch) -- the same draws the replicated-graph sampler uses, so results are
-//                      equal bit for bit -- into a fixed-stride reply: k (neighbour, global edge pointer) pairs per
-//                      request, -1 padded.  Fixed stride = no size exchange, no owner-side read-back.
-//   [all-to-all]       replies travel back; they arrive in request order.
-//   tg_part_emit       origin: one workgroup per batch compacts its frontier's replies in slot order (the reference's
-//                      output order, neighbor_sampling.rs:195-218) into the slabs: counts -> LDS scan -> LDS staging ->
-//                      coalesced writes, then advances the batch state.
-// Only the bucket sizes (world integers) reach the host per hop.
+// The origin rank keeps the ordinary per-batch output slabs of tg_ns_homo_batched (samples | rows | cols |
+// edge_index | layer_offsets | counts) plus a per-batch state.  All sizes stay on the device: every kernel reads the
+// number of requests it works on from device memory, so with world == 1 the whole call runs without one host
+// synchronisation, and with world > 1 the host reads back only what `all_to_all_single` needs as split sizes.  Per hop:
+//
+//   tg_part_requests   origin: every frontier slot of every batch becomes a 16-byte request (vertex, batch, slot),
+//                      grouped by the rank that owns the vertex's column: per-batch requests in frontier order ->
+//                      counting sort by owner (per-block histograms, column scan, scatter: no global atomics);
+//                      req_pos remembers where each frontier slot's request went.  send_counts[world] on the device.
+//   [sizes + requests all-to-all]
+//   tg_part_count      owner: sample count of every received request (min(deg, k), or k with replacement), their
+//                      exclusive prefix = where each request's samples start in the COMPACT reply, and the number of
+//                      reply entries per requesting rank (the split sizes of the reply exchange).
+//   tg_part_sample     owner: draws with the REQUESTER's address (tag NS_HOMO, id = slot, call id = the requester's
+//                      first call id + batch) -- the draws the replicated-graph sampler uses, so results are equal
+//                      bit for bit -- gathers the neighbour ids and writes (neighbour, global edge pointer) pairs,
+//                      coalesced (consecutive requests have consecutive replies).
+//   [counts + replies all-to-all: counts [m] u32 in request order, pairs compact]
+//   tg_part_emit       origin: prefix of the returned counts -> each request's reply offset; one workgroup per batch
+//                      copies its frontier's replies in slot order (the reference's output order,
+//                      neighbor_sampling.rs:195-218) into the slabs (counts -> LDS scan -> LDS staging -> coalesced
+//                      writes) and advances the batch state.
 #include "ns_tickets.h"
 #include "tg_device.h"
 #include "tg_host.h"
@@ -22,143 +29,197 @@
 namespace tg {
 
 constexpr int PART_MAX_WORLD = 64;
+constexpr int PART_BLOCKS = 256; // blocks of the bucketing kernels = rows of the owner histogram
+constexpr int PART_THREADS = 512;
+constexpr int PART_TILE = 4096;
 constexpr int PART_CHUNKS_PER_ROUND = 1024;
+constexpr int PSCAN_BLOCKS_HOST = 1024; // = PSCAN_BLOCKS (block sums of the device-length prefix sum)
 
-// state[b*4 ..] = {frontier begin, frontier end, edges so far, -}
-__global__ void part_init_kernel(const int64_t *__restrict__ seeds, int64_t n_batches, int64_t n_seeds, int64_t *samples,
-                                 int64_t cap_nodes, int64_t *state) {
-    const int64_t total = n_batches * n_seeds;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = t / n_seeds, i = t - b * n_seeds;
-        samples[b * cap_nodes + i] = seeds[t];
-    }
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_batches; b += (int64_t)gridDim.x * blockDim.x) {
-        state[b * 4 + 0] = 0;
-        state[b * 4 + 1] = n_seeds;
-        state[b * 4 + 2] = 0;
-        state[b * 4 + 3] = 0;
-    }
-}
+struct PartRequest { // 16 bytes on the wire
+    int64_t vertex;
+    uint32_t batch; // the requester's batch: call id = its first call id + batch
+    uint32_t slot;  // slot of the vertex in that batch's sample list = the draw id
+};
+static_assert(sizeof(PartRequest) == 16, "request layout");
 
-// batch_off[b] = sum of frontier sizes of the batches before b; batch_off[n_batches] = number of requests.
-// One workgroup.  Also clears the bucket histogram and cursors.
-__global__ void part_sizes_kernel(const int64_t *__restrict__ state, int64_t n_batches, int64_t *batch_off, int64_t *hist,
-                                  int64_t *cursor, int world) {
-    __shared__ int64_t wave_tot[16];
-    __shared__ int64_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    if (tid < world) {
-        hist[tid] = 0;
-        cursor[tid] = 0;
-    }
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_batches; base += blockDim.x) {
-        const int64_t b = base + tid;
-        const int64_t v = (b < n_batches) ? state[b * 4 + 1] - state[b * 4 + 0] : 0;
-        const int64_t incl = wave_inclusive_scan(v);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int64_t before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wave_tot[w];
-        if (b < n_batches) batch_off[b] = before + incl - v;
-        __syncthreads();
-        if (tid == 0) {
-            int64_t t = carry_s;
-            for (int w = 0; w < n_waves; ++w) t += wave_tot[w];
-            carry_s = t;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) batch_off[n_batches] = carry_s;
-}
-
-struct PartReqParams {
-    const int64_t *samples, *state, *batch_off;
-    int64_t cap_nodes, n_batches, shard_size, first_call_id;
-    int world;
-    int64_t *hist, *cursor;
-    int64_t *req;     // [M][3] vertex, call id, slot -- bucketed by owner
-    int64_t *req_pos; // [M] flat frontier index -> position of its request
+struct PartState {
+    int64_t begin, end, ne, fbase;
 };
 
-__device__ __forceinline__ void part_locate(const PartReqParams &p, int64_t f, int64_t &b, int64_t &i) {
-    int64_t lo = 0, hi = p.n_batches; // last b with batch_off[b] <= f
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (p.batch_off[mid] <= f)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    b = lo;
-    i = p.state[b * 4 + 0] + (f - p.batch_off[b]);
+// workspace (int64 words unless noted); host side: part_layout()
+struct PartLayout {
+    size_t state, n_req, send_counts, hist, base, req_in, req_pos, poff, scan_tmp, total;
+    size_t scan_tmp_bytes;
+};
+
+static PartLayout part_layout(int64_t n_batches, int64_t request_cap, int world) {
+    PartLayout L;
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) & ~(size_t)255;
+        return here;
+    };
+    L.state = take((size_t)n_batches * sizeof(PartState));
+    L.n_req = take(sizeof(unsigned long long) * 2);
+    L.send_counts = take(sizeof(int64_t) * (size_t)(world + 1));
+    L.hist = take((size_t)PART_BLOCKS * PART_MAX_WORLD * sizeof(uint32_t));
+    L.base = take((size_t)(PART_MAX_WORLD + 1) * sizeof(int64_t));
+    L.req_in = take((size_t)request_cap * sizeof(PartRequest));
+    L.req_pos = take((size_t)request_cap * sizeof(uint32_t));
+    L.poff = take((size_t)(request_cap + 1) * sizeof(int64_t));
+    L.scan_tmp_bytes = (size_t)(PSCAN_BLOCKS_HOST + 1) * sizeof(int64_t);
+    L.scan_tmp = take(L.scan_tmp_bytes);
+    L.total = at;
+    return L;
 }
 
-template <bool SCATTER> __global__ void part_bucket_kernel(const PartReqParams p) {
-    __shared__ int64_t base[PART_MAX_WORLD];
-    if (SCATTER) { // bucket bases = exclusive prefix of the histogram (world values: every workgroup recomputes them)
-        if (threadIdx.x == 0) {
-            int64_t acc = 0;
-            for (int o = 0; o < p.world; ++o) {
-                base[o] = acc;
-                acc += p.hist[o];
-            }
+// ---------------------------------------------------------------- begin: seeds -> slabs, frontier = the seeds
+__global__ void part_init_kernel(const int64_t *__restrict__ seeds, int64_t n_batches, int64_t n_seeds, int64_t *samples,
+                                 int64_t cap_nodes, PartState *state, int64_t *counts, int32_t n_hops) {
+    const int64_t b = blockIdx.x;
+    for (int64_t i = threadIdx.x; i < n_seeds; i += blockDim.x) samples[b * cap_nodes + i] = seeds[b * n_seeds + i];
+    if (threadIdx.x == 0) {
+        state[b] = PartState{0, n_seeds, 0, 0};
+        if (n_hops == 0) {
+            counts[b * 2 + 0] = n_seeds;
+            counts[b * 2 + 1] = 0;
         }
-        __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int64_t M = p.batch_off[p.n_batches];
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t f0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); f0 < M; f0 += step) {
-        const int64_t f = f0 + lane;
-        const bool valid = f < M;
-        int64_t b = 0, i = 0, v = 0;
-        int owner = -1;
-        if (valid) {
-            part_locate(p, f, b, i);
-            v = p.samples[b * p.cap_nodes + i];
-            const int64_t o = v / p.shard_size;
-            owner = (int)(o < (int64_t)p.world - 1 ? o : (int64_t)p.world - 1);
+}
+
+// ---------------------------------------------------------------- requests, step 1: frontier order, per batch
+__global__ void part_requests_kernel(const int64_t *__restrict__ samples, int64_t cap_nodes, PartState *state,
+                                     unsigned long long *n_req, PartRequest *req_in) {
+    __shared__ int64_t fbase_s;
+    const int64_t b = blockIdx.x;
+    const PartState st = state[b];
+    if (threadIdx.x == 0) {
+        fbase_s = (int64_t)atomicAdd(n_req, (unsigned long long)(st.end - st.begin)); // batch order does not matter
+        state[b].fbase = fbase_s;
+    }
+    __syncthreads();
+    const int64_t fbase = fbase_s;
+    for (int64_t i = st.begin + threadIdx.x; i < st.end; i += blockDim.x)
+        req_in[fbase + (i - st.begin)] = PartRequest{samples[b * cap_nodes + i], (uint32_t)b, (uint32_t)i};
+}
+
+__device__ __forceinline__ int part_owner(int64_t v, int64_t shard_size, int world) {
+    const int64_t o = v / shard_size;
+    return (int)(o < (int64_t)world - 1 ? o : (int64_t)world - 1);
+}
+
+// ---------------------------------------------------------------- requests, step 2: counting sort by owner
+__global__ void __launch_bounds__(PART_THREADS) part_hist_kernel(const PartRequest *__restrict__ req_in,
+                                                                  const unsigned long long *n_req, int64_t shard_size,
+                                                                  int world, uint32_t *hist) {
+    __shared__ uint32_t h[PART_MAX_WORLD];
+    if (threadIdx.x < PART_MAX_WORLD) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t n = *n_req;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * PART_TILE; t0 < n; t0 += (uint64_t)gridDim.x * PART_TILE)
+        for (uint64_t j = t0 + threadIdx.x; j < min(n, t0 + PART_TILE); j += blockDim.x)
+            atomicAdd(&h[part_owner(req_in[j].vertex, shard_size, world)], 1u);
+    __syncthreads();
+    if (threadIdx.x < world) hist[(size_t)blockIdx.x * PART_MAX_WORLD + threadIdx.x] = h[threadIdx.x];
+}
+
+// one block: hist[row][owner] -> running offsets per owner over the rows; base[owner] = bucket start; send_counts
+__global__ void part_scan_kernel(uint32_t *hist, int n_rows, int world, int64_t *base, int64_t *send_counts) {
+    __shared__ int64_t tot[PART_MAX_WORLD];
+    const int o = threadIdx.x;
+    if (o < world) {
+        uint32_t run = 0;
+        for (int r = 0; r < n_rows; ++r) {
+            uint32_t *cell = hist + (size_t)r * PART_MAX_WORLD + o;
+            const uint32_t v = *cell;
+            *cell = run;
+            run += v;
         }
-        // one atomic per (wavefront, owner): lanes of the same owner are ranked by ballot
-        uint64_t todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int o = __shfl(owner, leader, 64);
-            const uint64_t same = __ballot(valid && owner == o);
-            int64_t start = 0;
-            if (lane == leader)
-                start = (int64_t)atomicAdd(reinterpret_cast<unsigned long long *>(SCATTER ? &p.cursor[o] : &p.hist[o]),
-                                           (unsigned long long)__popcll(same));
-            if (SCATTER) {
-                start = __shfl(start, leader, 64);
-                if (valid && owner == o) {
-                    const int64_t pos = base[o] + start + (int64_t)__popcll(same & lt_mask);
-                    p.req[pos * 3 + 0] = v;
-                    p.req[pos * 3 + 1] = p.first_call_id + b;
-                    p.req[pos * 3 + 2] = i;
-                    p.req_pos[f] = pos;
-                }
-            }
-            todo &= ~same;
+        tot[o] = run;
+        send_counts[o] = run;
+    }
+    __syncthreads();
+    if (o == 0) {
+        int64_t acc = 0;
+        for (int w = 0; w < world; ++w) {
+            base[w] = acc;
+            acc += tot[w];
         }
+        base[world] = acc;
+        send_counts[world] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const PartRequest *__restrict__ req_in,
+                                                                     const unsigned long long *n_req, int64_t shard_size,
+                                                                     int world, const uint32_t *hist, const int64_t *base,
+                                                                     PartRequest *req_out, uint32_t *req_pos) {
+    __shared__ uint32_t cur[PART_MAX_WORLD];
+    if (threadIdx.x < world)
+        cur[threadIdx.x] = (uint32_t)base[threadIdx.x] + hist[(size_t)blockIdx.x * PART_MAX_WORLD + threadIdx.x];
+    __syncthreads();
+    const uint64_t n = *n_req;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * PART_TILE; t0 < n; t0 += (uint64_t)gridDim.x * PART_TILE)
+        for (uint64_t j = t0 + threadIdx.x; j < min(n, t0 + PART_TILE); j += blockDim.x) {
+            const PartRequest r = req_in[j];
+            const uint32_t pos = atomicAdd(&cur[part_owner(r.vertex, shard_size, world)], 1u);
+            req_out[pos] = r;
+            req_pos[j] = pos;
+        }
+}
+
+// world == 1: the frontier order IS the request order
+__global__ void part_identity_kernel(const PartRequest *__restrict__ req_in, const unsigned long long *n_req,
+                                     PartRequest *req_out, uint32_t *req_pos, int64_t *send_counts) {
+    const uint64_t n = *n_req;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        req_out[j] = req_in[j];
+        req_pos[j] = (uint32_t)j;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        send_counts[0] = (int64_t)n;
+        send_counts[1] = (int64_t)n;
     }
 }
 
 // ---------------------------------------------------------------- owner side
-struct PartSampleParams {
+struct PartOwnerParams {
     const int64_t *ptrs, *indices;
+    const uint32_t *indices32; // optional u32 shadow of `indices`
     int64_t n_major, v_lo, e_lo;
-    const int64_t *req; // [m][3]
-    int64_t m;
-    int32_t k, replace;
+    const PartRequest *req;
+    const int64_t *m_dev; // number of requests (device)
+    int32_t k, replace, world;
     uint64_t seed;
-    int64_t *reply; // [m][k][2]
+    int64_t seg_off[PART_MAX_WORLD + 1]; // requests of requesting rank p: [seg_off[p], seg_off[p+1])
+    uint64_t seg_call0[PART_MAX_WORLD];  // that rank's first call id
+    uint32_t *cnt;                       // [m]
+    const int64_t *off;                  // [m] exclusive prefix of cnt
+    int64_t *reply;                      // [sum cnt][2]
+    int64_t *reply_counts;               // [world + 1] reply entries per requesting rank, total
 };
 
-template <int KMAX> __global__ void part_sample_kernel(const PartSampleParams p) {
+__global__ void part_count_kernel(const PartOwnerParams p) {
+    const int64_t m = *p.m_dev;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = p.req[j].vertex - p.v_lo;
+        int64_t deg = 0;
+        if (w >= 0 && w < p.n_major) deg = p.ptrs[w + 1] - p.ptrs[w];
+        p.cnt[j] = (deg <= 0) ? 0u : (p.replace ? (uint32_t)p.k : (uint32_t)min(deg, (int64_t)p.k));
+    }
+}
+
+// reply entries per requesting rank, from the prefix (one thread per rank)
+__global__ void part_reply_counts_kernel(const PartOwnerParams p) {
+    const int t = threadIdx.x;
+    const int64_t m = *p.m_dev;
+    auto at = [&](int64_t j) -> int64_t { return p.off[j >= m ? m : j]; };
+    if (t < p.world) p.reply_counts[t] = at(p.seg_off[t + 1]) - at(p.seg_off[t]);
+    if (t == 0) p.reply_counts[p.world] = at(m);
+}
+
+template <int KMAX> __global__ void part_sample_kernel(const PartOwnerParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int k = p.k;
@@ -166,54 +227,76 @@ template <int KMAX> __global__ void part_sample_kernel(const PartSampleParams p)
     unsigned char *wbase = smem + (size_t)wave * wave_bytes;
     int64_t *ebase = reinterpret_cast<int64_t *>(wbase);
     uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 64 * sizeof(int64_t));
-    uint8_t *scratch_lane = reinterpret_cast<uint8_t *>(wbase + 64 * sizeof(int64_t) + (size_t)64 * k * sizeof(uint32_t));
-    const int64_t n_chunks = (p.m + 63) >> 6;
+    uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 64 * sizeof(int64_t) + (size_t)64 * k * sizeof(uint32_t));
+    const int64_t m = *p.m_dev;
+    const int64_t n_chunks = (m + 63) >> 6;
     for (int64_t c = (int64_t)blockIdx.x * n_waves + wave; c < n_chunks; c += (int64_t)gridDim.x * n_waves) {
         const int64_t j0 = c << 6, j = j0 + lane;
-        int64_t e0 = 0, deg = 0, call = 0, slot = 0;
-        if (j < p.m) {
-            const int64_t w = p.req[j * 3 + 0] - p.v_lo;
-            call = p.req[j * 3 + 1];
-            slot = p.req[j * 3 + 2];
-            if (w >= 0 && w < p.n_major) {
+        int64_t e0 = 0;
+        uint32_t cnt = 0, n = 0;
+        uint64_t call = 0, did = 0;
+        if (j < m) {
+            const PartRequest r = p.req[j];
+            const int64_t w = r.vertex - p.v_lo;
+            cnt = p.cnt[j];
+            if (cnt) {
                 e0 = p.ptrs[w];
-                deg = p.ptrs[w + 1] - e0;
+                n = (uint32_t)(p.ptrs[w + 1] - e0);
             }
+            int src = 0; // requesting rank of request j: the segment that holds j
+            while (src + 1 < p.world && p.seg_off[src + 1] <= j) ++src;
+            call = p.seg_call0[src] + (uint64_t)r.batch;
+            did = (uint64_t)r.slot;
         }
-        const uint32_t cnt = (deg <= 0) ? 0u : (p.replace ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        const uint32_t excl = incl - cnt;
+        const uint32_t total = __shfl(incl, 63, 64);
+        const int64_t out0 = (j0 < m) ? p.off[j0] : 0; // the chunk's replies are contiguous from here
         ebase[lane] = e0;
-        const uint32_t mine = (uint32_t)lane * (uint32_t)k; // fixed stride: slot s of this request at mine + s
-        for (uint32_t s = cnt; s < (uint32_t)k; ++s) spos[mine + s] = 0xffffffffu;
         if (cnt > 0) {
-            const CallKey ck = call_key(p.seed, (uint64_t)call, TAG_NS_HOMO);
-            const uint64_t did = (uint64_t)slot;
-            const uint32_t n = (uint32_t)deg;
+            const CallKey ck = call_key(p.seed, call, TAG_NS_HOMO);
             if (p.replace) { // sampling.rs:57-69
                 Draw d;
                 for (int s = 0; s < k; ++s) {
                     if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                    spos[mine + s] = bounded32(d.half(s & 1), n);
+                    spos[excl + s] = bounded32(d.half(s & 1), n);
+                    slane[excl + s] = (uint8_t)lane;
                 }
-            } else if (deg <= k) { // sampling.rs:12-15
-                for (uint32_t s = 0; s < cnt; ++s) spos[mine + s] = s;
+            } else if (n <= (uint32_t)k) { // sampling.rs:12-15
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    spos[excl + s] = s;
+                    slane[excl + s] = (uint8_t)lane;
+                }
             } else {
-                sample_tickets<KMAX>(ck, did, n, k, spos, scratch_lane, mine, lane);
+                sample_tickets<KMAX>(ck, did, n, k, spos, slane, excl, lane);
             }
         }
         wave_lds_handoff();
-        const uint32_t total = (uint32_t)(min((int64_t)64, p.m - j0) * k);
-        for (uint32_t q = lane; q < total; q += 64) {
-            const uint32_t l = q / (uint32_t)k;
-            const uint32_t pos = spos[q];
-            int64_t nbr = -1, ep = -1;
-            if (pos != 0xffffffffu) {
-                const int64_t e = ebase[l] + (int64_t)pos;
-                nbr = __builtin_nontemporal_load(&p.indices[e]);
-                ep = e + p.e_lo;
+        // gathers issued four per lane before the first store (unconditional loads, as in ns_homo.hip's emit)
+        for (uint32_t q0 = 0; q0 < total; q0 += 256) {
+            int64_t ep[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+                const uint32_t qq = q < total ? q : 0u;
+                ep[u] = ebase[slane[qq]] + (int64_t)spos[qq];
             }
-            int64_t *o = p.reply + ((j0 * k) + q) * 2;
-            o[0] = nbr;
-            o[1] = ep;
+            if (p.indices32) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (int64_t)__builtin_nontemporal_load(&p.indices32[ep[u]]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(&p.indices[ep[u]]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+                if (q < total) {
+                    int64_t *o = p.reply + (out0 + (int64_t)q) * 2;
+                    o[0] = v[u];
+                    o[1] = ep[u] + p.e_lo;
+                }
+            }
         }
         wave_lds_handoff();
     }
@@ -222,8 +305,11 @@ template <int KMAX> __global__ void part_sample_kernel(const PartSampleParams p)
 // ---------------------------------------------------------------- origin side: emit
 struct PartEmitParams {
     int64_t n_seeds, cap_nodes, cap_edges;
-    int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts, *state;
-    const int64_t *batch_off, *req_pos, *reply;
+    int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts;
+    PartState *state;
+    const uint32_t *req_pos, *cnt; // cnt: per request, request order (as returned)
+    const int64_t *poff;           // exclusive prefix of cnt
+    const int64_t *reply;          // pairs, compact, request order
     int32_t k, hop, n_hops;
 };
 
@@ -234,32 +320,28 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
     const int k = p.k;
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
     unsigned char *wbase = smem + ((((size_t)(PART_CHUNKS_PER_ROUND + 1) * 4) + 15) & ~(size_t)15) +
-                           (size_t)wave * 2 * (((size_t)64 * k + 15) & ~(size_t)15);
-    uint8_t *eslot = wbase;
-    uint8_t *elane = wbase + (((size_t)64 * k + 15) & ~(size_t)15);
+                           (size_t)wave * (64 * sizeof(int64_t) + 2 * (((size_t)64 * k + 15) & ~(size_t)15));
+    int64_t *rbase = reinterpret_cast<int64_t *>(wbase); // reply offset of each lane's request
+    uint8_t *eslot = wbase + 64 * sizeof(int64_t);
+    uint8_t *elane = eslot + (((size_t)64 * k + 15) & ~(size_t)15);
     int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges, *cols = p.cols + b * p.cap_edges, *eidx = p.edge_index + b * p.cap_edges;
-    const int64_t begin = p.state[b * 4 + 0], end = p.state[b * 4 + 1];
-    int64_t ne = p.state[b * 4 + 2];
-    const int64_t n_seeds = p.n_seeds, off_b = p.batch_off[b];
+    const PartState st = p.state[b];
+    const int64_t begin = st.begin, end = st.end, fbase = st.fbase;
+    int64_t ne = st.ne;
+    const int64_t n_seeds = p.n_seeds;
     if (tid == 0) { // neighbor_sampling.rs:193
         int64_t *lo = p.layer_offsets + (b * p.n_hops + p.hop) * 3;
         lo[0] = n_seeds + ne;
         lo[1] = ne;
         lo[2] = n_seeds + ne;
     }
-    auto count_of = [&](int64_t i) -> uint32_t { // replies are a prefix of valid pairs, then -1 padding
-        const int64_t *r = p.reply + p.req_pos[off_b + (i - begin)] * (int64_t)k * 2;
-        uint32_t c = 0;
-        while (c < (uint32_t)k && r[2 * c] >= 0) ++c;
-        return c;
-    };
     for (int64_t round_begin = begin; round_begin < end; round_begin += (int64_t)PART_CHUNKS_PER_ROUND * 64) {
         const int64_t round_end = min(end, round_begin + (int64_t)PART_CHUNKS_PER_ROUND * 64);
         const int nc = (int)((round_end - round_begin + 63) >> 6);
         for (int c = wave; c < nc; c += n_waves) {
             const int64_t i = round_begin + (int64_t)c * 64 + lane;
-            const uint32_t cnt = (i < round_end) ? count_of(i) : 0u;
+            const uint32_t cnt = (i < round_end) ? p.cnt[p.req_pos[fbase + (i - begin)]] : 0u;
             const uint32_t tot = wave_sum(cnt);
             if (lane == 0) chunk_off[c] = tot;
         }
@@ -278,10 +360,17 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
         for (int c = wave; c < nc; c += n_waves) {
             const int64_t i0 = round_begin + (int64_t)c * 64;
             const int64_t i = i0 + lane;
-            const uint32_t cnt = (i < round_end) ? count_of(i) : 0u;
+            uint32_t cnt = 0;
+            int64_t ro = 0;
+            if (i < round_end) {
+                const uint32_t rp = p.req_pos[fbase + (i - begin)];
+                cnt = p.cnt[rp];
+                ro = p.poff[rp];
+            }
             const uint32_t incl = wave_inclusive_scan(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = __shfl(incl, 63, 64);
+            rbase[lane] = ro;
             for (uint32_t s = 0; s < cnt; ++s) {
                 eslot[excl + s] = (uint8_t)s;
                 elane[excl + s] = (uint8_t)lane;
@@ -290,12 +379,12 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
             for (uint32_t q = lane; q < total; q += 64) {
                 const int l = elane[q];
-                const int64_t *r = p.reply + (p.req_pos[off_b + (i0 + l - begin)] * (int64_t)k + eslot[q]) * 2;
+                const int64_t *r = p.reply + (rbase[l] + (int64_t)eslot[q]) * 2;
                 const int64_t e = e_chunk + q;
-                samples[n_seeds + e] = r[0]; // :215
-                rows[e] = n_seeds + e;       // :217
-                cols[e] = i0 + l;
-                eidx[e] = r[1];
+                samples[n_seeds + e] = r[0];                                // :215 (the next hop's frontier)
+                __builtin_nontemporal_store(n_seeds + e, &rows[e]);        // :217
+                __builtin_nontemporal_store(i0 + (int64_t)l, &cols[e]);
+                __builtin_nontemporal_store(r[1], &eidx[e]);
             }
             wave_lds_handoff();
         }
@@ -304,12 +393,79 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
         __syncthreads();
     }
     if (tid == 0) { // :221-222
-        p.state[b * 4 + 0] = end;
-        p.state[b * 4 + 1] = n_seeds + ne;
-        p.state[b * 4 + 2] = ne;
+        p.state[b] = PartState{end, n_seeds + ne, ne, fbase};
         p.counts[b * 2 + 0] = n_seeds + ne;
         p.counts[b * 2 + 1] = ne;
     }
+}
+
+// ---------------------------------------------------------------- exclusive prefix of u32 counts, length on the device
+// (the host only knows an upper bound of the number of requests; scanning that bound would cost 5x the work)
+constexpr int PSCAN_BLOCKS = PSCAN_BLOCKS_HOST, PSCAN_THREADS = 256;
+
+__global__ void __launch_bounds__(PSCAN_THREADS) pscan_sums_kernel(const uint32_t *__restrict__ v, const int64_t *n_dev,
+                                                                    int64_t *block_sum) {
+    __shared__ int64_t ws[PSCAN_THREADS / 64];
+    const int64_t n = *n_dev;
+    const int64_t per = (n + PSCAN_BLOCKS - 1) / PSCAN_BLOCKS;
+    const int64_t lo = min(n, (int64_t)blockIdx.x * per), hi = min(n, lo + per);
+    int64_t s = 0;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += PSCAN_THREADS) s += v[j];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < PSCAN_THREADS / 64; ++w) t += ws[w];
+        block_sum[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(PSCAN_BLOCKS) pscan_top_kernel(int64_t *block_sum) { // -> exclusive, total at [BLOCKS]
+    __shared__ int64_t ws[PSCAN_BLOCKS / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t v = block_sum[t];
+    const int64_t incl = wave_inclusive_scan(v);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    int64_t before = 0;
+    for (int w = 0; w < wave; ++w) before += ws[w];
+    block_sum[t] = before + incl - v;
+    if (t == PSCAN_BLOCKS - 1) block_sum[PSCAN_BLOCKS] = before + incl;
+}
+
+__global__ void __launch_bounds__(PSCAN_THREADS) pscan_apply_kernel(const uint32_t *__restrict__ v, const int64_t *n_dev,
+                                                                     const int64_t *block_sum, int64_t *out) {
+    __shared__ int64_t ws[PSCAN_THREADS / 64];
+    __shared__ int64_t carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t n = *n_dev;
+    const int64_t per = (n + PSCAN_BLOCKS - 1) / PSCAN_BLOCKS;
+    const int64_t lo = min(n, (int64_t)blockIdx.x * per), hi = min(n, lo + per);
+    if (t == 0) carry_s = block_sum[blockIdx.x];
+    __syncthreads();
+    for (int64_t j0 = lo; j0 < hi; j0 += PSCAN_THREADS) {
+        const int64_t j = j0 + t;
+        const int64_t x = j < hi ? (int64_t)v[j] : 0;
+        const int64_t incl = wave_inclusive_scan(x);
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += ws[w];
+        if (j < hi) out[j] = before + incl - x;
+        __syncthreads();
+        if (t == PSCAN_THREADS - 1) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && t == 0) out[n] = block_sum[PSCAN_BLOCKS]; // total behind the last entry
+}
+
+static int part_scan(const uint32_t *v, const int64_t *n_dev, int64_t *block_sum, int64_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(pscan_sums_kernel, dim3(PSCAN_BLOCKS), dim3(PSCAN_THREADS), 0, s, v, n_dev, block_sum);
+    hipLaunchKernelGGL(pscan_top_kernel, dim3(1), dim3(PSCAN_BLOCKS), 0, s, block_sum);
+    hipLaunchKernelGGL(pscan_apply_kernel, dim3(PSCAN_BLOCKS), dim3(PSCAN_THREADS), 0, s, v, n_dev, block_sum, out);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
 }
 
 static inline unsigned part_grid(int64_t n, int threads, int64_t cap) {
@@ -321,82 +477,139 @@ static inline unsigned part_grid(int64_t n, int threads, int64_t cap) {
 
 } // namespace tg
 
-extern "C" int tg_part_workspace_bytes(int64_t n_batches, int32_t world, int64_t *bytes) {
-    TG_REQUIRE(bytes && n_batches >= 0 && world >= 1 && world <= tg::PART_MAX_WORLD,
-               "tg_part_workspace_bytes: bad arguments (world <= %d)", tg::PART_MAX_WORLD);
-    *bytes = (n_batches * 4 + (n_batches + 1) + 2 * (int64_t)world) * (int64_t)sizeof(int64_t);
+extern "C" int tg_part_workspace_bytes(int64_t n_batches, int64_t request_cap, int32_t world, int64_t *bytes) {
+    TG_REQUIRE(bytes && n_batches >= 0 && request_cap >= 0 && request_cap < ((int64_t)1 << 32) && world >= 1 &&
+                   world <= tg::PART_MAX_WORLD,
+               "tg_part_workspace_bytes: bad arguments (world <= %d, request_cap < 2^32)", tg::PART_MAX_WORLD);
+    *bytes = (int64_t)tg::part_layout(n_batches, request_cap, world).total;
     return TG_OK;
 }
 
-// workspace layout: state[n_batches*4] | batch_off[n_batches+1] | hist[world] | cursor[world]
-static inline int64_t *ws_state(void *ws) { return reinterpret_cast<int64_t *>(ws); }
-static inline int64_t *ws_batch_off(void *ws, int64_t nb) { return ws_state(ws) + nb * 4; }
-static inline int64_t *ws_hist(void *ws, int64_t nb) { return ws_batch_off(ws, nb) + nb + 1; }
-
-extern "C" int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, const tg_ns_out *out, void *workspace,
-                             void *stream) {
-    TG_REQUIRE(out && workspace && n_batches >= 0 && n_seeds >= 0 && (seeds || n_seeds == 0), "tg_part_begin: bad arguments");
-    TG_REQUIRE(out->samples && out->cap_nodes >= n_seeds, "tg_part_begin: samples slab too small");
+extern "C" int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, int32_t n_hops, const tg_ns_out *out,
+                             int64_t request_cap, int32_t world, void *workspace, void *stream) {
+    TG_REQUIRE(out && workspace && n_batches >= 0 && n_seeds >= 0 && (seeds || n_seeds == 0) && world >= 1 &&
+                   world <= tg::PART_MAX_WORLD && n_hops >= 0 && n_hops <= TG_MAX_HOPS,
+               "tg_part_begin: bad arguments");
+    TG_REQUIRE(out->samples && out->counts && out->cap_nodes >= n_seeds, "tg_part_begin: samples slab too small");
+    TG_REQUIRE(((uintptr_t)workspace & 255) == 0, "tg_part_begin: workspace must be 256-byte aligned");
     if (n_batches == 0) return TG_OK;
-    hipLaunchKernelGGL(tg::part_init_kernel, dim3(tg::part_grid(n_batches * (n_seeds > 0 ? n_seeds : 1), 256, 4096)), dim3(256), 0,
-                       (hipStream_t)stream, seeds, n_batches, n_seeds, out->samples, out->cap_nodes, ws_state(workspace));
+    const tg::PartLayout L = tg::part_layout(n_batches, request_cap, world);
+    unsigned char *w = static_cast<unsigned char *>(workspace);
+    hipLaunchKernelGGL(tg::part_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, (hipStream_t)stream, seeds, n_batches,
+                       n_seeds, out->samples, out->cap_nodes, reinterpret_cast<tg::PartState *>(w + L.state), out->counts,
+                       n_hops);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
 
 extern "C" int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t request_cap, int64_t shard_size,
-                                int32_t world, uint64_t first_call_id, void *workspace, int64_t *requests, int64_t *req_pos,
-                                void *stream) {
-    TG_REQUIRE(out && workspace && requests && req_pos && n_batches >= 1 && shard_size >= 1 && world >= 1 &&
+                                int32_t world, void *workspace, void *requests, int64_t *send_counts, void *stream) {
+    TG_REQUIRE(out && workspace && requests && send_counts && n_batches >= 1 && shard_size >= 1 && world >= 1 &&
                    world <= tg::PART_MAX_WORLD,
                "tg_part_requests: bad arguments");
+    using namespace tg;
     hipStream_t s = (hipStream_t)stream;
-    int64_t *hist = ws_hist(workspace, n_batches);
-    hipLaunchKernelGGL(tg::part_sizes_kernel, dim3(1), dim3(1024), 0, s, ws_state(workspace), n_batches,
-                       ws_batch_off(workspace, n_batches), hist, hist + world, (int)world);
-    tg::PartReqParams p;
-    p.samples = out->samples;
-    p.state = ws_state(workspace);
-    p.batch_off = ws_batch_off(workspace, n_batches);
-    p.cap_nodes = out->cap_nodes;
-    p.n_batches = n_batches;
-    p.shard_size = shard_size;
-    p.first_call_id = (int64_t)first_call_id;
-    p.world = world;
-    p.hist = hist;
-    p.cursor = hist + world;
-    p.req = requests;
-    p.req_pos = req_pos;
-    const unsigned grid = tg::part_grid(request_cap, 256, 2048);
-    hipLaunchKernelGGL(tg::part_bucket_kernel<false>, dim3(grid), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(tg::part_bucket_kernel<true>, dim3(grid), dim3(256), 0, s, p);
+    const PartLayout L = part_layout(n_batches, request_cap, world);
+    unsigned char *w = static_cast<unsigned char *>(workspace);
+    PartState *state = reinterpret_cast<PartState *>(w + L.state);
+    unsigned long long *n_req = reinterpret_cast<unsigned long long *>(w + L.n_req);
+    PartRequest *req_in = reinterpret_cast<PartRequest *>(w + L.req_in);
+    uint32_t *req_pos = reinterpret_cast<uint32_t *>(w + L.req_pos);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(w + L.hist);
+    int64_t *base = reinterpret_cast<int64_t *>(w + L.base);
+    TG_HIP(hipMemsetAsync(n_req, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(part_requests_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, out->samples, out->cap_nodes, state,
+                       n_req, req_in);
+    if (world == 1) {
+        hipLaunchKernelGGL(part_identity_kernel, dim3(part_grid(request_cap, 256, 4096)), dim3(256), 0, s, req_in, n_req,
+                           static_cast<PartRequest *>(requests), req_pos, send_counts);
+    } else {
+        hipLaunchKernelGGL(part_hist_kernel, dim3(PART_BLOCKS), dim3(PART_THREADS), 0, s, req_in, n_req, shard_size,
+                           (int)world, hist);
+        hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(64), 0, s, hist, PART_BLOCKS, (int)world, base, send_counts);
+        hipLaunchKernelGGL(part_scatter_kernel, dim3(PART_BLOCKS), dim3(PART_THREADS), 0, s, req_in, n_req, shard_size,
+                           (int)world, hist, base, static_cast<PartRequest *>(requests), req_pos);
+    }
+    // a copy of the sizes stays in the workspace for tg_part_emit
+    TG_HIP(hipMemcpyAsync(w + L.send_counts, send_counts, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyDeviceToDevice, s));
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
 
-extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const int64_t *requests, int64_t m,
-                              int32_t fanout, int32_t sampler, uint64_t seed, int64_t *reply, void *stream) {
-    TG_REQUIRE(shard && shard->ptrs && (shard->indices || shard->n_edges == 0), "tg_part_sample: null shard");
-    TG_REQUIRE(m >= 0 && fanout >= 1 && fanout <= TG_MAX_FANOUT, "tg_part_sample: fanout %d outside [1, %d]", fanout,
-               TG_MAX_FANOUT);
-    TG_REQUIRE(sampler == TG_SAMPLER_UNIFORM || sampler == TG_SAMPLER_UNIFORM_REPL, "tg_part_sample: unweighted samplers only");
-    if (m == 0) return TG_OK;
-    TG_REQUIRE(requests && reply, "tg_part_sample: null buffers");
-    tg::PartSampleParams p;
+static int part_owner_params(tg::PartOwnerParams &p, const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests,
+                             const int64_t *m_dev, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
+                             int32_t fanout, int32_t sampler, uint64_t seed) {
+    TG_REQUIRE(shard && shard->ptrs && (shard->indices || shard->n_edges == 0), "tg_part: null shard");
+    TG_REQUIRE(fanout >= 1 && fanout <= TG_MAX_FANOUT, "tg_part: fanout %d outside [1, %d]", fanout, TG_MAX_FANOUT);
+    TG_REQUIRE(sampler == TG_SAMPLER_UNIFORM || sampler == TG_SAMPLER_UNIFORM_REPL, "tg_part: unweighted samplers only");
+    TG_REQUIRE(world >= 1 && world <= tg::PART_MAX_WORLD && seg_off && seg_call0 && m_dev && requests,
+               "tg_part: bad owner arguments");
     p.ptrs = shard->ptrs;
     p.indices = shard->indices;
+    p.indices32 = shard->indices32;
     p.n_major = shard->n_major;
     p.v_lo = v_lo;
     p.e_lo = e_lo;
-    p.req = requests;
-    p.m = m;
+    p.req = static_cast<const tg::PartRequest *>(requests);
+    p.m_dev = m_dev;
     p.k = fanout;
     p.replace = sampler == TG_SAMPLER_UNIFORM_REPL;
+    p.world = world;
     p.seed = seed;
+    for (int i = 0; i <= world; ++i) p.seg_off[i] = seg_off[i];
+    for (int i = 0; i < world; ++i) p.seg_call0[i] = seg_call0[i];
+    return TG_OK;
+}
+
+extern "C" int tg_part_count(const tg_graph *shard, int64_t v_lo, const void *requests, const int64_t *m_dev, int64_t m_cap,
+                             int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout,
+                             int32_t sampler, uint32_t *cnt, int64_t *off, int64_t *reply_counts, void *scan_tmp,
+                             int64_t scan_tmp_bytes, void *stream) {
+    tg::PartOwnerParams p;
+    int rc = part_owner_params(p, shard, v_lo, 0, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, 0);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(cnt && off && reply_counts && m_cap >= 0, "tg_part_count: null buffers");
+    if (m_cap == 0) {
+        TG_HIP(hipMemsetAsync(reply_counts, 0, sizeof(int64_t) * (size_t)(world + 1), (hipStream_t)stream));
+        return TG_OK;
+    }
+    p.cnt = cnt;
+    p.off = off;
+    p.reply = nullptr;
+    p.reply_counts = reply_counts;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tg::part_count_kernel, dim3(tg::part_grid(m_cap, 256, 4096)), dim3(256), 0, s, p);
+    TG_REQUIRE(scan_tmp && scan_tmp_bytes >= (int64_t)((tg::PSCAN_BLOCKS + 1) * sizeof(int64_t)),
+               "tg_part_count: scan workspace too small");
+    rc = tg::part_scan(cnt, m_dev, static_cast<int64_t *>(scan_tmp), off, s); // off[0 .. m], off[m] = total
+    if (rc != TG_OK) return rc;
+    hipLaunchKernelGGL(tg::part_reply_counts_kernel, dim3(1), dim3(64), 0, s, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_part_scan_workspace_bytes(int64_t n, int64_t *bytes) {
+    TG_REQUIRE(bytes && n >= 0, "tg_part_scan_workspace_bytes: bad arguments");
+    *bytes = (int64_t)((tg::PSCAN_BLOCKS + 1) * sizeof(int64_t));
+    return TG_OK;
+}
+
+extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests, const int64_t *m_dev,
+                              int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
+                              int32_t fanout, int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off,
+                              int64_t *reply, void *stream) {
+    tg::PartOwnerParams p;
+    int rc = part_owner_params(p, shard, v_lo, e_lo, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed);
+    if (rc != TG_OK) return rc;
+    if (m_cap == 0) return TG_OK;
+    TG_REQUIRE(cnt && off && reply, "tg_part_sample: null buffers");
+    p.cnt = const_cast<uint32_t *>(cnt);
+    p.off = off;
     p.reply = reply;
+    p.reply_counts = nullptr;
     const int n_waves = 4;
     const size_t lds = (size_t)n_waves * (64 * sizeof(int64_t) + (size_t)64 * fanout * 4 + (((size_t)64 * fanout + 15) & ~(size_t)15));
-    const unsigned grid = tg::part_grid((m + 63) / 64, n_waves, 256 * 32);
+    const unsigned grid = tg::part_grid((m_cap + 63) / 64, n_waves, 256 * 16);
     if (fanout <= 16)
         hipLaunchKernelGGL(tg::part_sample_kernel<16>, dim3(grid), dim3(64 * n_waves), lds, (hipStream_t)stream, p);
     else
@@ -405,14 +618,28 @@ extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo,
     return TG_OK;
 }
 
-extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int32_t fanout, int32_t hop,
-                            int32_t n_hops, void *workspace, const int64_t *req_pos, const int64_t *reply, void *stream) {
-    TG_REQUIRE(out && workspace && req_pos && n_batches >= 1 && fanout >= 1 && fanout <= TG_MAX_FANOUT && hop >= 0 &&
+extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int64_t hop_cap,
+                            int32_t world, int32_t fanout, int32_t hop, int32_t n_hops, void *workspace,
+                            const uint32_t *cnt, const int64_t *cnt_prefix, const int64_t *reply, void *stream) {
+    TG_REQUIRE(out && workspace && cnt && n_batches >= 1 && fanout >= 1 && fanout <= TG_MAX_FANOUT && hop >= 0 &&
                    hop < n_hops && n_hops <= TG_MAX_HOPS,
                "tg_part_emit: bad arguments");
     TG_REQUIRE(out->samples && out->rows && out->cols && out->edge_index && out->layer_offsets && out->counts,
                "tg_part_emit: null output slabs");
-    tg::PartEmitParams p;
+    using namespace tg;
+    hipStream_t s = (hipStream_t)stream;
+    const PartLayout L = part_layout(n_batches, request_cap, world);
+    unsigned char *w = static_cast<unsigned char *>(workspace);
+    const int64_t *poff = cnt_prefix;
+    TG_REQUIRE(hop_cap >= 0 && hop_cap <= request_cap, "tg_part_emit: hop_cap outside [0, request_cap]");
+    if (!poff) { // reply offset of every request: prefix of the returned counts (the number of requests is on the device)
+        int64_t *mine = reinterpret_cast<int64_t *>(w + L.poff);
+        const int64_t *n_dev = reinterpret_cast<const int64_t *>(w + L.send_counts) + world; // total written by tg_part_requests
+        int rc = part_scan(cnt, n_dev, reinterpret_cast<int64_t *>(w + L.scan_tmp), mine, s);
+        if (rc != TG_OK) return rc;
+        poff = mine;
+    }
+    PartEmitParams p;
     p.n_seeds = n_seeds;
     p.cap_nodes = out->cap_nodes;
     p.cap_edges = out->cap_edges;
@@ -422,17 +649,18 @@ extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_s
     p.edge_index = out->edge_index;
     p.layer_offsets = out->layer_offsets;
     p.counts = out->counts;
-    p.state = ws_state(workspace);
-    p.batch_off = ws_batch_off(workspace, n_batches);
-    p.req_pos = req_pos;
+    p.state = reinterpret_cast<PartState *>(w + L.state);
+    p.req_pos = reinterpret_cast<uint32_t *>(w + L.req_pos);
+    p.cnt = cnt;
+    p.poff = poff;
     p.reply = reply;
     p.k = fanout;
     p.hop = hop;
     p.n_hops = n_hops;
     const int threads = 512;
-    const size_t lds = ((((size_t)(tg::PART_CHUNKS_PER_ROUND + 1) * 4) + 15) & ~(size_t)15) +
-                       (size_t)(threads / 64) * 2 * (((size_t)64 * fanout + 15) & ~(size_t)15);
-    hipLaunchKernelGGL(tg::part_emit_kernel, dim3((unsigned)n_batches), dim3(threads), lds, (hipStream_t)stream, p);
+    const size_t lds = ((((size_t)(PART_CHUNKS_PER_ROUND + 1) * 4) + 15) & ~(size_t)15) +
+                       (size_t)(threads / 64) * (64 * sizeof(int64_t) + 2 * (((size_t)64 * fanout + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(part_emit_kernel, dim3((unsigned)n_batches), dim3(threads), lds, s, p);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

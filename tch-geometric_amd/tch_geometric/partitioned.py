@@ -15,10 +15,9 @@ xGMI is point-to-point and these messages are small (<= 16 B per request, 16 B p
 latency-bound: all batches of a call travel in ONE set of collectives per hop.  With the "nccl" backend (RCCL)
 device tensors go straight into all_to_all_single; with "gloo" (tests) they are staged through the host.
 
-`ns_homo_partitioned_device` is the device form (csrc/partition.hip kernels, fixed-stride replies, ordinary per-batch
-output slabs); `ns_homo_partitioned` below is the same protocol spelled in torch operations, kept because it also
-runs on CPU tensors with any owner-side sampler (the gloo tests use the oracle there).
-Only the unweighted, unfiltered samplers are partitioned in this round.
+`PartitionedSampler` is the device form (csrc/partition.hip kernels, compact replies, ordinary per-batch output slabs,
+buffers allocated once); `ns_homo_partitioned` below is the same protocol spelled in torch operations, kept because it
+also runs on CPU tensors with any owner-side sampler (the gloo tests use the oracle there).
 """
 import torch
 import torch.distributed as dist
@@ -38,8 +37,9 @@ class CscShard:
         self._view = None
 
     def graph_view(self):
-        if self._view is None:
-            self._view = _cabi.graph_view(self.ptrs, self.indices)
+        if self._view is None:   # u32 shadow of the neighbour ids: half the bytes per gathered line (ids < 2^32)
+            i32 = self.indices.to(torch.int32) if self.n_nodes < 2 ** 32 and self.indices.is_cuda else None
+            self._view = _cabi.graph_view(self.ptrs, self.indices, indices32=i32)
         return self._view
 
     @staticmethod
@@ -81,11 +81,19 @@ def _all_to_all_rows(send, send_counts, recv_counts, group):
     return r
 
 
-def _exchange_counts(counts, group):
+def _exchange_counts(counts, group, device=None):
+    """all-to-all of one integer per peer.  `counts`: python list or a [world] int64 tensor.  RCCL ("nccl") only takes
+    device tensors, so the counts travel on `device` there; gloo stages them on the host.  Returns a python list
+    (one read-back)."""
     world, _ = _world(group)
-    c = torch.as_tensor(counts, dtype=torch.int64)
-    return [int(x) for x in _all_to_all_rows(c.reshape(world, 1), [1] * world, [1] * world, group).reshape(-1)] \
-        if world > 1 else list(counts)
+    if world == 1:
+        return [int(x) for x in (counts.tolist() if torch.is_tensor(counts) else counts)]
+    c = counts if torch.is_tensor(counts) else torch.as_tensor(counts, dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        if device is None or torch.device(device).type == "cpu":
+            raise ValueError("the %s backend needs the compute device for the size exchange" % dist.get_backend(group))
+        c = c.to(device)
+    return [int(x) for x in _all_to_all_rows(c.reshape(world, 1), [1] * world, [1] * world, group).reshape(-1).tolist()]
 
 
 def _hip_hop(shard, local_vertices, call_ids, slot_ids, k, seed, sampler):
@@ -116,54 +124,144 @@ def _a2a_flat(send, send_rows, recv_rows, row_len, group):
     return _all_to_all_rows(send.reshape(-1, row_len), send_rows, recv_rows, group).reshape(-1)
 
 
-def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None):
-    """The device form of the exchange (csrc/partition.hip): the origin keeps the ordinary per-batch slabs of
-    tg_ns_homo_batched; per hop  tg_part_requests -> all-to-all -> tg_part_sample (owner, fixed-stride replies, so no
-    reply sizes are exchanged) -> all-to-all -> tg_part_emit.  The host reads only the bucket sizes (world integers)
-    per hop.  Returns an `_cabi.NsBatchedOut` whose contents equal the replicated-graph sampler's bit for bit."""
-    import ctypes as C
-    lib, ptr = _cabi.lib, _cabi.ptr
-    world, rank = _world(group)
-    dev = seeds.device
-    nb, B = seeds.shape
-    H = len(fanout)
-    out = _cabi.NsBatchedOut(nb, B, fanout, dev)
-    so = out.struct()
-    stream = _cabi.stream_ptr(dev)
-    nbytes = C.c_int64(0)
-    _cabi.check(lib.tg_part_workspace_bytes(C.c_int64(nb), C.c_int32(world), C.byref(nbytes)))
-    ws = torch.zeros(nbytes.value // 8, dtype=torch.int64, device=dev)
-    seeds = seeds.contiguous()
-    _cabi.check(lib.tg_part_begin(ptr(seeds), C.c_int64(nb), C.c_int64(B), C.byref(so), ptr(ws), stream))
-    hist_at = 4 * nb + nb + 1                          # bucket_sizes[world] inside the workspace (include/tchgeo.h)
-    graph = shard.graph_view()
-    cap = nb * B                                       # worst-case frontier of the hop
-    for h, k in enumerate(fanout):
-        req = torch.empty(cap * 3, dtype=torch.int64, device=dev)
-        req_pos = torch.empty(cap, dtype=torch.int64, device=dev)
-        _cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(cap), C.c_int64(shard.shard_size),
-                                         C.c_int32(world), C.c_uint64(first_call_id), ptr(ws), ptr(req), ptr(req_pos), stream))
-        send = ws[hist_at:hist_at + world].tolist()    # the hop's only read-back: requests per owner
-        m_send = int(sum(send))
-        if world > 1:
-            recv = _exchange_counts(send, group)
-            got = _a2a_flat(req[:m_send * 3], send, recv, 3, group)
+class PartitionedSampler:
+    """The device form of the exchange (csrc/partition.hip) with every buffer allocated once and reused across calls.
+
+    Per hop: tg_part_requests -> [sizes, requests all-to-all] -> tg_part_count / tg_part_sample (owner: compact replies
+    = per-request counts + (neighbour, global edge pointer) pairs) -> [counts, reply sizes, replies all-to-all] ->
+    tg_part_emit.  Every size lives on the device; with world == 1 nothing is read back at all, with world > 1 the host
+    reads only the all-to-all split sizes (two small read-backs per hop).  The returned `_cabi.NsBatchedOut` equals
+    the replicated-graph sampler's bit for bit."""
+
+    def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None):
+        import ctypes as C
+        self.C, self.shard, self.group, self.sampler = C, shard, group, sampler
+        self.world, self.rank = _world(group)
+        self.nb, self.B, self.fanout = int(n_batches), int(n_seeds), [int(k) for k in fanout]
+        self.dev = shard.ptrs.device
+        self.hop_cap, cap = [], self.nb * self.B
+        for k in self.fanout:
+            self.hop_cap.append(cap)
+            cap *= k
+        self.request_cap = max(self.hop_cap + [1])
+        self.out = _cabi.NsBatchedOut(self.nb, self.B, self.fanout, self.dev)
+        nbytes = C.c_int64(0)
+        _cabi.check(_cabi.lib.tg_part_workspace_bytes(C.c_int64(self.nb), C.c_int64(self.request_cap),
+                                                      C.c_int32(self.world), C.byref(nbytes)))
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        self.ws = torch.empty(nbytes.value // 8 + 1, **i64)
+        self.requests = torch.empty((self.request_cap, 2), **i64)            # 16-byte requests
+        self.send_counts = torch.zeros(self.world + 1, **i64)
+        self.reply_counts = torch.zeros(self.world + 1, **i64)
+        self._bufs = {}
+        self.gloo = self.world > 1 and dist.get_backend(group) == "gloo"
+
+    def _buf(self, name, n, dtype, cols=None):
+        """persistent scratch that only ever grows"""
+        t = self._bufs.get(name)
+        need = max(int(n), 1)
+        if t is None or t.shape[0] < need:
+            t = torch.empty((need,) if cols is None else (need, cols), dtype=dtype, device=self.dev)
+            self._bufs[name] = t
+        return t
+
+    def _a2a(self, send, send_rows, recv_rows, name):
+        """all_to_all_v over dim 0 into a persistent buffer (RCCL: device tensors; gloo: staged through the host)"""
+        n_recv = int(sum(recv_rows))
+        recv = self._buf(name, n_recv, send.dtype, send.shape[1] if send.dim() > 1 else None)[:n_recv]
+        if self.gloo:
+            r = torch.empty(recv.shape, dtype=send.dtype)
+            dist.all_to_all_single(r, send.cpu().contiguous(), output_split_sizes=list(recv_rows),
+                                   input_split_sizes=list(send_rows), group=self.group)
+            recv.copy_(r)
         else:
-            recv, got = send, req
-        m_recv = int(sum(recv))
-        reply = torch.empty(max(m_recv, 1) * k * 2, dtype=torch.int64, device=dev)
-        _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
-                                       C.c_int64(m_recv), C.c_int32(int(k)), C.c_int32(sampler), C.c_uint64(seed),
-                                       ptr(reply), stream))
-        back = _a2a_flat(reply[:m_recv * k * 2], recv, send, 2 * k, group) if world > 1 else reply
-        if back.numel() == 0:
-            back = torch.empty(2, dtype=torch.int64, device=dev)
-        _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int32(int(k)), C.c_int32(h), C.c_int32(H),
-                                     ptr(ws), ptr(req_pos), ptr(back), stream))
-        cap *= k
-    if H == 0:
-        out.counts[:, 0] = B
-    return out
+            dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=list(recv_rows),
+                                   input_split_sizes=list(send_rows), group=self.group)
+        return recv
+
+    def _sizes(self, mine):
+        """mine: [world] int64 device tensor -> (mine as a list, the peers' as a list): one read-back"""
+        if self.gloo:
+            theirs = torch.empty(self.world, dtype=torch.int64)
+            m_host = mine.cpu()
+            dist.all_to_all_single(theirs, m_host, group=self.group)
+            return m_host.tolist(), theirs.tolist()
+        theirs = torch.empty_like(mine)
+        dist.all_to_all_single(theirs, mine.contiguous(), group=self.group)
+        both = torch.stack([mine, theirs]).tolist()
+        return both[0], both[1]
+
+    def sample(self, seeds, seed, first_call_id, first_call_ids=None):
+        """seeds: [n_batches, n_seeds] int64 on the shard's device; batch j draws with call id first_call_id + j.
+        first_call_ids: every rank's first call id (list), if the caller knows them; else they are all-gathered."""
+        C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
+        world, nb, B, H = self.world, self.nb, self.B, len(self.fanout)
+        assert tuple(seeds.shape) == (nb, B) and seeds.device == self.dev
+        stream = _cabi.stream_ptr(self.dev)
+        so = self.out.struct()
+        seeds = seeds.contiguous()
+        if world > 1 and first_call_ids is None:
+            mine = torch.tensor([first_call_id], dtype=torch.int64, device="cpu" if self.gloo else self.dev)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=self.group)
+            first_call_ids = [int(x) for x in torch.cat(parts).tolist()]
+        call0 = (C.c_uint64 * 64)(*([first_call_id] if world == 1 else first_call_ids))
+        _cabi.check(lib.tg_part_begin(ptr(seeds), C.c_int64(nb), C.c_int64(B), C.c_int32(H), C.byref(so),
+                                      C.c_int64(self.request_cap), C.c_int32(world), ptr(self.ws), stream))
+        graph = self.shard.graph_view()
+        shard = self.shard
+        for h, k in enumerate(self.fanout):
+            cap = self.hop_cap[h]
+            _cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(self.request_cap),
+                                             C.c_int64(shard.shard_size), C.c_int32(world), ptr(self.ws),
+                                             ptr(self.requests), ptr(self.send_counts), stream))
+            if world == 1:      # nothing travels and nothing is read back: sizes stay on the device
+                got, m_cap, m_dev = self.requests, cap, self.send_counts[1:]
+                seg = (C.c_int64 * 65)(0, cap)
+            else:
+                send, recv = self._sizes(self.send_counts[:world])
+                got = self._a2a(self.requests[:int(sum(send))], send, recv, "req_recv")
+                m_cap = int(sum(recv))
+                m_dev = self._buf("m_dev", 1, torch.int64)
+                m_dev.fill_(m_cap)
+                off_l, acc = [], 0
+                for r in recv:
+                    off_l.append(acc)
+                    acc += r
+                seg = (C.c_int64 * 65)(*(off_l + [acc]))
+            cnt = self._buf("cnt", m_cap, torch.int32)
+            off = self._buf("off", m_cap + 1, torch.int64)
+            reply = self._buf("reply", m_cap * k, torch.int64, 2)
+            tmp_bytes = C.c_int64(0)
+            _cabi.check(lib.tg_part_scan_workspace_bytes(C.c_int64(m_cap), C.byref(tmp_bytes)))
+            tmp = self._buf("scan_tmp", tmp_bytes.value // 8 + 1, torch.int64)
+            _cabi.check(lib.tg_part_count(C.byref(graph), C.c_int64(shard.v_lo), ptr(got), ptr(m_dev), C.c_int64(m_cap),
+                                          C.c_int32(world), seg, call0, C.c_int32(k), C.c_int32(self.sampler), ptr(cnt),
+                                          ptr(off), ptr(self.reply_counts), ptr(tmp), C.c_int64(tmp.numel() * 8), stream))
+            _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
+                                           ptr(m_dev), C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
+                                           C.c_int32(self.sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(reply),
+                                           stream))
+            if world == 1:
+                cnt_back, reply_back = cnt, reply
+            else:
+                rc_send, rc_recv = self._sizes(self.reply_counts[:world])
+                cnt_back = self._buf("cnt_back", self.request_cap, torch.int32)
+                n_back = int(sum(send))
+                cnt_back[:n_back] = self._a2a(cnt[:m_cap], recv, send, "cnt_recv")
+                reply_back = self._a2a(reply[:int(sum(rc_send))], rc_send, rc_recv, "reply_recv")
+                if reply_back.numel() == 0:
+                    reply_back = self._buf("reply_recv", 1, torch.int64, 2)
+            _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(self.request_cap),
+                                         C.c_int64(cap), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
+                                         ptr(self.ws), ptr(cnt_back), ptr(off) if world == 1 else None, ptr(reply_back), stream))
+        return self.out
+
+
+def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None):
+    """One call of the device form (a throw-away PartitionedSampler; keep one around to reuse its buffers)."""
+    ps = PartitionedSampler(shard, seeds.shape[0], seeds.shape[1], fanout, sampler=sampler, group=group)
+    return ps.sample(seeds, seed, first_call_id)
 
 
 def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
@@ -194,7 +292,7 @@ def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPL
             send_counts = torch.bincount(owner, minlength=world).tolist()
             req = torch.stack([f_vertex[perm], first_call_id + f_batch[perm], f_slot[perm]], dim=1)
             # ---- 2. sizes, then requests
-            recv_counts = _exchange_counts(send_counts, group)
+            recv_counts = _exchange_counts(send_counts, group, dev)
             got = _all_to_all_rows(req, send_counts, recv_counts, group)
             r_vertex, r_call, r_slot = got[:, 0], got[:, 1], got[:, 2]
         else:
@@ -207,7 +305,7 @@ def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPL
             cnt_sorted = _all_to_all_rows(cnt_r, recv_counts, send_counts, group)
             peer_of_req = torch.repeat_interleave(torch.arange(world, **i64), torch.as_tensor(recv_counts, **i64))
             rep_send = torch.zeros(world, **i64).index_add_(0, peer_of_req, cnt_r).tolist()
-            rep_recv = _exchange_counts(rep_send, group)
+            rep_recv = _exchange_counts(rep_send, group, dev)
             data_sorted = _all_to_all_rows(torch.stack([nbr_r, ep_r], dim=1), rep_send, rep_recv, group)
             # ---- 5. back to frontier (slot) order
             cnt_f = torch.empty_like(cnt_sorted)

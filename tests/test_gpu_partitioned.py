@@ -74,6 +74,23 @@ def test_device_form_other_fanouts_and_empty_columns(fan):
             assert (x == y) if isinstance(x, list) else torch.equal(x, y)
 
 
+def test_sampler_object_reuses_its_buffers():
+    """two calls through one PartitionedSampler (buffers allocated once) equal two replicated launches"""
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n = _graph(dev)
+    shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
+    ps = partitioned.PartitionedSampler(shard, 5, B, FANOUT)
+    for first in (40, 900):
+        seeds = _cabi.seed_batches(9, first, 5, B, n, dev)
+        out = ps.sample(seeds, SEED, first)
+        torch.cuda.synchronize()
+        ref = _replicated(ptrs, idx, seeds, first, 0)
+        for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
+            s, r, c, e, lo = out.batch(b)
+            assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -144,3 +161,29 @@ def test_device_kernels_with_an_emulated_world(world):
     for b in range(nb):
         for x, y in zip(out.batch(b), ref.batch(b)):
             assert (x == y) if isinstance(x, list) else torch.equal(x, y)
+
+
+def test_rccl_backend_gets_device_tensors_only(monkeypatch):
+    """every tensor the device form hands to all_to_all_single under a non-gloo backend lives on the GPU (the
+    collective is mocked as a loop-back: this rank's own buffers come back)"""
+    from tch_geometric import _cabi, partitioned
+    seen = []
+
+    def fake_a2a(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        seen.append((out.device.type, inp.device.type))
+        out.copy_(inp)
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "all_to_all_single", fake_a2a)
+    dev = torch.device("cuda:0")
+    assert partitioned._exchange_counts([3, 4], None, dev) == [3, 4]
+    ptrs, idx, n = _graph(dev)
+    shard = partitioned.CscShard.from_full(ptrs, idx, 0, 2)
+    ps = partitioned.PartitionedSampler(shard, 3, B, [4, 3])
+    seeds = _cabi.seed_batches(9, 0, 3, B, n, dev) % shard.v_hi          # keep every seed inside this rank's shard
+    ps.sample(seeds, SEED, 0, first_call_ids=[0, 0])
+    torch.cuda.synchronize()
+    assert len(seen) >= 1 + 2 * 5 and all(a == "cuda" and b == "cuda" for a, b in seen)

@@ -104,3 +104,28 @@ def test_shards_tile_the_graph():
         for s in shards:
             assert int(s.ptrs[0]) == 0 and int(s.ptrs[-1]) == s.indices.numel()
             assert torch.equal(s.indices, I[s.e_lo:s.e_lo + s.indices.numel()])
+
+
+def test_size_exchange_never_hands_cpu_tensors_to_rccl(monkeypatch):
+    """ProcessGroupNCCL rejects CPU tensors: with a non-gloo backend the split sizes must travel on the compute
+    device (and the call must say so when it has none) -- checked here with the collective mocked."""
+    import torch.distributed as dist
+    from tch_geometric import partitioned
+    seen = []
+
+    def fake_a2a(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        seen.append((out.device.type, inp.device.type))
+        out.copy_(inp)
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
+    monkeypatch.setattr(dist, "all_to_all_single", fake_a2a)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    with pytest.raises(ValueError, match="needs the compute device"):
+        partitioned._exchange_counts([3, 4], None)
+    with pytest.raises(ValueError, match="needs the compute device"):
+        partitioned._exchange_counts([3, 4], None, torch.device("cpu"))
+    assert not seen
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "gloo")
+    assert partitioned._exchange_counts([3, 4], None) == [3, 4] and seen == [("cpu", "cpu")]
