@@ -9,8 +9,10 @@
 //                exponents (<= 103, beyond that exp() is 0 in f32) in LDS, the denominator is summed from the
 //                histogram in a fixed order, pass 3 selects;
 //   linear       the weights are the descending-time argsort PERMUTATION (random_walk.rs:171, not the ranks): pass 1
-//                writes (time, position) keys, the wavefront sorts them bitonically -- in LDS up to 1024 candidates,
-//                in a global slab beyond -- pass 2 selects.
+//                writes (time, position) keys, the wavefront sorts them -- bitonically in LDS up to 1024 candidates;
+//                beyond, a stable LSD radix sort (8 bits per pass, only over the key bytes that differ inside the
+//                row) between two global slabs, O(n) per pass where the bitonic network was O(n log^2 n) -- pass 2
+//                selects.
 //
 // The reservoir's running f32 sum is the reference's own left-to-right sum (sampling.rs:48) and is kept exactly: 64
 // weights at a time go through LDS and one lane runs the dependent add chain.  Draws are addressed per candidate, so
@@ -27,7 +29,7 @@ namespace tg {
 constexpr uint32_t TAG_RW_BIASED = 11u;
 constexpr int BW_WAVES = 4;
 constexpr int BW_SORT_LDS = 1024; // keys per wavefront sorted in LDS
-constexpr int BW_HIST = 128;      // >= TG_EXP_NEG_BITS_N
+constexpr int BW_HIST = 256;      // >= TG_EXP_NEG_BITS_N; also the radix sort's digit counters
 constexpr int BW_P = 4;           // 64-edge chunks per load round of the row streamer (two rounds in flight)
 
 struct BwWaveLds {
@@ -65,6 +67,59 @@ __device__ void wave_bitonic_sort(uint64_t *buf, uint32_t n_pad, bool global) {
             wave_mem_handoff(global);
         }
     }
+}
+
+// Stable LSD radix sort of n u64 keys by their HIGH words (ascending), one wavefront, between two global buffers; only
+// the bytes of the high word that differ somewhere in the row (`vary`) get a pass.  Entries start in candidate order, so
+// equal times stay in candidate order: the argsort's tie rule.  Returns the buffer that holds the result.
+__device__ uint64_t *wave_radix_sort(uint64_t *src, uint64_t *dst, uint32_t n, uint32_t vary, uint32_t *hist) {
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int byte = 0; byte < 4; ++byte) {
+        if (((vary >> (8 * byte)) & 0xffu) == 0u) continue;
+        const int shift = 32 + 8 * byte;
+        for (int i = lane; i < 256; i += 64) hist[i] = 0u;
+        wave_lds_handoff();
+        for (uint32_t c = lane; c < n; c += 64) atomicAdd(&hist[(uint32_t)(src[c] >> shift) & 0xffu], 1u);
+        wave_lds_handoff();
+        { // exclusive prefix of the 256 counters: four per lane
+            const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const uint32_t s = h0 + h1 + h2 + h3;
+            const uint32_t base = wave_inclusive_scan(s) - s;
+            wave_lds_handoff();
+            hist[4 * lane] = base;
+            hist[4 * lane + 1] = base + h0;
+            hist[4 * lane + 2] = base + h0 + h1;
+            hist[4 * lane + 3] = base + h0 + h1 + h2;
+        }
+        wave_lds_handoff();
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) { // stable scatter, 64 keys at a time in order
+            const uint32_t c = c0 + (uint32_t)lane;
+            const bool valid = c < n;
+            const uint64_t key = valid ? src[c] : 0ull;
+            const uint32_t d = (uint32_t)(key >> shift) & 0xffu;
+            uint64_t same = __ballot(valid); // lanes holding this lane's digit
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const uint64_t bm = __ballot(valid && ((d >> bit) & 1u));
+                same &= ((d >> bit) & 1u) ? bm : ~bm;
+            }
+            const uint32_t rank = (uint32_t)__popcll(same & lt_mask);
+            uint32_t pos = 0;
+            if (valid) pos = hist[d] + rank;
+            wave_lds_handoff();
+            if (valid) {
+                dst[pos] = key;
+                if (rank == 0) hist[d] += (uint32_t)__popcll(same);
+            }
+            wave_lds_handoff();
+        }
+        wave_mem_handoff(true);
+        uint64_t *t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
 }
 
 // left-to-right inclusive f32 prefix over the 64 lanes starting from `carry` (see wave_serial_prefix_f64)
@@ -115,7 +170,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
     const int64_t gwave = (int64_t)blockIdx.x * BW_WAVES + wave, n_gwaves = (int64_t)gridDim.x * BW_WAVES;
     const CallKey ck = call_key(seed, call_id, TAG_RW_BIASED);
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint64_t *slab_keys = scratch ? scratch + (size_t)gwave * (size_t)slab : nullptr;
+    uint64_t *slab_keys = scratch ? scratch + (size_t)gwave * 2 * (size_t)slab : nullptr; // two buffers of `slab` keys
 
     for (int64_t i = gwave; i < n; i += n_gwaves) {
         for (int64_t c = lane; c < L; c += 64) { // :199-208 (position c is always written by lane c & 63)
@@ -174,6 +229,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                         break;
                     }
                     float mx = -__builtin_inff();
+                    uint32_t key_or = 0u, key_and = ~0u; // which bits of the time keys differ inside the row
                     stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
                         const Cand cd = classify(valid, ts, cur_ts);
                         const uint64_t mask = __ballot(cd.ok);
@@ -184,9 +240,12 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                                 first_t = ts;
                                 has_first = true;
                             }
-                            if (bias_now == 1) // descending time, ties by ascending position
-                                keys[c] = ((uint64_t)(~((uint32_t)cd.time32 ^ 0x80000000u)) << 32) | (uint64_t)c;
-                            else
+                            if (bias_now == 1) { // descending time, ties by ascending position
+                                const uint32_t hi = ~((uint32_t)cd.time32 ^ 0x80000000u);
+                                keys[c] = ((uint64_t)hi << 32) | (uint64_t)c;
+                                key_or |= hi;
+                                key_and &= hi;
+                            } else
                                 mx = fmaxf(mx, exp_delta(cd.time32, t32, forward));
                         }
                         n_c += (uint32_t)__popcll(mask);
@@ -194,11 +253,21 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                     if (n_c >= 2) {
                         float den;
                         if (bias_now == 1) {
-                            uint32_t n_pad = 2;
-                            while (n_pad < n_c) n_pad <<= 1;
-                            for (uint32_t c = n_c + lane; c < n_pad; c += 64) keys[c] = ~0ull;
-                            wave_mem_handoff(keys_global);
-                            wave_bitonic_sort(keys, n_pad, keys_global);
+                            if (keys_global) {
+#pragma unroll
+                                for (int off = 32; off > 0; off >>= 1) {
+                                    key_or |= __shfl_xor(key_or, off, 64);
+                                    key_and &= __shfl_xor(key_and, off, 64);
+                                }
+                                wave_mem_handoff(true);
+                                keys = wave_radix_sort(keys, keys + slab, n_c, key_or ^ key_and, lds.hist);
+                            } else {
+                                uint32_t n_pad = 2;
+                                while (n_pad < n_c) n_pad <<= 1;
+                                for (uint32_t c = n_c + lane; c < n_pad; c += 64) keys[c] = ~0ull;
+                                wave_mem_handoff(false);
+                                wave_bitonic_sort(keys, n_pad, false);
+                            }
                             den = (float)((int64_t)n_c * ((int64_t)n_c - 1) / 2);
                         } else {
 #pragma unroll
@@ -293,7 +362,7 @@ static inline int64_t pow2_ceil(int64_t x) {
 }
 static inline unsigned bw_grid(int64_t n, bool with_slab) {
     int64_t g = (n + BW_WAVES - 1) / BW_WAVES;
-    const int64_t cap = with_slab ? 512 : 2048;
+    const int64_t cap = with_slab ? 1024 : 2048;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (unsigned)g;
@@ -308,7 +377,7 @@ extern "C" int tg_biased_walk_workspace_bytes(int64_t n, int64_t max_degree, int
                (long long)max_degree);
     *bytes = 0;
     if (tg::bw_needs_slab(bias, max_degree))
-        *bytes = (int64_t)tg::bw_grid(n, true) * tg::BW_WAVES * tg::pow2_ceil(max_degree) * (int64_t)sizeof(uint64_t);
+        *bytes = (int64_t)tg::bw_grid(n, true) * tg::BW_WAVES * 2 * max_degree * (int64_t)sizeof(uint64_t);
     return TG_OK;
 }
 
@@ -335,7 +404,7 @@ extern "C" int tg_biased_tempo_random_walk(const tg_graph *csr, const int64_t *n
     hipLaunchKernelGGL(tg::biased_walk_kernel, dim3(tg::bw_grid(n, slab)), dim3(64 * tg::BW_WAVES), 0, (hipStream_t)stream,
                        csr->ptrs, csr->indices, node_ts, edge_ts, start, start_ts, n, walk_length, bias, forward,
                        retry_count, rng->seed, rng->call_id, walks, walks_ts, slab ? (uint64_t *)workspace : nullptr,
-                       slab ? tg::pow2_ceil(max_degree) : 0, status);
+                       slab ? max_degree : 0, status);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
