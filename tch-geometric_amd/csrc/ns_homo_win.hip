@@ -240,6 +240,9 @@ __global__ void win_emit_kernel(const WinParams p) {
             for (uint32_t q = lane; q < total; q += 64) { // three write-once streams, coalesced (:217)
                 const int l = slane[q];
                 const int64_t e = e_chunk + q;
+                // streaming stores: measured against plain ones (0.67 vs 0.75 ms for hop 2 of 4 096 batches); the
+                // kernel is bound by HBM write bandwidth (without the draws it takes the same time; with one stream
+                // instead of three, half), which differs from box to box by up to 35 %
                 __builtin_nontemporal_store(n_seeds + e, &rows[e]);
                 __builtin_nontemporal_store(i0 + (int64_t)l, &cols[e]);
                 __builtin_nontemporal_store(col0[c * 64 + l] + (int64_t)spos[q], &eidx[e]);
@@ -367,7 +370,10 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter_kernel(const Win
 }
 
 // ---------------------------------------------------------------- K4: window-ordered gather
-constexpr int WIN_EMIT = 4;
+#ifndef TG_WIN_EMIT
+#define TG_WIN_EMIT 5
+#endif
+constexpr int WIN_EMIT = TG_WIN_EMIT;
 
 // per wave: column start [64] i64 | samples base [64] i64 | staged positions [64*k] u32 | lanes u8
 __host__ __device__ inline size_t win_gather_wave_lds_bytes(int kmax) {
