@@ -239,6 +239,25 @@ TG_API int tg_ns_hetero_capacity(const tg_het_problem *problem, int64_t *cap_nod
 TG_API int tg_ns_hetero_batched(const tg_het_problem *problem, int64_t n_batches, const tg_rng *rng, const tg_het_out *out,
                                 void *stream);
 
+/* Device-side bookkeeping for neighbor_sampling_heterogenous (neighbor_sampling.rs:292-352) when its (hop, relation)
+ * steps run as flat hops -- temporal filters, the weighted sampler, sizes beyond the fused launch: list lengths,
+ * frontier slices and edge counts live in `meta` (device, tg_het_meta_words int64 words:
+ * len[T] | fbeg[T] | fend[T] | ne[R] | layer_offsets[R][H][3] | 4 scratch words; the caller initialises len = fend =
+ * number of inputs, fbeg = 0, ne = 0), so a call needs no read-back between steps.  Per hop, per relation in
+ * `edge_types` order: tg_het_step_begin (frontier = list[dst][fbeg, fend) into a buffer of cap_f slots padded with -1,
+ * draw ids = slot in the list, layer_offsets[rel][hop]) -> tg_ns_hop / tg_ns_hop_scan / tg_ns_hop_weighted with m =
+ * cap_f -> tg_het_step_end (append samples / states to list[src], (row, col, edge pointer) to the relation's lists,
+ * advance the lengths; status |= 4 if a capacity were exceeded); after the relations tg_het_hop_end. */
+TG_API int tg_het_meta_words(int32_t n_types, int32_t n_rels, int32_t n_hops, int64_t *words);
+TG_API int tg_het_step_begin(const int64_t *list_dst, const int64_t *state_dst, int64_t *meta, int32_t n_types, int32_t n_rels,
+                             int32_t n_hops, int32_t src, int32_t dst, int32_t rel, int32_t hop, int64_t cap_f,
+                             int64_t *frontier, int64_t *fstate, int64_t *ids, void *stream);
+TG_API int tg_het_step_end(const tg_hop_out *out, const int64_t *states_out, int64_t cap_f, int32_t fanout, int64_t *meta,
+                           int32_t n_types, int32_t n_rels, int32_t n_hops, int32_t src, int32_t rel, int64_t *list_src,
+                           int64_t *state_src, int64_t cap_list, int64_t *rows, int64_t *cols, int64_t *edge_index,
+                           int64_t cap_edges, int32_t *status, void *stream);
+TG_API int tg_het_hop_end(int64_t *meta, int32_t n_types, int32_t n_rels, int32_t n_hops, void *stream);
+
 /* neighbor_sampling_homogenous over a RANGE-PARTITIONED CSC (graphs beyond one GPU's HBM; host protocol in
  * tch_geometric/partitioned.py; SURVEY.md 8(e) mode 2).  The origin rank keeps ordinary
  * tg_ns_out slabs; per hop: tg_part_requests (origin) -> all-to-all -> tg_part_count + tg_part_sample (owner) ->

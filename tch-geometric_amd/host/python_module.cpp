@@ -498,6 +498,194 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         return py::make_tuple(samples, rows, cols, eidx, los);
     }
 
+    // ---- every other case: flat (hop, relation) steps.  Device-driven when the worst-case buffers are affordable: list
+    // lengths, frontier slices and edge counts stay on the device (csrc/het_steps.hip), the whole call issues its
+    // launches without a read-back in between and reads one small array at the end.
+    if (T <= 64 && num_hops >= 1 && num_hops <= TG_MAX_HOPS && dev.is_cuda()) {
+        const int R = (int)rels.size(), H = (int)num_hops;
+        std::vector<int64_t> cap_list(T), fsz(T), cap_e((size_t)std::max(R, 1), 0);
+        std::vector<std::vector<int64_t>> cap_f((size_t)H, std::vector<int64_t>((size_t)std::max(R, 1), 0));
+        for (size_t t = 0; t < T; ++t) cap_list[t] = fsz[t] = frontier[t].numel();
+        int64_t max_f = 1, max_out = 1, max_k = 1;
+        double words = 0;
+        bool affordable = true;
+        for (int h = 0; h < H && affordable; ++h) {
+            std::vector<int64_t> fresh(T, 0);
+            for (int r = 0; r < R; ++r) {
+                const Rel &rl = rels[(size_t)r];
+                if (!rl.active) continue;
+                const int64_t fr = fsz[rl.dst], k = rl.fanout[(size_t)h];
+                if (fr > 0 && k > ((int64_t)1 << 40) / fr) {
+                    affordable = false;
+                    break;
+                }
+                cap_f[(size_t)h][(size_t)r] = fr;
+                cap_e[(size_t)r] += fr * k;
+                fresh[rl.src] += fr * k;
+                max_f = std::max(max_f, fr);
+                max_out = std::max(max_out, fr * k);
+                max_k = std::max(max_k, k);
+            }
+            for (size_t t = 0; t < T; ++t) {
+                fsz[t] = fresh[t];
+                cap_list[t] += fresh[t];
+            }
+        }
+        for (size_t t = 0; t < T; ++t) words += (double)cap_list[t] * (has_state ? 2 : 1);
+        for (int r = 0; r < R; ++r) words += (double)cap_e[(size_t)r] * 3;
+        words += (double)max_f * 5 + (double)max_out * 4;
+        const bool weighted = s.kind == TG_SAMPLER_WEIGHTED;
+        if ((weighted || has_state) && max_k > 1024)
+            throw py::value_error("num_neighbors above 1024 is not supported with a temporal filter or weights");
+        if (affordable && words * 8 <= 8e9 && (weighted || has_state || max_k <= 4096)) {
+            int64_t meta_words = 0;
+            check_rc(tg_het_meta_words((int32_t)T, R, H, &meta_words));
+            Tensor meta_init = at::zeros({meta_words}, at::TensorOptions().dtype(at::kLong));
+            int64_t *mi = meta_init.data_ptr<int64_t>();
+            for (size_t t = 0; t < T; ++t) {
+                mi[t] = frontier[t].numel();          // len
+                mi[2 * T + t] = frontier[t].numel();  // fend (fbeg = 0)
+            }
+            std::vector<Tensor> lists(T), st_lists(T), RW((size_t)R), CL((size_t)R), EI((size_t)R);
+            for (size_t t = 0; t < T; ++t) {
+                lists[t] = at::empty({std::max<int64_t>(cap_list[t], 1)}, i64(dev));
+                if (frontier[t].numel()) lists[t].narrow(0, 0, frontier[t].numel()).copy_(frontier[t]);
+                if (has_state) {
+                    st_lists[t] = at::empty({std::max<int64_t>(cap_list[t], 1)}, i64(dev));
+                    if (frontier_st[t].numel()) st_lists[t].narrow(0, 0, frontier_st[t].numel()).copy_(frontier_st[t]);
+                }
+            }
+            for (int r = 0; r < R; ++r) {
+                const int64_t c = std::max<int64_t>(cap_e[(size_t)r], 1);
+                RW[(size_t)r] = at::empty({c}, i64(dev));
+                CL[(size_t)r] = at::empty({c}, i64(dev));
+                EI[(size_t)r] = at::empty({c}, i64(dev));
+            }
+            Tensor F = at::empty({max_f}, i64(dev)), ids = at::empty({max_f}, i64(dev)), fst = at::empty({max_f}, i64(dev));
+            Tensor cnt = at::empty({max_f}, i64(dev)), offsets = at::empty({max_f + 1}, i64(dev));
+            Tensor nbr = at::empty({max_out}, i64(dev)), ep = at::empty({max_out}, i64(dev)), par = at::empty({max_out}, i64(dev));
+            Tensor st_out = at::empty({max_out}, i64(dev));
+            Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+            Tensor meta, mh, ws;
+            int32_t status_h = 0;
+            for (int64_t group_mult = 1;; group_mult *= 8) { // a retry only when a column-group guess was too low
+                int64_t ws_max = 0; // one workspace for every step of the call
+                for (int h = 0; h < H; ++h)
+                    for (int r = 0; r < R; ++r) {
+                        const Rel &rl = rels[(size_t)r];
+                        const int64_t cf = cap_f[(size_t)h][(size_t)r];
+                        if (!rl.active || cf == 0) continue;
+                        int64_t b = 0;
+                        if (!weighted && !has_state)
+                            check_rc(tg_ns_hop_workspace_bytes(cf, &b));
+                        else
+                            check_rc(tg_ns_hop_scan_workspace_bytes(
+                                cf, (int32_t)rl.fanout[(size_t)h],
+                                weighted ? 1 : group_mult * std::max<int64_t>(1024, rl.idx.numel() / 512 + 2 * cf + 2), &b));
+                        ws_max = std::max(ws_max, b);
+                    }
+                ws = at::empty({ws_max / 8 + 1}, i64(dev));
+                meta = meta_init.to(dev);
+                status.zero_();
+                for (int h = 0; h < H; ++h) {
+                    for (int r = 0; r < R; ++r) {
+                        Rel &rl = rels[(size_t)r];
+                        const int64_t cf = cap_f[(size_t)h][(size_t)r];
+                        if (!rl.active) continue;
+                        if (cf == 0) { // nothing can be in the frontier; the layer offset is still recorded (:314)
+                            check_rc(tg_het_step_begin(lists[rl.dst].data_ptr<int64_t>(),
+                                                       has_state ? st_lists[rl.dst].data_ptr<int64_t>() : nullptr,
+                                                       meta.data_ptr<int64_t>(), (int32_t)T, R, H, (int32_t)rl.src,
+                                                       (int32_t)rl.dst, r, h, 1, F.data_ptr<int64_t>(),
+                                                       has_state ? fst.data_ptr<int64_t>() : nullptr, ids.data_ptr<int64_t>(),
+                                                       stream_of(dev)));
+                            continue;
+                        }
+                        const int64_t k = rl.fanout[(size_t)h];
+                        check_rc(tg_het_step_begin(lists[rl.dst].data_ptr<int64_t>(),
+                                                   has_state ? st_lists[rl.dst].data_ptr<int64_t>() : nullptr,
+                                                   meta.data_ptr<int64_t>(), (int32_t)T, R, H, (int32_t)rl.src, (int32_t)rl.dst, r,
+                                                   h, cf, F.data_ptr<int64_t>(), has_state ? fst.data_ptr<int64_t>() : nullptr,
+                                                   ids.data_ptr<int64_t>(), stream_of(dev)));
+                        tg_graph g{};
+                        g.ptrs = rl.ptrs.data_ptr<int64_t>();
+                        g.indices = rl.idx.numel() ? rl.idx.data_ptr<int64_t>() : nullptr;
+                        g.timestamps = has_state ? rl.ts.data_ptr<int64_t>() : nullptr;
+                        g.weights = weighted ? rl.w.data_ptr<double>() : nullptr;
+                        g.n_major = rl.ptrs.numel() - 1;
+                        g.n_edges = rl.idx.numel();
+                        tg_hop_in in{};
+                        in.vertices = F.data_ptr<int64_t>();
+                        in.ids = ids.data_ptr<int64_t>();
+                        in.m = cf;
+                        in.fanout = (int32_t)k;
+                        in.sampler = s.kind;
+                        in.rng_tag = TG_TAG_NS_HETERO | ((uint32_t)r << 8);
+                        tg_hop_filter flt{};
+                        flt.filter_mode = f.mode;
+                        flt.forward = f.forward ? 1 : 0;
+                        flt.win_lo = f.win_lo;
+                        flt.win_hi = f.win_hi;
+                        flt.states = has_state ? fst.data_ptr<int64_t>() : nullptr;
+                        tg_hop_out out{cnt.data_ptr<int64_t>(), offsets.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(),
+                                       ep.data_ptr<int64_t>(), par.data_ptr<int64_t>()};
+                        int64_t ws_bytes = 0;
+                        if (!weighted && !has_state) {
+                            check_rc(tg_ns_hop_workspace_bytes(cf, &ws_bytes));
+                            check_rc(tg_ns_hop(&g, &in, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
+                        } else if (weighted) {
+                            check_rc(tg_ns_hop_scan_workspace_bytes(cf, (int32_t)k, 1, &ws_bytes));
+                            check_rc(tg_ns_hop_weighted(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
+                                                        status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes,
+                                                        stream_of(dev)));
+                        } else {
+                            const int64_t group_cap = group_mult * std::max<int64_t>(1024, rl.idx.numel() / 512 + 2 * cf + 2);
+                            check_rc(tg_ns_hop_scan_workspace_bytes(cf, (int32_t)k, group_cap, &ws_bytes));
+                            check_rc(tg_ns_hop_scan(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
+                                                    status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes, group_cap,
+                                                    stream_of(dev)));
+                        }
+                        check_rc(tg_het_step_end(&out, has_state ? st_out.data_ptr<int64_t>() : nullptr, cf, (int32_t)k,
+                                                 meta.data_ptr<int64_t>(), (int32_t)T, R, H, (int32_t)rl.src, r,
+                                                 lists[rl.src].data_ptr<int64_t>(),
+                                                 has_state ? st_lists[rl.src].data_ptr<int64_t>() : nullptr, lists[rl.src].numel(),
+                                                 RW[(size_t)r].data_ptr<int64_t>(), CL[(size_t)r].data_ptr<int64_t>(),
+                                                 EI[(size_t)r].data_ptr<int64_t>(), RW[(size_t)r].numel(),
+                                                 status.data_ptr<int32_t>(), stream_of(dev)));
+                    }
+                    check_rc(tg_het_hop_end(meta.data_ptr<int64_t>(), (int32_t)T, R, H, stream_of(dev)));
+                }
+                // the call's only synchronisation: lengths, layer offsets and the status word in one array
+                Tensor both = at::cat({meta, status.to(at::kLong)});
+                mh = to_host(both);
+                status_h = (int32_t)mh.data_ptr<int64_t>()[meta_words];
+                if ((status_h & 1) && group_mult < 4096) continue;
+                break;
+            }
+            if (status_h & 1) throw std::runtime_error("neighbor_sampling_heterogenous: column-group workspace overflow");
+            if (status_h & 2) // sampling.rs:49: gen_range over an empty float range panics in the reference
+                throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+            if (status_h & 4) throw std::runtime_error("neighbor_sampling_heterogenous: internal capacity error");
+            const int64_t *m = mh.data_ptr<int64_t>();
+            py::dict samples, rows, cols, eidx, los;
+            for (size_t t = 0; t < T; ++t) samples[py::str(node_types[t])] = back(lists[t].narrow(0, 0, m[t]), out_dev);
+            for (int r = 0; r < R; ++r) {
+                const Rel &rl = rels[(size_t)r];
+                const int64_t ne = m[3 * T + (size_t)r];
+                rows[py::str(rl.key)] = back(RW[(size_t)r].narrow(0, 0, ne), out_dev);
+                cols[py::str(rl.key)] = back(CL[(size_t)r].narrow(0, 0, ne), out_dev);
+                eidx[py::str(rl.key)] = back(EI[(size_t)r].narrow(0, 0, ne), out_dev);
+                std::vector<std::tuple<int64_t, int64_t, int64_t>> lo;
+                for (int h = 0; h < H && rl.active; ++h) {
+                    const int64_t *q = m + 3 * T + R + ((size_t)r * H + (size_t)h) * 3;
+                    lo.emplace_back(q[0], q[1], q[2]);
+                }
+                los[py::str(rl.key)] = lo;
+            }
+            return py::make_tuple(samples, rows, cols, eidx, los);
+        }
+    }
+
     for (int64_t ell = 0; ell < num_hops; ++ell) { // :292
         for (size_t t = 0; t < T; ++t) {
             new_chunks[t].clear();

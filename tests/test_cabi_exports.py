@@ -78,7 +78,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.tg_biased_walk_workspace_bytes(C.c_int64(10), C.c_int64(100), C.c_int32(1), C.byref(nbytes)) == 0
     assert nbytes.value == 0                               # rows of <= 1024 edges sort in LDS
     assert lib.tg_biased_walk_workspace_bytes(C.c_int64(10), C.c_int64(5000), C.c_int32(1), C.byref(nbytes)) == 0
-    assert nbytes.value == 3 * 4 * 8192 * 8                # 3 workgroups x 4 wavefronts x 2^13 keys
+    assert nbytes.value == 3 * 4 * 2 * 5000 * 8            # 3 workgroups x 4 wavefronts x two radix buffers of 5000 keys
     assert lib.tg_biased_walk_workspace_bytes(C.c_int64(10), C.c_int64(5000), C.c_int32(2), C.byref(nbytes)) == 0
     assert nbytes.value == 0
     assert lib.tg_biased_tempo_random_walk(None, None, None, None, None, C.c_int64(1), C.c_int64(2), C.c_int32(7),

@@ -70,6 +70,21 @@ def filtered():
 dt, out = timeit(filtered)
 res["neighbor_sampling_homogenous_temporal_single_call"] = {"ms_per_call": dt * 1e3,
                                                             "sampled_edges_per_call": int(out[1].numel())}
+# ---- heterogeneous sampling under a temporal filter / with weights: flat (hop, relation) steps, device-driven
+hts = {k: torch.randint(0, 100, (I[k].numel(),), device=dev, generator=g) for k in P}
+hw = {k: torch.rand(I[k].numel(), device=dev, generator=g, dtype=torch.float64) + 0.1 for k in P}
+def het_filtered():
+    sd = seeds()
+    flt_h = (tg.TemporalEdgeFilter((0, 49), hts, False, tg.TEMPORAL_SAMPLE_STATIC), {"A": torch.full_like(sd, 50)})
+    return tg.neighbor_sampling_heterogenous(node_types, edge_types, P, I, {"A": sd}, nn, 2, None, flt_h)
+dt, out = timeit(het_filtered)
+res["neighbor_sampling_heterogenous_temporal"] = {"ms_per_call": dt * 1e3,
+                                                  "sampled_edges_per_call": sum(int(v.numel()) for v in out[1].values())}
+def het_weighted():
+    return tg.neighbor_sampling_heterogenous(node_types, edge_types, P, I, {"A": seeds()}, nn, 2, tg.WeightedEdgeSampler(hw))
+dt, out = timeit(het_weighted)
+res["neighbor_sampling_heterogenous_weighted"] = {"ms_per_call": dt * 1e3,
+                                                  "sampled_edges_per_call": sum(int(v.numel()) for v in out[1].values())}
 # ---- the batched C ABI (tg_ns_hetero_batched): many seed batches of type A in one launch, all hops and relations fused
 tix = {t: i for i, t in enumerate(node_types)}
 rels_c = [(tix[s_], tix[d_], P["%s__%s__%s" % (s_, n_, d_)], I["%s__%s__%s" % (s_, n_, d_)], [15, 10]) for (s_, n_, d_) in edge_types]
