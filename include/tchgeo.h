@@ -282,10 +282,10 @@ TG_API int tg_het_hop_end(int64_t *meta, int32_t n_types, int32_t n_rels, int32_
  *    counts. */
 TG_API int tg_part_workspace_bytes(int64_t n_batches, int64_t request_cap, int32_t world, int64_t *bytes);
 TG_API int tg_part_scan_workspace_bytes(int64_t n, int64_t *bytes);
-TG_API int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, int32_t n_hops, const tg_ns_out *out,
-                         int64_t request_cap, int32_t world, void *workspace, void *stream);
+TG_API int tg_part_begin(const int64_t *seeds, const int64_t *seeds_state, int64_t n_batches, int64_t n_seeds, int32_t n_hops,
+                         const tg_ns_out *out, int64_t request_cap, int32_t world, void *workspace, void *stream);
 TG_API int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t request_cap, int64_t shard_size, int32_t world,
-                            void *workspace, void *requests, int64_t *send_counts, void *stream);
+                            void *workspace, void *requests, int64_t *request_states, int64_t *send_counts, void *stream);
 TG_API int tg_part_count(const tg_graph *shard, int64_t v_lo, const void *requests, const int64_t *m_dev, int64_t m_cap,
                          int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout, int32_t sampler,
                          uint32_t *cnt, int64_t *off, int64_t *reply_counts, void *scan_tmp, int64_t scan_tmp_bytes,
@@ -294,9 +294,23 @@ TG_API int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, con
                           int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout,
                           int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off, int64_t *reply,
                           void *stream);
+/* Temporal filters and the weighted sampler (neighbor_sampling.rs:36-77, :131-158) on a partitioned graph: the origin
+ * also sends every frontier vertex's filter state (seeds_state / request_states [<= request_cap], grouped like the
+ * requests; NULL = no filter); the owner unpacks the requests into the flat-hop input arrays (tg_part_unpack: vertices
+ * rebased to the shard, -1 for padding; draw ids = the requesters' slots; call ids = the requesters'), runs
+ * tg_ns_hop_scan / tg_ns_hop_weighted over them (m = m_cap, shard.timestamps / shard.weights = the shard's slices) and
+ * packs the hop's compact outputs into the reply (tg_part_pack: cnt u32, entries of reply_stride words = neighbour,
+ * global edge pointer[, the sample's filter state], reply_counts).  tg_part_emit with reply_stride = 3 also fills the
+ * `states` slab.  Same draws as the replicated sampler, so the same results. */
+TG_API int tg_part_unpack(int64_t v_lo, int64_t n_major, const void *requests, const int64_t *m_dev, int64_t m_cap,
+                          int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int64_t *vertices, int64_t *ids,
+                          int64_t *call_ids, void *stream);
+TG_API int tg_part_pack(const tg_hop_out *hop, const int64_t *states_out, const int64_t *m_dev, int64_t m_cap, int64_t e_lo,
+                        int32_t world, const int64_t *seg_off, uint32_t *cnt, int64_t *reply, int32_t reply_stride,
+                        int64_t *reply_counts, void *stream);
 TG_API int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int64_t hop_cap,
                         int32_t world, int32_t fanout, int32_t hop, int32_t n_hops, void *workspace, const uint32_t *cnt,
-                        const int64_t *cnt_prefix, const int64_t *reply, void *stream);
+                        const int64_t *cnt_prefix, const int64_t *reply, int32_t reply_stride, void *stream);
 
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */

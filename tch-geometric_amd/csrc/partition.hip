@@ -48,7 +48,7 @@ struct PartState {
 
 // workspace (int64 words unless noted); host side: part_layout()
 struct PartLayout {
-    size_t state, n_req, send_counts, hist, base, req_in, req_pos, poff, scan_tmp, total;
+    size_t state, n_req, send_counts, hist, base, req_in, rstate_in, req_pos, poff, scan_tmp, total;
     size_t scan_tmp_bytes;
 };
 
@@ -66,6 +66,7 @@ static PartLayout part_layout(int64_t n_batches, int64_t request_cap, int world)
     L.hist = take((size_t)PART_BLOCKS * PART_MAX_WORLD * sizeof(uint32_t));
     L.base = take((size_t)(PART_MAX_WORLD + 1) * sizeof(int64_t));
     L.req_in = take((size_t)request_cap * sizeof(PartRequest));
+    L.rstate_in = take((size_t)request_cap * sizeof(int64_t));
     L.req_pos = take((size_t)request_cap * sizeof(uint32_t));
     L.poff = take((size_t)(request_cap + 1) * sizeof(int64_t));
     L.scan_tmp_bytes = (size_t)(PSCAN_BLOCKS_HOST + 1) * sizeof(int64_t);
@@ -75,10 +76,14 @@ static PartLayout part_layout(int64_t n_batches, int64_t request_cap, int world)
 }
 
 // ---------------------------------------------------------------- begin: seeds -> slabs, frontier = the seeds
-__global__ void part_init_kernel(const int64_t *__restrict__ seeds, int64_t n_batches, int64_t n_seeds, int64_t *samples,
-                                 int64_t cap_nodes, PartState *state, int64_t *counts, int32_t n_hops) {
+__global__ void part_init_kernel(const int64_t *__restrict__ seeds, const int64_t *__restrict__ seeds_state,
+                                 int64_t n_batches, int64_t n_seeds, int64_t *samples, int64_t *states, int64_t cap_nodes,
+                                 PartState *state, int64_t *counts, int32_t n_hops) {
     const int64_t b = blockIdx.x;
-    for (int64_t i = threadIdx.x; i < n_seeds; i += blockDim.x) samples[b * cap_nodes + i] = seeds[b * n_seeds + i];
+    for (int64_t i = threadIdx.x; i < n_seeds; i += blockDim.x) {
+        samples[b * cap_nodes + i] = seeds[b * n_seeds + i];
+        if (seeds_state) states[b * cap_nodes + i] = seeds_state[b * n_seeds + i];
+    }
     if (threadIdx.x == 0) {
         state[b] = PartState{0, n_seeds, 0, 0};
         if (n_hops == 0) {
@@ -89,8 +94,9 @@ __global__ void part_init_kernel(const int64_t *__restrict__ seeds, int64_t n_ba
 }
 
 // ---------------------------------------------------------------- requests, step 1: frontier order, per batch
-__global__ void part_requests_kernel(const int64_t *__restrict__ samples, int64_t cap_nodes, PartState *state,
-                                     unsigned long long *n_req, PartRequest *req_in) {
+__global__ void part_requests_kernel(const int64_t *__restrict__ samples, const int64_t *__restrict__ states,
+                                     int64_t cap_nodes, PartState *state, unsigned long long *n_req, PartRequest *req_in,
+                                     int64_t *rstate_in) {
     __shared__ int64_t fbase_s;
     const int64_t b = blockIdx.x;
     const PartState st = state[b];
@@ -100,8 +106,10 @@ __global__ void part_requests_kernel(const int64_t *__restrict__ samples, int64_
     }
     __syncthreads();
     const int64_t fbase = fbase_s;
-    for (int64_t i = st.begin + threadIdx.x; i < st.end; i += blockDim.x)
+    for (int64_t i = st.begin + threadIdx.x; i < st.end; i += blockDim.x) {
         req_in[fbase + (i - st.begin)] = PartRequest{samples[b * cap_nodes + i], (uint32_t)b, (uint32_t)i};
+        if (rstate_in) rstate_in[fbase + (i - st.begin)] = states[b * cap_nodes + i]; // the frontier vertex's filter state
+    }
 }
 
 __device__ __forceinline__ int part_owner(int64_t v, int64_t shard_size, int world) {
@@ -154,7 +162,8 @@ __global__ void part_scan_kernel(uint32_t *hist, int n_rows, int world, int64_t 
 __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const PartRequest *__restrict__ req_in,
                                                                      const unsigned long long *n_req, int64_t shard_size,
                                                                      int world, const uint32_t *hist, const int64_t *base,
-                                                                     PartRequest *req_out, uint32_t *req_pos) {
+                                                                     PartRequest *req_out, uint32_t *req_pos,
+                                                                     const int64_t *rstate_in, int64_t *rstate_out) {
     __shared__ uint32_t cur[PART_MAX_WORLD];
     if (threadIdx.x < world)
         cur[threadIdx.x] = (uint32_t)base[threadIdx.x] + hist[(size_t)blockIdx.x * PART_MAX_WORLD + threadIdx.x];
@@ -166,16 +175,19 @@ __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const PartRe
             const uint32_t pos = atomicAdd(&cur[part_owner(r.vertex, shard_size, world)], 1u);
             req_out[pos] = r;
             req_pos[j] = pos;
+            if (rstate_out) rstate_out[pos] = rstate_in[j];
         }
 }
 
 // world == 1: the frontier order IS the request order
 __global__ void part_identity_kernel(const PartRequest *__restrict__ req_in, const unsigned long long *n_req,
-                                     PartRequest *req_out, uint32_t *req_pos, int64_t *send_counts) {
+                                     PartRequest *req_out, uint32_t *req_pos, int64_t *send_counts,
+                                     const int64_t *rstate_in, int64_t *rstate_out) {
     const uint64_t n = *n_req;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         req_out[j] = req_in[j];
         req_pos[j] = (uint32_t)j;
+        if (rstate_out) rstate_out[j] = rstate_in[j];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         send_counts[0] = (int64_t)n;
@@ -302,6 +314,50 @@ template <int KMAX> __global__ void part_sample_kernel(const PartOwnerParams p) 
     }
 }
 
+// ---------------------------------------------------------------- owner side, general form (temporal filters, weights)
+// The flat hops of ns_hop_scan.hip sample a frontier given as arrays (vertex, draw id, call id, state); here the
+// received requests are unpacked into that shape (vertices rebased to the shard, -1 = not mine / padding) and the hop's
+// compact outputs are packed into the reply format.
+__global__ void part_unpack_kernel(const PartOwnerParams p, int64_t m_cap, int64_t *vertices, int64_t *ids,
+                                   int64_t *call_ids) {
+    const int64_t m = *p.m_dev;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m_cap; j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t v = -1, id = 0, call = 0;
+        if (j < m) {
+            const PartRequest r = p.req[j];
+            const int64_t w = r.vertex - p.v_lo;
+            if (w >= 0 && w < p.n_major) v = w;
+            int src = 0;
+            while (src + 1 < p.world && p.seg_off[src + 1] <= j) ++src;
+            id = (int64_t)r.slot;
+            call = (int64_t)(p.seg_call0[src] + (uint64_t)r.batch);
+        }
+        vertices[j] = v;
+        ids[j] = id;
+        call_ids[j] = call;
+    }
+}
+
+// hop outputs (cnt i64 [m_cap], offsets [m_cap + 1], neighbours / local edge pointers / states compact) -> reply
+__global__ void part_pack_kernel(const PartOwnerParams p, int64_t m_cap, const int64_t *hop_cnt, const int64_t *hop_off,
+                                 const int64_t *nbr, const int64_t *ep, const int64_t *st_out, int32_t stride) {
+    const int64_t m = *p.m_dev;
+    const int64_t total = hop_off[m_cap];
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x)
+        p.cnt[j] = (uint32_t)hop_cnt[j];
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        int64_t *o = p.reply + q * stride;
+        o[0] = nbr[q];
+        o[1] = ep[q] + p.e_lo;
+        if (stride == 3) o[2] = st_out[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= p.world) { // reply entries per requesting rank (padding slots count 0)
+        const int t = threadIdx.x;
+        auto at = [&](int64_t j) -> int64_t { return hop_off[j >= m ? m : j]; };
+        p.reply_counts[t] = (t < p.world) ? at(p.seg_off[t + 1]) - at(p.seg_off[t]) : at(m);
+    }
+}
+
 // ---------------------------------------------------------------- origin side: emit
 struct PartEmitParams {
     int64_t n_seeds, cap_nodes, cap_edges;
@@ -309,8 +365,9 @@ struct PartEmitParams {
     PartState *state;
     const uint32_t *req_pos, *cnt; // cnt: per request, request order (as returned)
     const int64_t *poff;           // exclusive prefix of cnt
-    const int64_t *reply;          // pairs, compact, request order
-    int32_t k, hop, n_hops;
+    const int64_t *reply;          // pairs (or triples with the sample's filter state), compact, request order
+    int64_t *states;               // filter-state slab, written when reply_stride == 3
+    int32_t k, hop, n_hops, reply_stride;
 };
 
 __global__ void part_emit_kernel(const PartEmitParams p) {
@@ -379,9 +436,10 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
             for (uint32_t q = lane; q < total; q += 64) {
                 const int l = elane[q];
-                const int64_t *r = p.reply + (rbase[l] + (int64_t)eslot[q]) * 2;
+                const int64_t *r = p.reply + (rbase[l] + (int64_t)eslot[q]) * p.reply_stride;
                 const int64_t e = e_chunk + q;
                 samples[n_seeds + e] = r[0];                                // :215 (the next hop's frontier)
+                if (p.reply_stride == 3) p.states[b * p.cap_nodes + n_seeds + e] = r[2]; // :216 filter.mutate()
                 __builtin_nontemporal_store(n_seeds + e, &rows[e]);        // :217
                 __builtin_nontemporal_store(i0 + (int64_t)l, &cols[e]);
                 __builtin_nontemporal_store(r[1], &eidx[e]);
@@ -485,25 +543,28 @@ extern "C" int tg_part_workspace_bytes(int64_t n_batches, int64_t request_cap, i
     return TG_OK;
 }
 
-extern "C" int tg_part_begin(const int64_t *seeds, int64_t n_batches, int64_t n_seeds, int32_t n_hops, const tg_ns_out *out,
-                             int64_t request_cap, int32_t world, void *workspace, void *stream) {
+extern "C" int tg_part_begin(const int64_t *seeds, const int64_t *seeds_state, int64_t n_batches, int64_t n_seeds,
+                             int32_t n_hops, const tg_ns_out *out, int64_t request_cap, int32_t world, void *workspace,
+                             void *stream) {
     TG_REQUIRE(out && workspace && n_batches >= 0 && n_seeds >= 0 && (seeds || n_seeds == 0) && world >= 1 &&
                    world <= tg::PART_MAX_WORLD && n_hops >= 0 && n_hops <= TG_MAX_HOPS,
                "tg_part_begin: bad arguments");
     TG_REQUIRE(out->samples && out->counts && out->cap_nodes >= n_seeds, "tg_part_begin: samples slab too small");
+    TG_REQUIRE(!seeds_state || out->states, "tg_part_begin: filter states need the `states` slab");
     TG_REQUIRE(((uintptr_t)workspace & 255) == 0, "tg_part_begin: workspace must be 256-byte aligned");
     if (n_batches == 0) return TG_OK;
     const tg::PartLayout L = tg::part_layout(n_batches, request_cap, world);
     unsigned char *w = static_cast<unsigned char *>(workspace);
-    hipLaunchKernelGGL(tg::part_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, (hipStream_t)stream, seeds, n_batches,
-                       n_seeds, out->samples, out->cap_nodes, reinterpret_cast<tg::PartState *>(w + L.state), out->counts,
-                       n_hops);
+    hipLaunchKernelGGL(tg::part_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, (hipStream_t)stream, seeds, seeds_state,
+                       n_batches, n_seeds, out->samples, out->states, out->cap_nodes,
+                       reinterpret_cast<tg::PartState *>(w + L.state), out->counts, n_hops);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
 
 extern "C" int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t request_cap, int64_t shard_size,
-                                int32_t world, void *workspace, void *requests, int64_t *send_counts, void *stream) {
+                                int32_t world, void *workspace, void *requests, int64_t *request_states,
+                                int64_t *send_counts, void *stream) {
     TG_REQUIRE(out && workspace && requests && send_counts && n_batches >= 1 && shard_size >= 1 && world >= 1 &&
                    world <= tg::PART_MAX_WORLD,
                "tg_part_requests: bad arguments");
@@ -517,18 +578,20 @@ extern "C" int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t
     uint32_t *req_pos = reinterpret_cast<uint32_t *>(w + L.req_pos);
     uint32_t *hist = reinterpret_cast<uint32_t *>(w + L.hist);
     int64_t *base = reinterpret_cast<int64_t *>(w + L.base);
+    TG_REQUIRE(!request_states || out->states, "tg_part_requests: request states need the `states` slab");
+    int64_t *rstate_in = request_states ? reinterpret_cast<int64_t *>(w + L.rstate_in) : nullptr;
     TG_HIP(hipMemsetAsync(n_req, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(part_requests_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, out->samples, out->cap_nodes, state,
-                       n_req, req_in);
+    hipLaunchKernelGGL(part_requests_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, out->samples, out->states,
+                       out->cap_nodes, state, n_req, req_in, rstate_in);
     if (world == 1) {
         hipLaunchKernelGGL(part_identity_kernel, dim3(part_grid(request_cap, 256, 4096)), dim3(256), 0, s, req_in, n_req,
-                           static_cast<PartRequest *>(requests), req_pos, send_counts);
+                           static_cast<PartRequest *>(requests), req_pos, send_counts, rstate_in, request_states);
     } else {
         hipLaunchKernelGGL(part_hist_kernel, dim3(PART_BLOCKS), dim3(PART_THREADS), 0, s, req_in, n_req, shard_size,
                            (int)world, hist);
         hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(64), 0, s, hist, PART_BLOCKS, (int)world, base, send_counts);
         hipLaunchKernelGGL(part_scatter_kernel, dim3(PART_BLOCKS), dim3(PART_THREADS), 0, s, req_in, n_req, shard_size,
-                           (int)world, hist, base, static_cast<PartRequest *>(requests), req_pos);
+                           (int)world, hist, base, static_cast<PartRequest *>(requests), req_pos, rstate_in, request_states);
     }
     // a copy of the sizes stays in the workspace for tg_part_emit
     TG_HIP(hipMemcpyAsync(w + L.send_counts, send_counts, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyDeviceToDevice, s));
@@ -538,10 +601,11 @@ extern "C" int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t
 
 static int part_owner_params(tg::PartOwnerParams &p, const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests,
                              const int64_t *m_dev, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
-                             int32_t fanout, int32_t sampler, uint64_t seed) {
+                             int32_t fanout, int32_t sampler, uint64_t seed, bool general = false) {
     TG_REQUIRE(shard && shard->ptrs && (shard->indices || shard->n_edges == 0), "tg_part: null shard");
-    TG_REQUIRE(fanout >= 1 && fanout <= TG_MAX_FANOUT, "tg_part: fanout %d outside [1, %d]", fanout, TG_MAX_FANOUT);
-    TG_REQUIRE(sampler == TG_SAMPLER_UNIFORM || sampler == TG_SAMPLER_UNIFORM_REPL, "tg_part: unweighted samplers only");
+    TG_REQUIRE(fanout >= 1 && (general || fanout <= TG_MAX_FANOUT), "tg_part: fanout %d outside [1, %d]", fanout, TG_MAX_FANOUT);
+    TG_REQUIRE(general || sampler == TG_SAMPLER_UNIFORM || sampler == TG_SAMPLER_UNIFORM_REPL,
+               "tg_part_count / tg_part_sample: unweighted samplers only (filters and weights: tg_part_unpack + a flat hop + tg_part_pack)");
     TG_REQUIRE(world >= 1 && world <= tg::PART_MAX_WORLD && seg_off && seg_call0 && m_dev && requests,
                "tg_part: bad owner arguments");
     p.ptrs = shard->ptrs;
@@ -618,12 +682,60 @@ extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo,
     return TG_OK;
 }
 
+extern "C" int tg_part_unpack(int64_t v_lo, int64_t n_major, const void *requests, const int64_t *m_dev, int64_t m_cap,
+                              int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int64_t *vertices, int64_t *ids,
+                              int64_t *call_ids, void *stream) {
+    TG_REQUIRE(requests && m_dev && seg_off && seg_call0 && vertices && ids && call_ids && m_cap >= 0 && world >= 1 &&
+                   world <= tg::PART_MAX_WORLD,
+               "tg_part_unpack: bad arguments");
+    if (m_cap == 0) return TG_OK;
+    tg::PartOwnerParams p{};
+    p.req = static_cast<const tg::PartRequest *>(requests);
+    p.m_dev = m_dev;
+    p.v_lo = v_lo;
+    p.n_major = n_major;
+    p.world = world;
+    for (int i = 0; i <= world; ++i) p.seg_off[i] = seg_off[i];
+    for (int i = 0; i < world; ++i) p.seg_call0[i] = seg_call0[i];
+    hipLaunchKernelGGL(tg::part_unpack_kernel, dim3(tg::part_grid(m_cap, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, m_cap,
+                       vertices, ids, call_ids);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_part_pack(const tg_hop_out *hop, const int64_t *states_out, const int64_t *m_dev, int64_t m_cap, int64_t e_lo,
+                            int32_t world, const int64_t *seg_off, uint32_t *cnt, int64_t *reply, int32_t reply_stride,
+                            int64_t *reply_counts, void *stream) {
+    TG_REQUIRE(hop && hop->cnt && hop->offsets && hop->neighbors && hop->edge_ptrs && m_dev && seg_off && cnt && reply &&
+                   reply_counts && m_cap >= 0 && world >= 1 && world <= tg::PART_MAX_WORLD,
+               "tg_part_pack: bad arguments");
+    TG_REQUIRE(reply_stride == 2 || (reply_stride == 3 && states_out), "tg_part_pack: reply_stride is 2, or 3 with states");
+    if (m_cap == 0) {
+        TG_HIP(hipMemsetAsync(reply_counts, 0, sizeof(int64_t) * (size_t)(world + 1), (hipStream_t)stream));
+        return TG_OK;
+    }
+    tg::PartOwnerParams p{};
+    p.m_dev = m_dev;
+    p.e_lo = e_lo;
+    p.world = world;
+    for (int i = 0; i <= world; ++i) p.seg_off[i] = seg_off[i];
+    p.cnt = cnt;
+    p.reply = reply;
+    p.reply_counts = reply_counts;
+    hipLaunchKernelGGL(tg::part_pack_kernel, dim3(tg::part_grid(m_cap * 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p,
+                       m_cap, hop->cnt, hop->offsets, hop->neighbors, hop->edge_ptrs, states_out, reply_stride);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
 extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int64_t hop_cap,
                             int32_t world, int32_t fanout, int32_t hop, int32_t n_hops, void *workspace,
-                            const uint32_t *cnt, const int64_t *cnt_prefix, const int64_t *reply, void *stream) {
-    TG_REQUIRE(out && workspace && cnt && n_batches >= 1 && fanout >= 1 && fanout <= TG_MAX_FANOUT && hop >= 0 &&
-                   hop < n_hops && n_hops <= TG_MAX_HOPS,
+                            const uint32_t *cnt, const int64_t *cnt_prefix, const int64_t *reply, int32_t reply_stride,
+                            void *stream) {
+    TG_REQUIRE(out && workspace && cnt && n_batches >= 1 && fanout >= 1 && fanout <= 255 && hop >= 0 && hop < n_hops &&
+                   n_hops <= TG_MAX_HOPS,
                "tg_part_emit: bad arguments");
+    TG_REQUIRE(reply_stride == 2 || (reply_stride == 3 && out->states), "tg_part_emit: reply_stride is 2, or 3 with a `states` slab");
     TG_REQUIRE(out->samples && out->rows && out->cols && out->edge_index && out->layer_offsets && out->counts,
                "tg_part_emit: null output slabs");
     using namespace tg;
@@ -654,6 +766,8 @@ extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_s
     p.cnt = cnt;
     p.poff = poff;
     p.reply = reply;
+    p.states = out->states;
+    p.reply_stride = reply_stride;
     p.k = fanout;
     p.hop = hop;
     p.n_hops = n_hops;

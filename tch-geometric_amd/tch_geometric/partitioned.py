@@ -30,8 +30,9 @@ SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL = _cabi.SAMPLER_UNIFORM, _cabi.SAMPLER_UNI
 class CscShard:
     """Columns [v_lo, v_hi) of a CSC: ptrs rebased to 0, indices = global row ids, e_lo = global edge offset."""
 
-    def __init__(self, ptrs, indices, v_lo, v_hi, e_lo, n_nodes, shard_size):
+    def __init__(self, ptrs, indices, v_lo, v_hi, e_lo, n_nodes, shard_size, weights=None, timestamps=None):
         self.ptrs, self.indices = ptrs, indices
+        self.weights, self.timestamps = weights, timestamps      # this shard's slices of the per-edge attributes
         self.v_lo, self.v_hi, self.e_lo = int(v_lo), int(v_hi), int(e_lo)
         self.n_nodes, self.shard_size = int(n_nodes), int(shard_size)
         self._view = None
@@ -39,7 +40,8 @@ class CscShard:
     def graph_view(self):
         if self._view is None:   # u32 shadow of the neighbour ids: half the bytes per gathered line (ids < 2^32)
             i32 = self.indices.to(torch.int32) if self.n_nodes < 2 ** 32 and self.indices.is_cuda else None
-            self._view = _cabi.graph_view(self.ptrs, self.indices, indices32=i32)
+            self._view = _cabi.graph_view(self.ptrs, self.indices, weights=self.weights, timestamps=self.timestamps,
+                                          indices32=i32)
         return self._view
 
     @staticmethod
@@ -47,13 +49,15 @@ class CscShard:
         return (n_nodes + world - 1) // world
 
     @classmethod
-    def from_full(cls, ptrs, indices, rank, world):
+    def from_full(cls, ptrs, indices, rank, world, weights=None, timestamps=None):
         """Cut rank's shard out of a replicated CSC (tests / benchmarks; a real loader reads only its shard)."""
         n = ptrs.numel() - 1
         size = cls.shard_size_for(n, world)
         lo, hi = min(rank * size, n), min((rank + 1) * size, n)
         e_lo, e_hi = int(ptrs[lo]), int(ptrs[hi])
-        return cls((ptrs[lo:hi + 1] - e_lo).contiguous(), indices[e_lo:e_hi].contiguous(), lo, hi, e_lo, n, size)
+        cut = lambda a: a[e_lo:e_hi].contiguous() if a is not None else None
+        return cls((ptrs[lo:hi + 1] - e_lo).contiguous(), indices[e_lo:e_hi].contiguous(), lo, hi, e_lo, n, size,
+                   weights=cut(weights), timestamps=cut(timestamps))
 
 
 def _world(group):
@@ -133,9 +137,20 @@ class PartitionedSampler:
     reads only the all-to-all split sizes (two small read-backs per hop).  The returned `_cabi.NsBatchedOut` equals
     the replicated-graph sampler's bit for bit."""
 
-    def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None):
+    def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None,
+                 filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0)):
+        """sampler: uniform / with replacement / weighted (shard.weights); filter_mode: a TemporalFilter mode over
+        shard.timestamps (`sample()` then takes the seeds' filter states).  Filters and weights take the general
+        owner path: tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack."""
         import ctypes as C
         self.C, self.shard, self.group, self.sampler = C, shard, group, sampler
+        self.filter_mode, self.forward, self.window = filter_mode, bool(forward), tuple(window)
+        self.filtered = filter_mode != _cabi.FILTER_NONE
+        self.general = self.filtered or sampler == _cabi.SAMPLER_WEIGHTED
+        if sampler == _cabi.SAMPLER_WEIGHTED and shard.weights is None:
+            raise ValueError("the weighted sampler needs shard.weights")
+        if self.filtered and shard.timestamps is None:
+            raise ValueError("a temporal filter needs shard.timestamps")
         self.world, self.rank = _world(group)
         self.nb, self.B, self.fanout = int(n_batches), int(n_seeds), [int(k) for k in fanout]
         self.dev = shard.ptrs.device
@@ -144,13 +159,14 @@ class PartitionedSampler:
             self.hop_cap.append(cap)
             cap *= k
         self.request_cap = max(self.hop_cap + [1])
-        self.out = _cabi.NsBatchedOut(self.nb, self.B, self.fanout, self.dev)
+        self.out = _cabi.NsBatchedOut(self.nb, self.B, self.fanout, self.dev, with_states=self.filtered)
         nbytes = C.c_int64(0)
         _cabi.check(_cabi.lib.tg_part_workspace_bytes(C.c_int64(self.nb), C.c_int64(self.request_cap),
                                                       C.c_int32(self.world), C.byref(nbytes)))
         i64 = dict(dtype=torch.int64, device=self.dev)
         self.ws = torch.empty(nbytes.value // 8 + 1, **i64)
         self.requests = torch.empty((self.request_cap, 2), **i64)            # 16-byte requests
+        self.request_states = torch.empty(self.request_cap, **i64) if self.filtered else None
         self.send_counts = torch.zeros(self.world + 1, **i64)
         self.reply_counts = torch.zeros(self.world + 1, **i64)
         self._bufs = {}
@@ -191,9 +207,60 @@ class PartitionedSampler:
         both = torch.stack([mine, theirs]).tolist()
         return both[0], both[1]
 
-    def sample(self, seeds, seed, first_call_id, first_call_ids=None):
+    def _owner_general(self, got, got_states, m_dev, m_cap, seg, call0, k, seed, stream):
+        """owner side under a filter / with weights: requests -> flat-hop arrays -> tg_ns_hop_scan / _weighted -> reply"""
+        C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
+        shard, graph = self.shard, self.shard.graph_view()
+        i64 = torch.int64
+        vert, ids, calls = (self._buf(n, m_cap, i64) for n in ("g_vert", "g_ids", "g_calls"))
+        _cabi.check(lib.tg_part_unpack(C.c_int64(shard.v_lo), C.c_int64(shard.v_hi - shard.v_lo), ptr(got), ptr(m_dev),
+                                       C.c_int64(m_cap), C.c_int32(self.world), seg, call0, ptr(vert), ptr(ids), ptr(calls),
+                                       stream))
+        hcnt, hoff = self._buf("g_cnt", m_cap, i64), self._buf("g_off", m_cap + 1, i64)
+        nbr, ep, par, st_out = (self._buf(n, m_cap * k, i64) for n in ("g_nbr", "g_ep", "g_par", "g_st"))
+        status = self._buf("g_status", 1, torch.int32)
+        hin, hout, flt = _cabi.TgHopIn(), _cabi.TgHopOut(), _cabi.TgHopFilter()
+        hin.vertices, hin.ids, hin.call_ids = vert.data_ptr(), ids.data_ptr(), calls.data_ptr()
+        hin.m, hin.id_base, hin.fanout, hin.sampler, hin.rng_tag = m_cap, 0, k, self.sampler, 0
+        hout.cnt, hout.offsets = hcnt.data_ptr(), hoff.data_ptr()
+        hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+        flt.filter_mode, flt.forward = self.filter_mode, int(self.forward)
+        flt.win_lo, flt.win_hi = self.window
+        flt.states = got_states.data_ptr() if self.filtered else None
+        rng = _cabi.TgRng(seed, 0)
+        nbytes = C.c_int64(0)
+        mult = 1
+        while True:
+            status.zero_()
+            weighted = self.sampler == _cabi.SAMPLER_WEIGHTED
+            group_cap = 1 if weighted else mult * max(1024, graph.n_edges // 512 + 2 * m_cap + 2)
+            _cabi.check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m_cap), C.c_int32(k), C.c_int64(group_cap),
+                                                           C.byref(nbytes)))
+            ws = self._buf("g_ws", nbytes.value // 8 + 1, i64)
+            if weighted:
+                _cabi.check(lib.tg_ns_hop_weighted(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
+                                                   ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), stream))
+                break
+            _cabi.check(lib.tg_ns_hop_scan(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
+                                           ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), C.c_int64(group_cap),
+                                           stream))
+            if int(status[0]) & 1 and mult < 4096:   # the column-group guess was too low (rare): larger workspace
+                mult *= 8
+                continue
+            break
+        stride = 3 if self.filtered else 2
+        cnt = self._buf("cnt", m_cap, torch.int32)
+        reply = self._buf("reply%d" % stride, m_cap * k, i64, stride)
+        _cabi.check(lib.tg_part_pack(C.byref(hout), ptr(st_out) if self.filtered else None, ptr(m_dev), C.c_int64(m_cap),
+                                     C.c_int64(shard.e_lo), C.c_int32(self.world), seg, ptr(cnt), ptr(reply),
+                                     C.c_int32(stride), ptr(self.reply_counts), stream))
+        self._weighted_status = status
+        return cnt, hoff, reply
+
+    def sample(self, seeds, seed, first_call_id, first_call_ids=None, seeds_state=None):
         """seeds: [n_batches, n_seeds] int64 on the shard's device; batch j draws with call id first_call_id + j.
-        first_call_ids: every rank's first call id (list), if the caller knows them; else they are all-gathered."""
+        first_call_ids: every rank's first call id (list), if the caller knows them; else they are all-gathered.
+        seeds_state: [n_batches, n_seeds] filter states of the seeds (with a temporal filter)."""
         C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
         world, nb, B, H = self.world, self.nb, self.B, len(self.fanout)
         assert tuple(seeds.shape) == (nb, B) and seeds.device == self.dev
@@ -206,21 +273,30 @@ class PartitionedSampler:
             dist.all_gather(parts, mine, group=self.group)
             first_call_ids = [int(x) for x in torch.cat(parts).tolist()]
         call0 = (C.c_uint64 * 64)(*([first_call_id] if world == 1 else first_call_ids))
-        _cabi.check(lib.tg_part_begin(ptr(seeds), C.c_int64(nb), C.c_int64(B), C.c_int32(H), C.byref(so),
-                                      C.c_int64(self.request_cap), C.c_int32(world), ptr(self.ws), stream))
+        if self.filtered:
+            assert seeds_state is not None and tuple(seeds_state.shape) == (nb, B)
+            seeds_state = seeds_state.contiguous()
+        _cabi.check(lib.tg_part_begin(ptr(seeds), ptr(seeds_state) if self.filtered else None, C.c_int64(nb), C.c_int64(B),
+                                      C.c_int32(H), C.byref(so), C.c_int64(self.request_cap), C.c_int32(world),
+                                      ptr(self.ws), stream))
+        stride = 3 if self.filtered else 2
         graph = self.shard.graph_view()
         shard = self.shard
         for h, k in enumerate(self.fanout):
             cap = self.hop_cap[h]
             _cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(self.request_cap),
                                              C.c_int64(shard.shard_size), C.c_int32(world), ptr(self.ws),
-                                             ptr(self.requests), ptr(self.send_counts), stream))
+                                             ptr(self.requests), ptr(self.request_states) if self.filtered else None,
+                                             ptr(self.send_counts), stream))
+            got_states = self.request_states
             if world == 1:      # nothing travels and nothing is read back: sizes stay on the device
                 got, m_cap, m_dev = self.requests, cap, self.send_counts[1:]
                 seg = (C.c_int64 * 65)(0, cap)
             else:
                 send, recv = self._sizes(self.send_counts[:world])
                 got = self._a2a(self.requests[:int(sum(send))], send, recv, "req_recv")
+                if self.filtered:
+                    got_states = self._a2a(self.request_states[:int(sum(send))], send, recv, "st_recv")
                 m_cap = int(sum(recv))
                 m_dev = self._buf("m_dev", 1, torch.int64)
                 m_dev.fill_(m_cap)
@@ -229,19 +305,10 @@ class PartitionedSampler:
                     off_l.append(acc)
                     acc += r
                 seg = (C.c_int64 * 65)(*(off_l + [acc]))
-            cnt = self._buf("cnt", m_cap, torch.int32)
-            off = self._buf("off", m_cap + 1, torch.int64)
-            reply = self._buf("reply", m_cap * k, torch.int64, 2)
-            tmp_bytes = C.c_int64(0)
-            _cabi.check(lib.tg_part_scan_workspace_bytes(C.c_int64(m_cap), C.byref(tmp_bytes)))
-            tmp = self._buf("scan_tmp", tmp_bytes.value // 8 + 1, torch.int64)
-            _cabi.check(lib.tg_part_count(C.byref(graph), C.c_int64(shard.v_lo), ptr(got), ptr(m_dev), C.c_int64(m_cap),
-                                          C.c_int32(world), seg, call0, C.c_int32(k), C.c_int32(self.sampler), ptr(cnt),
-                                          ptr(off), ptr(self.reply_counts), ptr(tmp), C.c_int64(tmp.numel() * 8), stream))
-            _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
-                                           ptr(m_dev), C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
-                                           C.c_int32(self.sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(reply),
-                                           stream))
+            if self.general:
+                cnt, off, reply = self._owner_general(got, got_states, m_dev, m_cap, seg, call0, k, seed, stream)
+            else:
+                cnt, off, reply = self._owner_uniform(graph, got, m_dev, m_cap, seg, call0, k, seed, stream)
             if world == 1:
                 cnt_back, reply_back = cnt, reply
             else:
@@ -249,19 +316,43 @@ class PartitionedSampler:
                 cnt_back = self._buf("cnt_back", self.request_cap, torch.int32)
                 n_back = int(sum(send))
                 cnt_back[:n_back] = self._a2a(cnt[:m_cap], recv, send, "cnt_recv")
-                reply_back = self._a2a(reply[:int(sum(rc_send))], rc_send, rc_recv, "reply_recv")
+                reply_back = self._a2a(reply[:int(sum(rc_send))], rc_send, rc_recv, "reply_recv%d" % stride)
                 if reply_back.numel() == 0:
-                    reply_back = self._buf("reply_recv", 1, torch.int64, 2)
+                    reply_back = self._buf("reply_recv%d" % stride, 1, torch.int64, stride)
             _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(self.request_cap),
                                          C.c_int64(cap), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
-                                         ptr(self.ws), ptr(cnt_back), ptr(off) if world == 1 else None, ptr(reply_back), stream))
+                                         ptr(self.ws), ptr(cnt_back), ptr(off) if world == 1 else None, ptr(reply_back),
+                                         C.c_int32(stride), stream))
+        if self.sampler == _cabi.SAMPLER_WEIGHTED and int(self._weighted_status[0]) & 2:   # sampling.rs:49
+            raise RuntimeError("weighted sampling met a non-positive running weight sum (the reference panics here)")
         return self.out
 
+    def _owner_uniform(self, graph, got, m_dev, m_cap, seg, call0, k, seed, stream):
+        """owner side, unweighted and unfiltered: the dedicated count / sample kernels of csrc/partition.hip"""
+        C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
+        shard, world = self.shard, self.world
+        cnt = self._buf("cnt", m_cap, torch.int32)
+        off = self._buf("off", m_cap + 1, torch.int64)
+        reply = self._buf("reply2", m_cap * k, torch.int64, 2)
+        tmp_bytes = C.c_int64(0)
+        _cabi.check(lib.tg_part_scan_workspace_bytes(C.c_int64(m_cap), C.byref(tmp_bytes)))
+        tmp = self._buf("scan_tmp", tmp_bytes.value // 8 + 1, torch.int64)
+        _cabi.check(lib.tg_part_count(C.byref(graph), C.c_int64(shard.v_lo), ptr(got), ptr(m_dev), C.c_int64(m_cap),
+                                      C.c_int32(world), seg, call0, C.c_int32(k), C.c_int32(self.sampler), ptr(cnt),
+                                      ptr(off), ptr(self.reply_counts), ptr(tmp), C.c_int64(tmp.numel() * 8), stream))
+        _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
+                                       ptr(m_dev), C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
+                                       C.c_int32(self.sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(reply),
+                                       stream))
+        return cnt, off, reply
 
-def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None):
+
+def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
+                               filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), seeds_state=None):
     """One call of the device form (a throw-away PartitionedSampler; keep one around to reuse its buffers)."""
-    ps = PartitionedSampler(shard, seeds.shape[0], seeds.shape[1], fanout, sampler=sampler, group=group)
-    return ps.sample(seeds, seed, first_call_id)
+    ps = PartitionedSampler(shard, seeds.shape[0], seeds.shape[1], fanout, sampler=sampler, group=group,
+                            filter_mode=filter_mode, forward=forward, window=window)
+    return ps.sample(seeds, seed, first_call_id, seeds_state=seeds_state)
 
 
 def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,

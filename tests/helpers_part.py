@@ -6,13 +6,18 @@ import ctypes as C
 import torch
 
 
-def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0):
-    """-> (NsBatchedOut filled through tg_part_begin / requests / count / sample / emit, requests that left shard 0)."""
+def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0, filter_mode=-1, forward=False,
+                          window=(0, 0), seeds_state=None):
+    """-> (NsBatchedOut filled through tg_part_begin / requests / [count + sample | unpack + flat hop + pack] / emit,
+    requests that left shard 0).  Filters / weights take the general owner path."""
+    filtered = filter_mode != -1
+    general = filtered or sampler == 2
+    stride = 3 if filtered else 2
     lib, ptr = cabi.lib, cabi.ptr
     dev, world = seeds.device, len(shards)
     nb, B = seeds.shape
     H = len(fan)
-    out = cabi.NsBatchedOut(nb, B, fan, dev)
+    out = cabi.NsBatchedOut(nb, B, fan, dev, with_states=filtered)
     so, stream = out.struct(), cabi.stream_ptr(dev)
     hop_cap, cap = [], nb * B
     for k in fan:
@@ -26,14 +31,17 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0)
     requests = torch.empty((request_cap, 2), **i64)
     send_counts = torch.zeros(world + 1, **i64)
     seeds = seeds.contiguous()
-    cabi.check(lib.tg_part_begin(ptr(seeds), C.c_int64(nb), C.c_int64(B), C.c_int32(H), C.byref(so),
-                                 C.c_int64(request_cap), C.c_int32(world), ptr(ws), stream))
+    req_states = torch.empty(request_cap, **i64) if filtered else None
+    if filtered:
+        seeds_state = seeds_state.contiguous()
+    cabi.check(lib.tg_part_begin(ptr(seeds), ptr(seeds_state) if filtered else None, C.c_int64(nb), C.c_int64(B),
+                                 C.c_int32(H), C.byref(so), C.c_int64(request_cap), C.c_int32(world), ptr(ws), stream))
     crossed = 0
     call0 = (C.c_uint64 * 64)(first_call)                   # owner side sees ONE requesting rank: the origin
     for h, k in enumerate(fan):
         cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(request_cap),
                                         C.c_int64(shards[0].shard_size), C.c_int32(world), ptr(ws), ptr(requests),
-                                        ptr(send_counts), stream))
+                                        ptr(req_states) if filtered else None, ptr(send_counts), stream))
         sizes = send_counts.tolist()
         assert sum(sizes[:world]) == sizes[world]
         cnts, replies, lo = [], [], 0
@@ -44,6 +52,13 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0)
                 assert bool((owner == p).all())
                 crossed += m if p else 0
             m_dev = torch.tensor([m], **i64)
+            if general:
+                cnt, rep = _general_owner(cabi, shards[p], mine, req_states[lo:lo + m].contiguous() if filtered else None,
+                                          m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, stride, stream)
+                cnts.append(cnt[:m])
+                replies.append(rep)
+                lo += m
+                continue
             cnt = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
             off = torch.empty(max(m, 1) + 1, **i64)
             rc = torch.zeros(2, **i64)
@@ -69,9 +84,56 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0)
         cnt_back[:allc.numel()] = allc
         back = torch.cat(replies).contiguous()
         if back.numel() == 0:
-            back = torch.empty((1, 2), **i64)
+            back = torch.empty((1, stride), **i64)
         cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(request_cap),
                                     C.c_int64(hop_cap[h]), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
-                                    ptr(ws), ptr(cnt_back), None, ptr(back), stream))
+                                    ptr(ws), ptr(cnt_back), None, ptr(back), C.c_int32(stride), stream))
     torch.cuda.synchronize()
     return out, crossed
+
+
+def _general_owner(cabi, shard, mine, states, m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, stride, stream):
+    """tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack for one bucket of requests"""
+    lib, ptr = cabi.lib, cabi.ptr
+    dev = mine.device
+    i64 = dict(dtype=torch.int64, device=dev)
+    mc = max(m, 1)
+    vert, ids, calls = (torch.empty(mc, **i64) for _ in range(3))
+    seg = (C.c_int64 * 65)(0, m)
+    if m == 0:
+        return torch.zeros(1, dtype=torch.int32, device=dev), torch.empty((0, stride), **i64)
+    cabi.check(lib.tg_part_unpack(C.c_int64(shard.v_lo), C.c_int64(shard.v_hi - shard.v_lo), ptr(mine), ptr(m_dev),
+                                  C.c_int64(m), C.c_int32(1), seg, call0, ptr(vert), ptr(ids), ptr(calls), stream))
+    hcnt, hoff = torch.empty(mc, **i64), torch.empty(mc + 1, **i64)
+    nbr, ep, par, st_out = (torch.empty(mc * k, **i64) for _ in range(4))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hin, hout, flt = cabi.TgHopIn(), cabi.TgHopOut(), cabi.TgHopFilter()
+    hin.vertices, hin.ids, hin.call_ids = vert.data_ptr(), ids.data_ptr(), calls.data_ptr()
+    hin.m, hin.id_base, hin.fanout, hin.sampler, hin.rng_tag = m, 0, k, sampler, 0
+    hout.cnt, hout.offsets = hcnt.data_ptr(), hoff.data_ptr()
+    hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+    flt.filter_mode, flt.forward = filter_mode, int(bool(forward))
+    flt.win_lo, flt.win_hi = window
+    flt.states = states.data_ptr() if states is not None else None
+    g = shard.graph_view()
+    rng = cabi.TgRng(seed, 0)
+    group_cap = 1 if sampler == 2 else max(1024, g.n_edges // 512 + 2 * m + 2) * 8
+    nbytes = C.c_int64(0)
+    cabi.check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(k), C.c_int64(group_cap), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, **i64)
+    if sampler == 2:
+        cabi.check(lib.tg_ns_hop_weighted(C.byref(g), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout), ptr(st_out),
+                                          ptr(status), ptr(ws), C.c_int64(nbytes.value), stream))
+    else:
+        cabi.check(lib.tg_ns_hop_scan(C.byref(g), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout), ptr(st_out),
+                                      ptr(status), ptr(ws), C.c_int64(nbytes.value), C.c_int64(group_cap), stream))
+    assert int(status[0]) == 0
+    total = int(hoff[m])
+    cnt = torch.empty(mc, dtype=torch.int32, device=dev)
+    rep = torch.empty((max(total, 1), stride), **i64)
+    rc = torch.zeros(2, **i64)
+    cabi.check(lib.tg_part_pack(C.byref(hout), ptr(st_out) if stride == 3 else None, ptr(m_dev), C.c_int64(m),
+                                C.c_int64(shard.e_lo), C.c_int32(1), seg, ptr(cnt), ptr(rep), C.c_int32(stride), ptr(rc),
+                                stream))
+    assert int(rc[0]) == total == int(rc[1])
+    return cnt, rep[:total]

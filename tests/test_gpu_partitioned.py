@@ -119,6 +119,21 @@ def _worker(rank, world, port, q):
     for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
         s, r, c, e, lo = dout.batch(b)
         ok = ok and lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_)
+    # the same exchange under a dynamic temporal filter and with weights (filter states travel with the requests)
+    aptrs, aidx, _, ts, w = _attr_graph(dev)
+    states = torch.randint(0, 60, (4, B), device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    for case in (FILTER_CASES[2], FILTER_CASES[4]):
+        ash = partitioned.CscShard.from_full(aptrs, aidx, rank, world, weights=w, timestamps=ts)
+        ps = partitioned.PartitionedSampler(ash, 4, B, [6, 4], sampler=case["sampler"], filter_mode=case["filter_mode"],
+                                            forward=case["forward"], window=case["window"])
+        got = ps.sample(seeds, SEED, first, seeds_state=states)
+        want = _replicated_general(aptrs, aidx, ts, w, seeds, states, [6, 4], first, case)
+        c = want.counts.cpu()
+        ok = ok and torch.equal(got.counts.cpu(), c)
+        for b in range(4):
+            x, y = got.batch(b, c), want.batch(b, c)
+            ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+            ok = ok and torch.equal(got.states[b, :int(c[b, 0])], want.states[b, :int(c[b, 0])])
     remote = sum(int(((s[B:] // shard.shard_size).clamp(max=world - 1) != rank).sum()) for s, *_ in res)
     q.put((rank, ok, remote, sum(int(r.numel()) for _, r, *_ in res)))
     dist.barrier()
@@ -187,3 +202,71 @@ def test_rccl_backend_gets_device_tensors_only(monkeypatch):
     ps.sample(seeds, SEED, 0, first_call_ids=[0, 0])
     torch.cuda.synchronize()
     assert len(seen) >= 1 + 2 * 5 and all(a == "cuda" and b == "cuda" for a, b in seen)
+
+
+# ---------------------------------------------------------------- temporal filters and weights on a partitioned graph
+def _attr_graph(dev):
+    ptrs, idx, n = _graph(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    ts = torch.randint(0, 60, (idx.numel(),), device=dev, generator=g)
+    w = torch.rand(idx.numel(), device=dev, generator=g, dtype=torch.float64) + 0.05
+    return ptrs, idx, n, ts, w
+
+
+FILTER_CASES = [dict(sampler=0, filter_mode=0, forward=False, window=(10, 45)),      # static window
+                dict(sampler=1, filter_mode=1, forward=True, window=(-20, 5)),       # relative, with replacement
+                dict(sampler=0, filter_mode=2, forward=False, window=(0, 30)),       # dynamic: states follow the edges
+                dict(sampler=2, filter_mode=-1, forward=False, window=(0, 0)),       # weighted, no filter
+                dict(sampler=2, filter_mode=2, forward=True, window=(-15, 15))]      # weighted under a dynamic filter
+
+
+def _replicated_general(ptrs, idx, ts, w, seeds, states, fan, first, case):
+    from tch_geometric import _cabi
+    out = _cabi.NsBatchedOut(seeds.shape[0], seeds.shape[1], fan, seeds.device, with_states=case["filter_mode"] != -1)
+    g = _cabi.graph_view(ptrs, idx, weights=w if case["sampler"] == 2 else None,
+                         timestamps=ts if case["filter_mode"] != -1 else None)
+    _cabi.ns_homo_batched(g, seeds, fan, SEED, first, out, sampler=case["sampler"], filter_mode=case["filter_mode"],
+                          forward=case["forward"], window=case["window"],
+                          seeds_state=states if case["filter_mode"] != -1 else None)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("case", FILTER_CASES)
+@pytest.mark.parametrize("world", [1, 3])
+def test_filters_and_weights_equal_the_replicated_launch(case, world):
+    """neighbor_sampling.rs:36-77 / :131-158 over a partitioned graph: world 1 through PartitionedSampler, world 3 with
+    the exchange emulated (bucket p answered from shard p); both equal tg_ns_homo_batched on the whole graph"""
+    from helpers_part import emulated_world_sample
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n, ts, w = _attr_graph(dev)
+    fan, nb, first = [6, 4], 4, 70
+    seeds = _cabi.seed_batches(21, first, nb, B, n, dev)
+    states = torch.randint(0, 60, (nb, B), device=dev)
+    ref = _replicated_general(ptrs, idx, ts, w, seeds, states, fan, first, case)
+    assert int(ref.counts[:, 1].sum()) > 0
+    filtered = case["filter_mode"] != -1
+    if world == 1:
+        shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1, weights=w, timestamps=ts)
+        ps = partitioned.PartitionedSampler(shard, nb, B, fan, sampler=case["sampler"], filter_mode=case["filter_mode"],
+                                            forward=case["forward"], window=case["window"])
+        out = ps.sample(seeds, SEED, first, seeds_state=states if filtered else None)
+        torch.cuda.synchronize()
+    else:
+        shards = [partitioned.CscShard.from_full(ptrs, idx, r, world, weights=w, timestamps=ts) for r in range(world)]
+        out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, first, sampler=case["sampler"],
+                                             filter_mode=case["filter_mode"], forward=case["forward"],
+                                             window=case["window"], seeds_state=states)
+        assert crossed > 0
+    c = ref.counts.cpu()
+    assert torch.equal(out.counts.cpu(), c)
+    for b in range(nb):
+        x, y = out.batch(b, c), ref.batch(b, c)
+        assert x[4] == y[4]
+        for u, v in zip(x[:4], y[:4]):
+            assert torch.equal(u, v), (case, b)
+        if filtered:
+            ns = int(c[b, 0])
+            assert torch.equal(out.states[b, :ns], ref.states[b, :ns])
