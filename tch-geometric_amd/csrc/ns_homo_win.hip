@@ -138,7 +138,11 @@ __host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
 }
 
 // ---------------------------------------------------------------- K1: counts, offsets, draws, the three streams, items
-template <typename Item, int KMAX, bool REPLACE>
+// DIRECT: the hop's gathers are issued here, in batch order, and `samples` is written with the other streams -- no
+// items, no sort, no K4.  That is the right form for hop 0: the seeds are arbitrary vertices, so a launch touches a
+// line of `indices` only ~1.4 times there (RMAT-24, 4 096 batches: 11.3 M gathers over 8.3 M lines) and ordering them
+// buys nothing; deeper frontiers are drawn by degree, repeat the hubs and touch every line ~13 times.
+template <typename Item, int KMAX, bool REPLACE, bool DIRECT>
 __global__ void win_emit_kernel(const WinParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
@@ -153,7 +157,7 @@ __global__ void win_emit_kernel(const WinParams p) {
     uint8_t *slane = wbase + (size_t)64 * p.kmax * sizeof(uint32_t);
     Item *items = static_cast<Item *>(p.items_in);
 
-    const int64_t *samples = p.samples + b * p.cap_nodes;
+    int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges;
     int64_t *cols = p.cols + b * p.cap_edges;
     int64_t *eidx = p.edge_index + b * p.cap_edges;
@@ -170,7 +174,7 @@ __global__ void win_emit_kernel(const WinParams p) {
         lo[1] = ne;
         lo[2] = n_seeds + ne;
         // this batch's range of the hop's flat item array (order between batches does not matter)
-        *shared_fbase = (int64_t)atomicAdd(&p.n_items[p.hop], (unsigned long long)(end - begin));
+        *shared_fbase = DIRECT ? 0 : (int64_t)atomicAdd(&p.n_items[p.hop], (unsigned long long)(end - begin));
     }
     __syncthreads();
     const int64_t fbase = *shared_fbase;
@@ -216,7 +220,7 @@ __global__ void win_emit_kernel(const WinParams p) {
             const uint32_t excl = incl - cnt;
             const uint32_t total = __shfl(incl, 63, 64);
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
-            if (i < round_end)
+            if (!DIRECT && i < round_end)
                 items[fbase + (i - begin)] =
                     Item::make((uint64_t)e0, n, (uint32_t)b, (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
             if (cnt > 0) {
@@ -237,6 +241,37 @@ __global__ void win_emit_kernel(const WinParams p) {
                 }
             }
             wave_lds_handoff();
+            if constexpr (DIRECT) { // gathers four per lane before the first store; unconditional loads (ns_homo.hip's emit)
+                for (uint32_t q0 = 0; q0 < total; q0 += 256) {
+                    int l4[4];
+                    int64_t ep[4], v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+                        const uint32_t qq = q < total ? q : 0u;
+                        l4[u] = slane[qq];
+                        ep[u] = col0[c * 64 + l4[u]] + (int64_t)spos[qq];
+                    }
+                    if (p.indices32) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = (int64_t)__builtin_nontemporal_load(&p.indices32[ep[u]]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(&p.indices[ep[u]]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+                        if (q < total) {
+                            const int64_t e = e_chunk + q;
+                            samples[n_seeds + e] = v[u]; // :215 (the next hop's frontier)
+                            __builtin_nontemporal_store(n_seeds + e, &rows[e]);
+                            __builtin_nontemporal_store(i0 + (int64_t)l4[u], &cols[e]);
+                            __builtin_nontemporal_store(ep[u], &eidx[e]);
+                        }
+                    }
+                }
+            } else
             for (uint32_t q = lane; q < total; q += 64) { // three write-once streams, coalesced (:217)
                 const int l = slane[q];
                 const int64_t e = e_chunk + q;
@@ -535,6 +570,7 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
 template <typename Item, int KMAX, bool REPLACE>
 static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
     static const int emit_threads = win_env_int("TG_WIN_EMIT_THREADS", 256);
+    static const int direct_hop0 = win_env_int("TG_WIN_DIRECT_HOP0", 1);
     static const int gather_threads = win_env_int("TG_WIN_GATHER_THREADS", 512);
     static const int gather_blocks = (win_env_int("TG_WIN_GATHER_BLOCKS", 256) + 7) & ~7; // 8 groups of equal size
     hipLaunchKernelGGL(win_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, stream, p, n_batches);
@@ -544,7 +580,13 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
         p.k = (int32_t)fanout[h];
         int threads = emit_threads;
         while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
-        hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
+        if (h == 0 && direct_hop0) { // arbitrary seeds: nothing to gain from ordering their gathers
+            hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, true>), dim3((unsigned)n_batches), dim3(threads),
+                               win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
+            TG_LAUNCH_CHECK();
+            continue;
+        }
+        hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, false>), dim3((unsigned)n_batches), dim3(threads),
                            win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
         TG_LAUNCH_CHECK();
         hipLaunchKernelGGL(win_hist_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
