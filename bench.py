@@ -229,9 +229,16 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
     t_build = time.time()
     row, col = _cabi.rmat_edges(args.scale, n * args.edge_factor, 0x5EED0000 + args.scale, dev)
     below = int((col < v_lo).sum())         # global edge offset of the shard = edges of the columns before v_lo
-    keep = (col >= v_lo) & (col < v_hi)
-    row, col = row[keep], col[keep] - v_lo
-    del keep
+    if world > 1:                           # keep the shard's columns (in pieces: masks of 2^31 elements overflow torch's indexing)
+        rows_, cols_ = [], []
+        for lo in range(0, col.numel(), 1 << 28):
+            c = col[lo:lo + (1 << 28)]
+            keep = (c >= v_lo) & (c < v_hi)
+            rows_.append(row[lo:lo + (1 << 28)][keep])
+            cols_.append(c[keep] - v_lo)
+        del row, col, keep, c
+        row, col = torch.cat(rows_), torch.cat(cols_)
+        del rows_, cols_
     ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, v_hi - v_lo, True)
     del row, col
     shard = partitioned.CscShard(ptrs, idx, v_lo, v_hi, below, n, size)
