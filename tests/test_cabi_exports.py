@@ -84,3 +84,42 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.tg_biased_tempo_random_walk(None, None, None, None, None, C.c_int64(1), C.c_int64(2), C.c_int32(7),
                                            C.c_int32(1), C.c_int64(1), C.c_int64(0), None, None, None, None, None,
                                            C.c_int64(0), None) == 1
+
+
+def test_round2_entry_points_reject_bad_arguments(lib):
+    """the window-ordered launch, the partitioned protocol and the heterogeneous step helpers refuse bad sizes / null
+    buffers before any launch (no GPU needed)"""
+    lib.tg_last_error.restype = C.c_char_p
+    nbytes = C.c_int64(-1)
+    fan = (C.c_int64 * 2)(15, 10)
+    assert lib.tg_ns_homo_workspace_bytes(C.c_int64(4096), C.c_int64(1024), fan, C.c_int32(2), C.byref(nbytes)) == 0
+    assert nbytes.value > 4096 * 15360 * 16 * 2            # room for the widest hop's items, unsorted and sorted
+    bad = (C.c_int64 * 2)(15, 300)
+    assert lib.tg_ns_homo_workspace_bytes(C.c_int64(8), C.c_int64(8), bad, C.c_int32(2), C.byref(nbytes)) == 1
+    assert b"fanout" in lib.tg_last_error()
+    assert lib.tg_ns_homo_workspace_bytes(C.c_int64(-1), C.c_int64(8), fan, C.c_int32(2), C.byref(nbytes)) == 1
+    # tg_ns_homo_batched_ws: a workspace size without a workspace, an unknown form
+    assert lib.tg_ns_homo_batched_ws(None, None, C.c_int64(1), C.c_int64(1), fan, C.c_int32(2), None, None, None, None,
+                                     C.c_int64(64), C.c_int32(0), None) == 1
+    assert lib.tg_ns_homo_batched_ws(None, None, C.c_int64(1), C.c_int64(1), fan, C.c_int32(2), None, None, None, None,
+                                     C.c_int64(0), C.c_int32(9), None) == 1
+    assert b"mode" in lib.tg_last_error()
+    # partitioned protocol
+    assert lib.tg_part_workspace_bytes(C.c_int64(4), C.c_int64(1 << 20), C.c_int32(65), C.byref(nbytes)) == 1
+    assert lib.tg_part_workspace_bytes(C.c_int64(4), C.c_int64(1 << 33), C.c_int32(8), C.byref(nbytes)) == 1
+    assert lib.tg_part_workspace_bytes(C.c_int64(4), C.c_int64(1 << 20), C.c_int32(8), C.byref(nbytes)) == 0
+    assert nbytes.value > (1 << 20) * (16 + 8 + 4 + 8)     # requests, their states, positions, reply offsets
+    assert lib.tg_part_requests(None, C.c_int64(1), C.c_int64(1), C.c_int64(1), C.c_int32(1), None, None, None, None,
+                                None) == 1
+    assert lib.tg_part_emit(None, C.c_int64(1), C.c_int64(1), C.c_int64(1), C.c_int64(1), C.c_int32(1), C.c_int32(5),
+                            C.c_int32(0), C.c_int32(2), None, None, None, None, C.c_int32(2), None) == 1
+    assert lib.tg_part_pack(None, None, None, C.c_int64(0), C.c_int64(0), C.c_int32(1), None, None, None, C.c_int32(2),
+                            None, None) == 1
+    # heterogeneous step helpers
+    words = C.c_int64(0)
+    assert lib.tg_het_meta_words(C.c_int32(3), C.c_int32(5), C.c_int32(2), C.byref(words)) == 0
+    assert words.value == 3 * 3 + 5 + 5 * 2 * 3 + 4
+    assert lib.tg_het_meta_words(C.c_int32(0), C.c_int32(5), C.c_int32(2), C.byref(words)) == 1
+    assert lib.tg_het_step_begin(None, None, None, C.c_int32(3), C.c_int32(5), C.c_int32(2), C.c_int32(0), C.c_int32(0),
+                                 C.c_int32(0), C.c_int32(0), C.c_int64(8), None, None, None, None) == 1
+    assert lib.tg_het_hop_end(None, C.c_int32(3), C.c_int32(5), C.c_int32(2), None) == 1
