@@ -99,8 +99,18 @@ def main():
     n_pool = max(1, min(W + K, 32))
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
     form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
-    out = _cabi.NsBatchedOut(G, B, fanout, dev)
-    ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
+    while True:  # 16 384 batches per launch need ~100 GB of slabs + workspace: on a GPU with less free HBM, halve
+        try:
+            out = _cabi.NsBatchedOut(G, B, fanout, dev)
+            ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
+            break
+        except torch.OutOfMemoryError:
+            out = ws = None
+            torch.cuda.empty_cache()
+            if G <= 256:
+                raise
+            G //= 2
+            seeds = seeds[:n_pool * G].contiguous()
     acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
 
     def run(lo, hi, events=None):
