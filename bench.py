@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--mode", choices=["replicated", "partitioned"], default="replicated",
                     help="replicated: CSC on every rank, seed batches sharded (the headline).  partitioned: every rank owns "
                          "the columns of a contiguous vertex range; remote neighbours are fetched by all-to-all (cfg5 shape)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="--mode partitioned with one rank: still run every collective of the protocol over RCCL (the rank "
+                         "exchanges with itself) -- what a one-GPU box can exercise of the transport")
     ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
                     help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
     return ap.parse_args()
@@ -254,7 +257,11 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
     shard = partitioned.CscShard(ptrs, idx, v_lo, v_hi, below, n, size)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
-    ps = partitioned.PartitionedSampler(shard, G, B, fanout, group=None)
+    if args.force_exchange and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ps = partitioned.PartitionedSampler(shard, G, B, fanout, group=None, force_exchange=args.force_exchange)
     firsts = [sharding.rank_batch_range(r, world, (W + K) * G)[0] for r in range(world)]
     first = firsts[rank]
     acc = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -294,14 +301,16 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
             "batches_per_step_per_rank": G,
             "parallelism": "range-partitioned CSC (contiguous vertex ranges) over %d rank(s); per hop requests and compact "
                            "replies travel by all_to_all_single (RCCL)%s" %
-                           (world, "" if world > 1 else "; one rank: no exchange, no host read-back"),
+                           (world, "" if world > 1 else ("; one rank exchanging with itself over RCCL (all collectives and "
+                                                         "read-backs of the multi-rank protocol run)" if args.force_exchange
+                                                         else "; one rank: no exchange, no host read-back")),
             "avg_call_ms_this_rank": sum(ms) / len(ms),
             "shard_build_s": round(t_build, 2),
         },
     }
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

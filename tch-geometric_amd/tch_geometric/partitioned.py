@@ -138,10 +138,13 @@ class PartitionedSampler:
     the replicated-graph sampler's bit for bit."""
 
     def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None,
-                 filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0)):
+                 filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), force_exchange=False):
         """sampler: uniform / with replacement / weighted (shard.weights); filter_mode: a TemporalFilter mode over
         shard.timestamps (`sample()` then takes the seeds' filter states).  Filters and weights take the general
-        owner path: tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack."""
+        owner path: tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack.
+        force_exchange: with ONE rank, still run every collective of the multi-rank protocol (sizes, requests, counts,
+        replies travel through all_to_all_single to the rank itself) -- this is how the RCCL transport is exercised on
+        a one-GPU box."""
         import ctypes as C
         self.C, self.shard, self.group, self.sampler = C, shard, group, sampler
         self.filter_mode, self.forward, self.window = filter_mode, bool(forward), tuple(window)
@@ -170,7 +173,10 @@ class PartitionedSampler:
         self.send_counts = torch.zeros(self.world + 1, **i64)
         self.reply_counts = torch.zeros(self.world + 1, **i64)
         self._bufs = {}
-        self.gloo = self.world > 1 and dist.get_backend(group) == "gloo"
+        self.exchange = self.world > 1 or bool(force_exchange)
+        if force_exchange and not (dist.is_available() and dist.is_initialized()):
+            raise ValueError("force_exchange needs an initialised process group")
+        self.gloo = self.exchange and dist.get_backend(group) == "gloo"
 
     def _buf(self, name, n, dtype, cols=None):
         """persistent scratch that only ever grows"""
@@ -267,12 +273,12 @@ class PartitionedSampler:
         stream = _cabi.stream_ptr(self.dev)
         so = self.out.struct()
         seeds = seeds.contiguous()
-        if world > 1 and first_call_ids is None:
+        if self.exchange and first_call_ids is None:
             mine = torch.tensor([first_call_id], dtype=torch.int64, device="cpu" if self.gloo else self.dev)
             parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine, group=self.group)
             first_call_ids = [int(x) for x in torch.cat(parts).tolist()]
-        call0 = (C.c_uint64 * 64)(*([first_call_id] if world == 1 else first_call_ids))
+        call0 = (C.c_uint64 * 64)(*(first_call_ids if self.exchange else [first_call_id]))
         if self.filtered:
             assert seeds_state is not None and tuple(seeds_state.shape) == (nb, B)
             seeds_state = seeds_state.contiguous()
@@ -289,7 +295,7 @@ class PartitionedSampler:
                                              ptr(self.requests), ptr(self.request_states) if self.filtered else None,
                                              ptr(self.send_counts), stream))
             got_states = self.request_states
-            if world == 1:      # nothing travels and nothing is read back: sizes stay on the device
+            if not self.exchange:   # nothing travels and nothing is read back: sizes stay on the device
                 got, m_cap, m_dev = self.requests, cap, self.send_counts[1:]
                 seg = (C.c_int64 * 65)(0, cap)
             else:
@@ -309,7 +315,7 @@ class PartitionedSampler:
                 cnt, off, reply = self._owner_general(got, got_states, m_dev, m_cap, seg, call0, k, seed, stream)
             else:
                 cnt, off, reply = self._owner_uniform(graph, got, m_dev, m_cap, seg, call0, k, seed, stream)
-            if world == 1:
+            if not self.exchange:
                 cnt_back, reply_back = cnt, reply
             else:
                 rc_send, rc_recv = self._sizes(self.reply_counts[:world])
@@ -321,7 +327,7 @@ class PartitionedSampler:
                     reply_back = self._buf("reply_recv%d" % stride, 1, torch.int64, stride)
             _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(self.request_cap),
                                          C.c_int64(cap), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
-                                         ptr(self.ws), ptr(cnt_back), ptr(off) if world == 1 else None, ptr(reply_back),
+                                         ptr(self.ws), ptr(cnt_back), None if self.exchange else ptr(off), ptr(reply_back),
                                          C.c_int32(stride), stream))
         if self.sampler == _cabi.SAMPLER_WEIGHTED and int(self._weighted_status[0]) & 2:   # sampling.rs:49
             raise RuntimeError("weighted sampling met a non-positive running weight sum (the reference panics here)")

@@ -270,3 +270,56 @@ def test_filters_and_weights_equal_the_replicated_launch(case, world):
         if filtered:
             ns = int(c[b, 0])
             assert torch.equal(out.states[b, :ns], ref.states[b, :ns])
+
+
+# ---------------------------------------------------------------- the multi-rank protocol over RCCL itself, one rank
+def _rccl_worker(port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tch-geometric_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        from tch_geometric import _cabi, partitioned
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        ok, calls = True, 0
+        real = dist.all_to_all_single
+
+        def counted(*a, **k):
+            nonlocal calls
+            calls += 1
+            return real(*a, **k)
+
+        dist.all_to_all_single = counted
+        aptrs, aidx, n, ts, w = _attr_graph(dev)
+        seeds = _cabi.seed_batches(21, 70, 4, B, n, dev)
+        states = torch.randint(0, 60, (4, B), device=dev)
+        shard = partitioned.CscShard.from_full(aptrs, aidx, 0, 1, weights=w, timestamps=ts)
+        for case in (dict(sampler=0, filter_mode=-1, forward=False, window=(0, 0)), FILTER_CASES[2], FILTER_CASES[4]):
+            ps = partitioned.PartitionedSampler(shard, 4, B, [6, 4], sampler=case["sampler"], filter_mode=case["filter_mode"],
+                                                forward=case["forward"], window=case["window"], force_exchange=True)
+            got = ps.sample(seeds, SEED, 70, seeds_state=states if case["filter_mode"] != -1 else None)
+            want = _replicated_general(aptrs, aidx, ts, w, seeds, states, [6, 4], 70, case)
+            c = want.counts.cpu()
+            ok = ok and torch.equal(got.counts.cpu(), c)
+            for b in range(4):
+                x, y = got.batch(b, c), want.batch(b, c)
+                ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+        q.put(("ok" if ok else "mismatch", calls, dist.get_backend()))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put(("error: %r" % (e,), 0, ""))
+
+
+def test_protocol_over_rccl_with_one_rank():
+    """every collective of the multi-rank protocol (sizes, requests, filter states, counts, reply sizes, replies) through
+    RCCL (`backend="nccl"`) with device tensors: one rank exchanging with itself -- the transport a one-GPU box can run"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    status, calls, backend = q.get(timeout=300)
+    p.join(timeout=120)
+    assert status == "ok", status
+    assert backend == "nccl" and calls >= 3 * 2 * 5      # three configurations x two hops x >= 5 collectives per hop
