@@ -48,8 +48,27 @@ def parse_args():
     return ap.parse_args()
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """The contract is ONE JSON line on stdout.  RCCL prints its version banner to stdout when a communicator starts, so
+    file descriptor 1 is pointed at stderr for the run and the result line is written to the saved descriptor."""
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def print_result(result):
+    line = (json.dumps(result) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_RESULT_FD if _RESULT_FD is not None else 1, line)
+
+
 def main():
     args = parse_args()
+    keep_stdout_for_the_result()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
     import torch
     import torch.distributed as dist
@@ -224,7 +243,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print_result(result)
     if world > 1:
         dist.destroy_process_group()
 
@@ -254,7 +273,7 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
         del rows_, cols_
     ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, v_hi - v_lo, True)
     del row, col
-    shard = partitioned.CscShard(ptrs, idx, v_lo, v_hi, below, n, size)
+    shard = partitioned.CscShard(ptrs, idx, v_lo, v_hi, below, n, size, n_edges_global=n * args.edge_factor)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
     if args.force_exchange and world == 1 and not dist.is_initialized():
@@ -304,12 +323,13 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
                            (world, "" if world > 1 else ("; one rank exchanging with itself over RCCL (all collectives and "
                                                          "read-backs of the multi-rank protocol run)" if args.force_exchange
                                                          else "; one rank: no exchange, no host read-back")),
+            "reply_entry_bytes": 8 * ps.reply_words,
             "avg_call_ms_this_rank": sum(ms) / len(ms),
             "shard_build_s": round(t_build, 2),
         },
     }
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print_result(result)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -274,12 +274,20 @@ TG_API int tg_het_hop_end(int64_t *meta, int32_t n_types, int32_t n_rels, int32_
  *    requesting rank p are [seg_off[p], seg_off[p+1]); seg_call0[world] (host): that rank's first call id.
  *    -> cnt[m] u32 samples per request, off[m + 1] their exclusive prefix (off[m] = total), reply_counts[world + 1] (device): reply entries
  *    per requesting rank, then their total.  scan_tmp: tg_part_scan_workspace_bytes(m_cap).
- *  - tg_part_sample: reply [sum cnt][2] = (neighbour id, global edge pointer = local pointer + e_lo), compact, in
+ *  - tg_part_sample: reply [sum cnt] entries = (neighbour id, global edge pointer = local pointer + e_lo), compact, in
  *    request order; unweighted samplers, fanout <= TG_MAX_FANOUT.
+ *  - reply_format (the same value on every rank; entry size in int64 words in brackets):
+ *    TG_PART_REPLY_PAIRS [2] neighbour, edge pointer; TG_PART_REPLY_TRIPLES [3] + the sample's filter state;
+ *    TG_PART_REPLY_PACKED [1] neighbour | edge pointer << 32 -- valid when the whole graph has < 2^32 vertices and
+ *    < 2^32 edges, halves what the reply all-to-all moves; TG_PART_REPLY_PACKED_STATE [2] packed word, filter state.
  *  - tg_part_emit: cnt / reply as returned to the origin (request order); cnt_prefix: the exclusive prefix of cnt if
  *    the caller already holds it (world == 1: tg_part_count's `off`), else NULL; hop_cap = n_batches * this hop's
  *    widest frontier; compacts the replies into the slabs in slot order, advances the frontier, writes layer_offsets[hop],
  *    counts. */
+#define TG_PART_REPLY_PACKED 1
+#define TG_PART_REPLY_PAIRS 2
+#define TG_PART_REPLY_TRIPLES 3
+#define TG_PART_REPLY_PACKED_STATE 4
 TG_API int tg_part_workspace_bytes(int64_t n_batches, int64_t request_cap, int32_t world, int64_t *bytes);
 TG_API int tg_part_scan_workspace_bytes(int64_t n, int64_t *bytes);
 TG_API int tg_part_begin(const int64_t *seeds, const int64_t *seeds_state, int64_t n_batches, int64_t n_seeds, int32_t n_hops,
@@ -293,24 +301,23 @@ TG_API int tg_part_count(const tg_graph *shard, int64_t v_lo, const void *reques
 TG_API int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests, const int64_t *m_dev,
                           int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout,
                           int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off, int64_t *reply,
-                          void *stream);
+                          int32_t reply_format, void *stream);
 /* Temporal filters and the weighted sampler (neighbor_sampling.rs:36-77, :131-158) on a partitioned graph: the origin
  * also sends every frontier vertex's filter state (seeds_state / request_states [<= request_cap], grouped like the
  * requests; NULL = no filter); the owner unpacks the requests into the flat-hop input arrays (tg_part_unpack: vertices
  * rebased to the shard, -1 for padding; draw ids = the requesters' slots; call ids = the requesters'), runs
  * tg_ns_hop_scan / tg_ns_hop_weighted over them (m = m_cap, shard.timestamps / shard.weights = the shard's slices) and
- * packs the hop's compact outputs into the reply (tg_part_pack: cnt u32, entries of reply_stride words = neighbour,
- * global edge pointer[, the sample's filter state], reply_counts).  tg_part_emit with reply_stride = 3 also fills the
- * `states` slab.  Same draws as the replicated sampler, so the same results. */
+ * packs the hop's compact outputs into the reply (tg_part_pack: cnt u32, entries in reply_format, reply_counts).
+ * tg_part_emit with a reply_format that carries the filter state also fills the `states` slab.  Same draws as the replicated sampler, so the same results. */
 TG_API int tg_part_unpack(int64_t v_lo, int64_t n_major, const void *requests, const int64_t *m_dev, int64_t m_cap,
                           int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int64_t *vertices, int64_t *ids,
                           int64_t *call_ids, void *stream);
 TG_API int tg_part_pack(const tg_hop_out *hop, const int64_t *states_out, const int64_t *m_dev, int64_t m_cap, int64_t e_lo,
-                        int32_t world, const int64_t *seg_off, uint32_t *cnt, int64_t *reply, int32_t reply_stride,
+                        int32_t world, const int64_t *seg_off, uint32_t *cnt, int64_t *reply, int32_t reply_format,
                         int64_t *reply_counts, void *stream);
 TG_API int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int64_t hop_cap,
                         int32_t world, int32_t fanout, int32_t hop, int32_t n_hops, void *workspace, const uint32_t *cnt,
-                        const int64_t *cnt_prefix, const int64_t *reply, int32_t reply_stride, void *stream);
+                        const int64_t *cnt_prefix, const int64_t *reply, int32_t reply_format, void *stream);
 
 /* random_walk (src/algo/random_walk.rs:10-75; binding python.rs:584-608).
  * walks: [n, walk_length + 1] device int64, -1 padded after a dead end. */

@@ -196,19 +196,27 @@ __global__ void part_identity_kernel(const PartRequest *__restrict__ req_in, con
 }
 
 // ---------------------------------------------------------------- owner side
+__host__ __device__ inline int part_reply_words(int format) { return format == TG_PART_REPLY_PACKED_STATE ? 2 : format; }
+__host__ __device__ inline bool part_reply_packed(int format) {
+    return format == TG_PART_REPLY_PACKED || format == TG_PART_REPLY_PACKED_STATE;
+}
+__host__ __device__ inline bool part_reply_has_state(int format) {
+    return format == TG_PART_REPLY_TRIPLES || format == TG_PART_REPLY_PACKED_STATE;
+}
+
 struct PartOwnerParams {
     const int64_t *ptrs, *indices;
     const uint32_t *indices32; // optional u32 shadow of `indices`
     int64_t n_major, v_lo, e_lo;
     const PartRequest *req;
     const int64_t *m_dev; // number of requests (device)
-    int32_t k, replace, world;
+    int32_t k, replace, world, packed;
     uint64_t seed;
     int64_t seg_off[PART_MAX_WORLD + 1]; // requests of requesting rank p: [seg_off[p], seg_off[p+1])
     uint64_t seg_call0[PART_MAX_WORLD];  // that rank's first call id
     uint32_t *cnt;                       // [m]
     const int64_t *off;                  // [m] exclusive prefix of cnt
-    int64_t *reply;                      // [sum cnt][2]
+    int64_t *reply;                      // [sum cnt][2], or [sum cnt] packed words
     int64_t *reply_counts;               // [world + 1] reply entries per requesting rank, total
 };
 
@@ -304,9 +312,13 @@ template <int KMAX> __global__ void part_sample_kernel(const PartOwnerParams p) 
             for (int u = 0; u < 4; ++u) {
                 const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
                 if (q < total) {
-                    int64_t *o = p.reply + (out0 + (int64_t)q) * 2;
-                    o[0] = v[u];
-                    o[1] = ep[u] + p.e_lo;
+                    if (p.packed) { // one word per sample: halves what the reply all-to-all moves
+                        p.reply[out0 + (int64_t)q] = (int64_t)((uint64_t)v[u] | ((uint64_t)(ep[u] + p.e_lo) << 32));
+                    } else {
+                        int64_t *o = p.reply + (out0 + (int64_t)q) * 2;
+                        o[0] = v[u];
+                        o[1] = ep[u] + p.e_lo;
+                    }
                 }
             }
         }
@@ -340,16 +352,21 @@ __global__ void part_unpack_kernel(const PartOwnerParams p, int64_t m_cap, int64
 
 // hop outputs (cnt i64 [m_cap], offsets [m_cap + 1], neighbours / local edge pointers / states compact) -> reply
 __global__ void part_pack_kernel(const PartOwnerParams p, int64_t m_cap, const int64_t *hop_cnt, const int64_t *hop_off,
-                                 const int64_t *nbr, const int64_t *ep, const int64_t *st_out, int32_t stride) {
+                                 const int64_t *nbr, const int64_t *ep, const int64_t *st_out, int32_t format) {
     const int64_t m = *p.m_dev;
     const int64_t total = hop_off[m_cap];
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x)
         p.cnt[j] = (uint32_t)hop_cnt[j];
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-        int64_t *o = p.reply + q * stride;
-        o[0] = nbr[q];
-        o[1] = ep[q] + p.e_lo;
-        if (stride == 3) o[2] = st_out[q];
+        int64_t *o = p.reply + q * part_reply_words(format);
+        if (part_reply_packed(format)) {
+            o[0] = (int64_t)((uint64_t)nbr[q] | ((uint64_t)(ep[q] + p.e_lo) << 32));
+            if (format == TG_PART_REPLY_PACKED_STATE) o[1] = st_out[q];
+        } else {
+            o[0] = nbr[q];
+            o[1] = ep[q] + p.e_lo;
+            if (format == TG_PART_REPLY_TRIPLES) o[2] = st_out[q];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x <= p.world) { // reply entries per requesting rank (padding slots count 0)
         const int t = threadIdx.x;
@@ -366,8 +383,8 @@ struct PartEmitParams {
     const uint32_t *req_pos, *cnt; // cnt: per request, request order (as returned)
     const int64_t *poff;           // exclusive prefix of cnt
     const int64_t *reply;          // pairs (or triples with the sample's filter state), compact, request order
-    int64_t *states;               // filter-state slab, written when reply_stride == 3
-    int32_t k, hop, n_hops, reply_stride;
+    int64_t *states;               // filter-state slab, written when the reply carries states
+    int32_t k, hop, n_hops, reply_format;
 };
 
 __global__ void part_emit_kernel(const PartEmitParams p) {
@@ -387,6 +404,8 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
     const int64_t begin = st.begin, end = st.end, fbase = st.fbase;
     int64_t ne = st.ne;
     const int64_t n_seeds = p.n_seeds;
+    const int words = part_reply_words(p.reply_format);
+    const bool packed = part_reply_packed(p.reply_format), has_state = part_reply_has_state(p.reply_format);
     if (tid == 0) { // neighbor_sampling.rs:193
         int64_t *lo = p.layer_offsets + (b * p.n_hops + p.hop) * 3;
         lo[0] = n_seeds + ne;
@@ -436,13 +455,20 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
             for (uint32_t q = lane; q < total; q += 64) {
                 const int l = elane[q];
-                const int64_t *r = p.reply + (rbase[l] + (int64_t)eslot[q]) * p.reply_stride;
+                const int64_t *r = p.reply + (rbase[l] + (int64_t)eslot[q]) * words;
                 const int64_t e = e_chunk + q;
-                samples[n_seeds + e] = r[0];                                // :215 (the next hop's frontier)
-                if (p.reply_stride == 3) p.states[b * p.cap_nodes + n_seeds + e] = r[2]; // :216 filter.mutate()
+                int64_t nbr = r[0], ep;
+                if (packed) {
+                    ep = (int64_t)((uint64_t)nbr >> 32);
+                    nbr = (int64_t)((uint64_t)nbr & 0xffffffffull);
+                } else {
+                    ep = r[1];
+                }
+                samples[n_seeds + e] = nbr;                                 // :215 (the next hop's frontier)
+                if (has_state) p.states[b * p.cap_nodes + n_seeds + e] = r[words - 1]; // :216 filter.mutate()
                 __builtin_nontemporal_store(n_seeds + e, &rows[e]);        // :217
                 __builtin_nontemporal_store(i0 + (int64_t)l, &cols[e]);
-                __builtin_nontemporal_store(r[1], &eidx[e]);
+                __builtin_nontemporal_store(ep, &eidx[e]);
             }
             wave_lds_handoff();
         }
@@ -661,12 +687,15 @@ extern "C" int tg_part_scan_workspace_bytes(int64_t n, int64_t *bytes) {
 extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests, const int64_t *m_dev,
                               int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
                               int32_t fanout, int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off,
-                              int64_t *reply, void *stream) {
+                              int64_t *reply, int32_t reply_format, void *stream) {
     tg::PartOwnerParams p;
     int rc = part_owner_params(p, shard, v_lo, e_lo, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed);
     if (rc != TG_OK) return rc;
+    TG_REQUIRE(reply_format == TG_PART_REPLY_PAIRS || reply_format == TG_PART_REPLY_PACKED,
+               "tg_part_sample: reply_format is TG_PART_REPLY_PAIRS or TG_PART_REPLY_PACKED");
     if (m_cap == 0) return TG_OK;
     TG_REQUIRE(cnt && off && reply, "tg_part_sample: null buffers");
+    p.packed = reply_format == TG_PART_REPLY_PACKED;
     p.cnt = const_cast<uint32_t *>(cnt);
     p.off = off;
     p.reply = reply;
@@ -704,12 +733,14 @@ extern "C" int tg_part_unpack(int64_t v_lo, int64_t n_major, const void *request
 }
 
 extern "C" int tg_part_pack(const tg_hop_out *hop, const int64_t *states_out, const int64_t *m_dev, int64_t m_cap, int64_t e_lo,
-                            int32_t world, const int64_t *seg_off, uint32_t *cnt, int64_t *reply, int32_t reply_stride,
+                            int32_t world, const int64_t *seg_off, uint32_t *cnt, int64_t *reply, int32_t reply_format,
                             int64_t *reply_counts, void *stream) {
     TG_REQUIRE(hop && hop->cnt && hop->offsets && hop->neighbors && hop->edge_ptrs && m_dev && seg_off && cnt && reply &&
                    reply_counts && m_cap >= 0 && world >= 1 && world <= tg::PART_MAX_WORLD,
                "tg_part_pack: bad arguments");
-    TG_REQUIRE(reply_stride == 2 || (reply_stride == 3 && states_out), "tg_part_pack: reply_stride is 2, or 3 with states");
+    TG_REQUIRE(reply_format >= TG_PART_REPLY_PACKED && reply_format <= TG_PART_REPLY_PACKED_STATE &&
+                   (!tg::part_reply_has_state(reply_format) || states_out),
+               "tg_part_pack: reply_format is one of TG_PART_REPLY_*, the ones with a state need states_out");
     if (m_cap == 0) {
         TG_HIP(hipMemsetAsync(reply_counts, 0, sizeof(int64_t) * (size_t)(world + 1), (hipStream_t)stream));
         return TG_OK;
@@ -723,19 +754,21 @@ extern "C" int tg_part_pack(const tg_hop_out *hop, const int64_t *states_out, co
     p.reply = reply;
     p.reply_counts = reply_counts;
     hipLaunchKernelGGL(tg::part_pack_kernel, dim3(tg::part_grid(m_cap * 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p,
-                       m_cap, hop->cnt, hop->offsets, hop->neighbors, hop->edge_ptrs, states_out, reply_stride);
+                       m_cap, hop->cnt, hop->offsets, hop->neighbors, hop->edge_ptrs, states_out, reply_format);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
 
 extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int64_t hop_cap,
                             int32_t world, int32_t fanout, int32_t hop, int32_t n_hops, void *workspace,
-                            const uint32_t *cnt, const int64_t *cnt_prefix, const int64_t *reply, int32_t reply_stride,
+                            const uint32_t *cnt, const int64_t *cnt_prefix, const int64_t *reply, int32_t reply_format,
                             void *stream) {
     TG_REQUIRE(out && workspace && cnt && n_batches >= 1 && fanout >= 1 && fanout <= 255 && hop >= 0 && hop < n_hops &&
                    n_hops <= TG_MAX_HOPS,
                "tg_part_emit: bad arguments");
-    TG_REQUIRE(reply_stride == 2 || (reply_stride == 3 && out->states), "tg_part_emit: reply_stride is 2, or 3 with a `states` slab");
+    TG_REQUIRE(reply_format >= TG_PART_REPLY_PACKED && reply_format <= TG_PART_REPLY_PACKED_STATE &&
+                   (!tg::part_reply_has_state(reply_format) || out->states),
+               "tg_part_emit: reply_format is one of TG_PART_REPLY_*, the ones with a state need a `states` slab");
     TG_REQUIRE(out->samples && out->rows && out->cols && out->edge_index && out->layer_offsets && out->counts,
                "tg_part_emit: null output slabs");
     using namespace tg;
@@ -767,7 +800,7 @@ extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_s
     p.poff = poff;
     p.reply = reply;
     p.states = out->states;
-    p.reply_stride = reply_stride;
+    p.reply_format = reply_format;
     p.k = fanout;
     p.hop = hop;
     p.n_hops = n_hops;

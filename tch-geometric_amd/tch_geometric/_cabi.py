@@ -15,6 +15,7 @@ TG_OK = 0
 TG_MAX_HOPS = 8
 TG_MAX_FANOUT = 32
 SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL, SAMPLER_WEIGHTED = 0, 1, 2
+PART_REPLY_PACKED, PART_REPLY_PAIRS, PART_REPLY_TRIPLES, PART_REPLY_PACKED_STATE = 1, 2, 3, 4   # tchgeo.h TG_PART_REPLY_*
 FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",

@@ -30,8 +30,10 @@ SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL = _cabi.SAMPLER_UNIFORM, _cabi.SAMPLER_UNI
 class CscShard:
     """Columns [v_lo, v_hi) of a CSC: ptrs rebased to 0, indices = global row ids, e_lo = global edge offset."""
 
-    def __init__(self, ptrs, indices, v_lo, v_hi, e_lo, n_nodes, shard_size, weights=None, timestamps=None):
+    def __init__(self, ptrs, indices, v_lo, v_hi, e_lo, n_nodes, shard_size, weights=None, timestamps=None,
+                 n_edges_global=None):
         self.ptrs, self.indices = ptrs, indices
+        self.n_edges_global = None if n_edges_global is None else int(n_edges_global)   # the whole graph's edge count
         self.weights, self.timestamps = weights, timestamps      # this shard's slices of the per-edge attributes
         self.v_lo, self.v_hi, self.e_lo = int(v_lo), int(v_hi), int(e_lo)
         self.n_nodes, self.shard_size = int(n_nodes), int(shard_size)
@@ -57,7 +59,7 @@ class CscShard:
         e_lo, e_hi = int(ptrs[lo]), int(ptrs[hi])
         cut = lambda a: a[e_lo:e_hi].contiguous() if a is not None else None
         return cls((ptrs[lo:hi + 1] - e_lo).contiguous(), indices[e_lo:e_hi].contiguous(), lo, hi, e_lo, n, size,
-                   weights=cut(weights), timestamps=cut(timestamps))
+                   weights=cut(weights), timestamps=cut(timestamps), n_edges_global=int(ptrs[n]))
 
 
 def _world(group):
@@ -138,13 +140,17 @@ class PartitionedSampler:
     the replicated-graph sampler's bit for bit."""
 
     def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None,
-                 filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), force_exchange=False):
+                 filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), force_exchange=False,
+                 packed_replies=None):
         """sampler: uniform / with replacement / weighted (shard.weights); filter_mode: a TemporalFilter mode over
         shard.timestamps (`sample()` then takes the seeds' filter states).  Filters and weights take the general
         owner path: tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack.
         force_exchange: with ONE rank, still run every collective of the multi-rank protocol (sizes, requests, counts,
         replies travel through all_to_all_single to the rank itself) -- this is how the RCCL transport is exercised on
-        a one-GPU box."""
+        a one-GPU box.
+        packed_replies: a reply entry is one word (neighbour | global edge pointer << 32) instead of two -- half the bytes
+        of the largest all-to-all.  None = whenever the graph allows it (shard.n_nodes and shard.n_edges_global < 2^32);
+        every rank must pass the same value."""
         import ctypes as C
         self.C, self.shard, self.group, self.sampler = C, shard, group, sampler
         self.filter_mode, self.forward, self.window = filter_mode, bool(forward), tuple(window)
@@ -177,6 +183,13 @@ class PartitionedSampler:
         if force_exchange and not (dist.is_available() and dist.is_initialized()):
             raise ValueError("force_exchange needs an initialised process group")
         self.gloo = self.exchange and dist.get_backend(group) == "gloo"
+        fits = shard.n_nodes < 2 ** 32 and shard.n_edges_global is not None and shard.n_edges_global < 2 ** 32
+        if packed_replies and not fits:
+            raise ValueError("packed replies need n_nodes and the graph's n_edges_global below 2^32")
+        packed = fits if packed_replies is None else bool(packed_replies)
+        self.reply_format = ((_cabi.PART_REPLY_PACKED_STATE if packed else _cabi.PART_REPLY_TRIPLES) if self.filtered
+                             else (_cabi.PART_REPLY_PACKED if packed else _cabi.PART_REPLY_PAIRS))
+        self.reply_words = 2 if self.reply_format == _cabi.PART_REPLY_PACKED_STATE else self.reply_format
 
     def _buf(self, name, n, dtype, cols=None):
         """persistent scratch that only ever grows"""
@@ -254,12 +267,11 @@ class PartitionedSampler:
                 mult *= 8
                 continue
             break
-        stride = 3 if self.filtered else 2
         cnt = self._buf("cnt", m_cap, torch.int32)
-        reply = self._buf("reply%d" % stride, m_cap * k, i64, stride)
+        reply = self._buf("reply", m_cap * k, i64, self.reply_words)
         _cabi.check(lib.tg_part_pack(C.byref(hout), ptr(st_out) if self.filtered else None, ptr(m_dev), C.c_int64(m_cap),
                                      C.c_int64(shard.e_lo), C.c_int32(self.world), seg, ptr(cnt), ptr(reply),
-                                     C.c_int32(stride), ptr(self.reply_counts), stream))
+                                     C.c_int32(self.reply_format), ptr(self.reply_counts), stream))
         self._weighted_status = status
         return cnt, hoff, reply
 
@@ -285,7 +297,6 @@ class PartitionedSampler:
         _cabi.check(lib.tg_part_begin(ptr(seeds), ptr(seeds_state) if self.filtered else None, C.c_int64(nb), C.c_int64(B),
                                       C.c_int32(H), C.byref(so), C.c_int64(self.request_cap), C.c_int32(world),
                                       ptr(self.ws), stream))
-        stride = 3 if self.filtered else 2
         graph = self.shard.graph_view()
         shard = self.shard
         for h, k in enumerate(self.fanout):
@@ -322,13 +333,13 @@ class PartitionedSampler:
                 cnt_back = self._buf("cnt_back", self.request_cap, torch.int32)
                 n_back = int(sum(send))
                 cnt_back[:n_back] = self._a2a(cnt[:m_cap], recv, send, "cnt_recv")
-                reply_back = self._a2a(reply[:int(sum(rc_send))], rc_send, rc_recv, "reply_recv%d" % stride)
+                reply_back = self._a2a(reply[:int(sum(rc_send))], rc_send, rc_recv, "reply_recv")
                 if reply_back.numel() == 0:
-                    reply_back = self._buf("reply_recv%d" % stride, 1, torch.int64, stride)
+                    reply_back = self._buf("reply_recv", 1, torch.int64, self.reply_words)
             _cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(self.request_cap),
                                          C.c_int64(cap), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
                                          ptr(self.ws), ptr(cnt_back), None if self.exchange else ptr(off), ptr(reply_back),
-                                         C.c_int32(stride), stream))
+                                         C.c_int32(self.reply_format), stream))
         if self.sampler == _cabi.SAMPLER_WEIGHTED and int(self._weighted_status[0]) & 2:   # sampling.rs:49
             raise RuntimeError("weighted sampling met a non-positive running weight sum (the reference panics here)")
         return self.out
@@ -339,7 +350,7 @@ class PartitionedSampler:
         shard, world = self.shard, self.world
         cnt = self._buf("cnt", m_cap, torch.int32)
         off = self._buf("off", m_cap + 1, torch.int64)
-        reply = self._buf("reply2", m_cap * k, torch.int64, 2)
+        reply = self._buf("reply", m_cap * k, torch.int64, self.reply_words)
         tmp_bytes = C.c_int64(0)
         _cabi.check(lib.tg_part_scan_workspace_bytes(C.c_int64(m_cap), C.byref(tmp_bytes)))
         tmp = self._buf("scan_tmp", tmp_bytes.value // 8 + 1, torch.int64)
@@ -349,15 +360,16 @@ class PartitionedSampler:
         _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
                                        ptr(m_dev), C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
                                        C.c_int32(self.sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(reply),
-                                       stream))
+                                       C.c_int32(self.reply_format), stream))
         return cnt, off, reply
 
 
 def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
-                               filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), seeds_state=None):
+                               filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), seeds_state=None,
+                               packed_replies=None):
     """One call of the device form (a throw-away PartitionedSampler; keep one around to reuse its buffers)."""
     ps = PartitionedSampler(shard, seeds.shape[0], seeds.shape[1], fanout, sampler=sampler, group=group,
-                            filter_mode=filter_mode, forward=forward, window=window)
+                            filter_mode=filter_mode, forward=forward, window=window, packed_replies=packed_replies)
     return ps.sample(seeds, seed, first_call_id, seeds_state=seeds_state)
 
 

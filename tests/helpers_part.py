@@ -7,12 +7,14 @@ import torch
 
 
 def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0, filter_mode=-1, forward=False,
-                          window=(0, 0), seeds_state=None):
+                          window=(0, 0), seeds_state=None, packed=False):
     """-> (NsBatchedOut filled through tg_part_begin / requests / [count + sample | unpack + flat hop + pack] / emit,
-    requests that left shard 0).  Filters / weights take the general owner path."""
+    requests that left shard 0).  Filters / weights take the general owner path.  packed: one-word reply entries
+    (TG_PART_REPLY_PACKED / _PACKED_STATE) instead of pairs / triples."""
     filtered = filter_mode != -1
     general = filtered or sampler == 2
-    stride = 3 if filtered else 2
+    fmt = (4 if packed else 3) if filtered else (1 if packed else 2)     # tchgeo.h TG_PART_REPLY_*
+    words = 2 if fmt == 4 else fmt
     lib, ptr = cabi.lib, cabi.ptr
     dev, world = seeds.device, len(shards)
     nb, B = seeds.shape
@@ -54,7 +56,7 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
             m_dev = torch.tensor([m], **i64)
             if general:
                 cnt, rep = _general_owner(cabi, shards[p], mine, req_states[lo:lo + m].contiguous() if filtered else None,
-                                          m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, stride, stream)
+                                          m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, fmt, stream)
                 cnts.append(cnt[:m])
                 replies.append(rep)
                 lo += m
@@ -72,10 +74,11 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
                                          ptr(rc), ptr(tmp), C.c_int64(tmp.numel() * 8), stream))
             total = int(rc[1])
             assert total == int(rc[0]) and (m == 0 or total == int(cnt[:m].sum()))
-            rep = torch.empty((max(total, 1), 2), **i64)
+            rep = torch.empty((max(total, 1), words), **i64)
             cabi.check(lib.tg_part_sample(C.byref(g), C.c_int64(shards[p].v_lo), C.c_int64(shards[p].e_lo), ptr(mine),
                                           ptr(m_dev), C.c_int64(m), C.c_int32(1), seg, call0, C.c_int32(k),
-                                          C.c_int32(sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(rep), stream))
+                                          C.c_int32(sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(rep),
+                                          C.c_int32(fmt), stream))
             cnts.append(cnt[:m])
             replies.append(rep[:total])
             lo += m
@@ -84,24 +87,25 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
         cnt_back[:allc.numel()] = allc
         back = torch.cat(replies).contiguous()
         if back.numel() == 0:
-            back = torch.empty((1, stride), **i64)
+            back = torch.empty((1, words), **i64)
         cabi.check(lib.tg_part_emit(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(request_cap),
                                     C.c_int64(hop_cap[h]), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
-                                    ptr(ws), ptr(cnt_back), None, ptr(back), C.c_int32(stride), stream))
+                                    ptr(ws), ptr(cnt_back), None, ptr(back), C.c_int32(fmt), stream))
     torch.cuda.synchronize()
     return out, crossed
 
 
-def _general_owner(cabi, shard, mine, states, m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, stride, stream):
+def _general_owner(cabi, shard, mine, states, m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, fmt, stream):
     """tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack for one bucket of requests"""
     lib, ptr = cabi.lib, cabi.ptr
     dev = mine.device
     i64 = dict(dtype=torch.int64, device=dev)
+    words = 2 if fmt == 4 else fmt
     mc = max(m, 1)
     vert, ids, calls = (torch.empty(mc, **i64) for _ in range(3))
     seg = (C.c_int64 * 65)(0, m)
     if m == 0:
-        return torch.zeros(1, dtype=torch.int32, device=dev), torch.empty((0, stride), **i64)
+        return torch.zeros(1, dtype=torch.int32, device=dev), torch.empty((0, words), **i64)
     cabi.check(lib.tg_part_unpack(C.c_int64(shard.v_lo), C.c_int64(shard.v_hi - shard.v_lo), ptr(mine), ptr(m_dev),
                                   C.c_int64(m), C.c_int32(1), seg, call0, ptr(vert), ptr(ids), ptr(calls), stream))
     hcnt, hoff = torch.empty(mc, **i64), torch.empty(mc + 1, **i64)
@@ -130,10 +134,10 @@ def _general_owner(cabi, shard, mine, states, m_dev, m, k, sampler, filter_mode,
     assert int(status[0]) == 0
     total = int(hoff[m])
     cnt = torch.empty(mc, dtype=torch.int32, device=dev)
-    rep = torch.empty((max(total, 1), stride), **i64)
+    rep = torch.empty((max(total, 1), words), **i64)
     rc = torch.zeros(2, **i64)
-    cabi.check(lib.tg_part_pack(C.byref(hout), ptr(st_out) if stride == 3 else None, ptr(m_dev), C.c_int64(m),
-                                C.c_int64(shard.e_lo), C.c_int32(1), seg, ptr(cnt), ptr(rep), C.c_int32(stride), ptr(rc),
+    cabi.check(lib.tg_part_pack(C.byref(hout), ptr(st_out) if fmt in (3, 4) else None, ptr(m_dev), C.c_int64(m),
+                                C.c_int64(shard.e_lo), C.c_int32(1), seg, ptr(cnt), ptr(rep), C.c_int32(fmt), ptr(rc),
                                 stream))
     assert int(rc[0]) == total == int(rc[1])
     return cnt, rep[:total]

@@ -115,6 +115,11 @@ def test_round2_entry_points_reject_bad_arguments(lib):
                             C.c_int32(0), C.c_int32(2), None, None, None, None, C.c_int32(2), None) == 1
     assert lib.tg_part_pack(None, None, None, C.c_int64(0), C.c_int64(0), C.c_int32(1), None, None, None, C.c_int32(2),
                             None, None) == 1
+    assert lib.tg_part_sample(None, C.c_int64(0), C.c_int64(0), None, None, C.c_int64(0), C.c_int32(1), None, None,
+                              C.c_int32(4), C.c_int32(0), C.c_uint64(0), None, None, None, C.c_int32(1), None) == 1
+    # an unknown reply format is refused by pack and emit alike
+    assert lib.tg_part_emit(None, C.c_int64(1), C.c_int64(1), C.c_int64(1), C.c_int64(1), C.c_int32(1), C.c_int32(5),
+                            C.c_int32(0), C.c_int32(2), None, None, None, None, C.c_int32(7), None) == 1
     # heterogeneous step helpers
     words = C.c_int64(0)
     assert lib.tg_het_meta_words(C.c_int32(3), C.c_int32(5), C.c_int32(2), C.byref(words)) == 0

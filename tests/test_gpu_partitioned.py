@@ -51,11 +51,14 @@ def test_single_rank_partitioned_equals_batched(sampler):
                     sampler=sampler)
     assert np.array_equal(res[2][0].cpu().numpy(), o[0]) and np.array_equal(res[2][3].cpu().numpy(), o[3])
     # the device form of the exchange (csrc/partition.hip) fills ordinary per-batch slabs with the same contents
-    dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler)
-    torch.cuda.synchronize()
-    for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
-        s, r, c, e, lo = dout.batch(b)
-        assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_), b
+    # (with one-word packed replies, which this small graph allows, and with pairs)
+    for packed in (None, False):
+        dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler,
+                                                      packed_replies=packed)
+        torch.cuda.synchronize()
+        for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
+            s, r, c, e, lo = dout.batch(b)
+            assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_), b
 
 
 @pytest.mark.parametrize("fan", [[1], [32, 2], [3, 3, 3], []])
@@ -157,10 +160,12 @@ def test_two_ranks_on_one_gpu_over_gloo():
         assert edges > 0 and remote > 0        # the test really crossed the partition boundary
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("world", [3, 8])
-def test_device_kernels_with_an_emulated_world(world):
+def test_device_kernels_with_an_emulated_world(world, packed):
     """The request bucketing / owner sampling / emit kernels for world > 2, with the all-to-alls emulated in one
-    process: bucket p of the requests is sampled against shard p, replies are concatenated in bucket order."""
+    process: bucket p of the requests is sampled against shard p, replies are concatenated in bucket order.  Both reply
+    formats: (neighbour, edge pointer) pairs and the one-word packed entries."""
     from helpers_part import emulated_world_sample
     from tch_geometric import _cabi, partitioned
     dev = torch.device("cuda:0")
@@ -168,7 +173,7 @@ def test_device_kernels_with_an_emulated_world(world):
     nb, fan = 6, [7, 5]
     seeds = _cabi.seed_batches(13, 500, nb, B, n, dev)
     shards = [partitioned.CscShard.from_full(ptrs, idx, r, world) for r in range(world)]
-    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 500)
+    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 500, packed=packed)
     ref = _cabi.NsBatchedOut(nb, B, fan, dev)
     _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED, 500, ref)
     torch.cuda.synchronize()
@@ -233,9 +238,10 @@ def _replicated_general(ptrs, idx, ts, w, seeds, states, fan, first, case):
     return out
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("case", FILTER_CASES)
 @pytest.mark.parametrize("world", [1, 3])
-def test_filters_and_weights_equal_the_replicated_launch(case, world):
+def test_filters_and_weights_equal_the_replicated_launch(case, world, packed):
     """neighbor_sampling.rs:36-77 / :131-158 over a partitioned graph: world 1 through PartitionedSampler, world 3 with
     the exchange emulated (bucket p answered from shard p); both equal tg_ns_homo_batched on the whole graph"""
     from helpers_part import emulated_world_sample
@@ -251,14 +257,14 @@ def test_filters_and_weights_equal_the_replicated_launch(case, world):
     if world == 1:
         shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1, weights=w, timestamps=ts)
         ps = partitioned.PartitionedSampler(shard, nb, B, fan, sampler=case["sampler"], filter_mode=case["filter_mode"],
-                                            forward=case["forward"], window=case["window"])
+                                            forward=case["forward"], window=case["window"], packed_replies=packed)
         out = ps.sample(seeds, SEED, first, seeds_state=states if filtered else None)
         torch.cuda.synchronize()
     else:
         shards = [partitioned.CscShard.from_full(ptrs, idx, r, world, weights=w, timestamps=ts) for r in range(world)]
         out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, first, sampler=case["sampler"],
                                              filter_mode=case["filter_mode"], forward=case["forward"],
-                                             window=case["window"], seeds_state=states)
+                                             window=case["window"], seeds_state=states, packed=packed)
         assert crossed > 0
     c = ref.counts.cpu()
     assert torch.equal(out.counts.cpu(), c)
