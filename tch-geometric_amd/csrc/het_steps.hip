@@ -11,8 +11,8 @@
 //                       draw ids = fbeg + i (the slot of the vertex in its type's list), filter states alongside.
 //   [tg_ns_hop / tg_ns_hop_scan / tg_ns_hop_weighted over the padded frontier]
 //   tg_het_step_end     appends the step's samples to list[src] (and their filter states), (row = new index in
-//                       src's list, col = frontier slot, edge pointer) to the relation's lists (:333-340), then
-//                       advances len[src] and ne[r].
+//                       src's list, col = frontier slot, edge pointer) to the relation's lists (:333-340) and
+//                       advances len[src] and ne[r] (same launch: the append reads the snapshot, not the live lengths).
 //   tg_het_hop_end      slices[t] = (end, len[t]) for every node type (:345-348).
 #include "tg_device.h"
 #include "tg_host.h"
@@ -67,6 +67,11 @@ __global__ void het_end_kernel(const int64_t *__restrict__ offsets, const int64_
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, 4);
         return;
     }
+    // the append works from the snapshot tg_het_step_begin took, so the live lengths can advance in the same launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        M.len[src] = base_s + total;
+        M.ne[rel] = base_e + total;
+    }
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
         list_src[base_s + j] = nbr[j];                       // :333
         if (state_src) state_src[base_s + j] = st_out[j];    // :334
@@ -74,14 +79,6 @@ __global__ void het_end_kernel(const int64_t *__restrict__ offsets, const int64_
         cols[base_e + j] = par[j] + fb;                      // :340 i
         eidx[base_e + j] = ep[j];
     }
-}
-
-// after het_end_kernel (its own launch: every thread of the append has read the snapshot by then)
-__global__ void het_advance_kernel(const int64_t *offsets, int64_t cap_f, int64_t *meta, int T, int R, int H, int src, int rel) {
-    const HetMeta M = het_meta(meta, T, R, H);
-    const int64_t total = offsets[cap_f];
-    M.len[src] = M.snap[0] + total;
-    M.ne[rel] = M.snap[1] + total;
 }
 
 __global__ void het_hop_end_kernel(int64_t *meta, int T, int R, int H) {
@@ -131,8 +128,6 @@ extern "C" int tg_het_step_end(const tg_hop_out *out, const int64_t *states_out,
     hipLaunchKernelGGL(tg::het_end_kernel, dim3((unsigned)g), dim3(256), 0, s, out->offsets, out->neighbors, out->edge_ptrs,
                        out->parents, states_out, cap_f, meta, (int)n_types, (int)n_rels, (int)n_hops, (int)src, (int)rel,
                        list_src, state_src, cap_list, rows, cols, edge_index, cap_edges, status);
-    hipLaunchKernelGGL(tg::het_advance_kernel, dim3(1), dim3(1), 0, s, out->offsets, cap_f, meta, (int)n_types, (int)n_rels,
-                       (int)n_hops, (int)src, (int)rel);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -19,11 +19,12 @@
 
 #include "tg_device.h"
 #include "tg_host.h"
+#include "tg_scan.h"
 
 namespace tg {
 
 constexpr int HS_GROUP = 512;  // edges per group = 8 chunks of 64
-constexpr int HS_RUN = 32;     // groups per wavefront work unit
+constexpr int HS_RUN = 32;     // groups per wavefront work unit, at most (fewer when the frontier has few groups)
 constexpr int HS_CHUNKS = 8;
 
 struct HopScanParams {
@@ -40,6 +41,7 @@ struct HopScanParams {
     // workspace
     int64_t *vgroups; // [m + 1] groups per vertex, then (in place) first group of every vertex; [m] = total
     uint32_t *gcount; // [group_cap]
+    uint64_t *gchunk; // [group_cap] admissible edges of each of the group's 8 chunks, one byte each (<= 64)
     int64_t *gpref;   // [group_cap + 1] exclusive prefix of gcount
     int64_t *park;    // [m * k]
     int32_t *status;  // [0] overflow flag
@@ -67,14 +69,53 @@ __global__ void hs_check_kernel(const HopScanParams p) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && p.vgroups[p.m] >= p.group_cap) p.status[0] = 1;
 }
 
-// wavefront per run of HS_RUN consecutive groups
+// The three prefix sums of a hop in one launch each when the frontier is short (tg_scan.h): a per-call hop is bound by
+// its number of launches.  groups1 = hs_groups_kernel + scan + hs_check_kernel.
+__global__ void __launch_bounds__(SCAN1_THREADS) hs_groups1_kernel(const HopScanParams p) {
+    for (int64_t i0 = threadIdx.x; i0 < p.m; i0 += 8 * SCAN1_THREADS) { // eight independent gathers in flight per lane
+        int64_t w[8], a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + (int64_t)u * SCAN1_THREADS;
+            w[u] = (i < p.m) ? p.vertices[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = (w[u] >= 0) ? p.ptrs[w[u]] : 0;
+            b[u] = (w[u] >= 0) ? p.ptrs[w[u] + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + (int64_t)u * SCAN1_THREADS;
+            if (i < p.m) p.vgroups[i + 1] = (b[u] - a[u] + HS_GROUP - 1) / HS_GROUP;
+        }
+    }
+    __syncthreads();
+    block_scan_exclusive_plus1(p.m, [&](int64_t i) { return p.vgroups[i + 1]; }, p.vgroups);
+    __syncthreads();
+    if (threadIdx.x == 0 && p.vgroups[p.m] >= p.group_cap) p.status[0] = 1;
+}
+// gpref[0 .. n_groups]: only the groups the frontier really has are scanned (their number is on the device)
+__global__ void __launch_bounds__(SCAN1_THREADS) hs_gscan1_kernel(const HopScanParams p) {
+    const int64_t gt = p.vgroups[p.m];
+    if (gt >= p.group_cap) return;
+    block_scan_exclusive_plus1(gt, [&](int64_t i) { return p.gcount[i]; }, p.gpref);
+}
+__global__ void __launch_bounds__(SCAN1_THREADS) hs_oscan1_kernel(const HopScanParams p) {
+    block_scan_exclusive_plus1(p.m, [&](int64_t i) { return p.cnt[i]; }, p.offsets);
+}
+
+// wavefront per run of consecutive groups
 __global__ void hs_count_kernel(const HopScanParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t gt = p.vgroups[p.m];
     if (gt >= p.group_cap) return;
-    for (int64_t g0 = wave_id * HS_RUN; g0 < gt; g0 += n_waves * HS_RUN) {
+    // a run's groups are read one after the other (each a dependent chain of loads): long runs only when there are
+    // more groups than wavefronts to spread them over
+    const int64_t run = max((int64_t)1, min((int64_t)HS_RUN, (gt + n_waves - 1) / n_waves));
+    for (int64_t g0 = wave_id * run; g0 < gt; g0 += n_waves * run) {
         // vertex owning group g0: last v with vgroups[v] <= g0
         int64_t lo = 0, hi = p.m - 1;
         while (lo < hi) {
@@ -85,7 +126,7 @@ __global__ void hs_count_kernel(const HopScanParams p) {
                 hi = mid - 1;
         }
         int64_t v = lo;
-        const int64_t g1 = min(g0 + HS_RUN, gt);
+        const int64_t g1 = min(g0 + run, gt);
         for (int64_t g = g0; g < g1; ++g) {
             while (g >= p.vgroups[v + 1]) ++v; // skip to the owner (vertices without groups own nothing)
             const int64_t w = p.vertices[v];
@@ -99,12 +140,18 @@ __global__ void hs_count_kernel(const HopScanParams p) {
                 tsv[u] = (e < e1) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
             }
             uint32_t c = 0;
+            uint64_t per_chunk = 0;
 #pragma unroll
             for (int u = 0; u < HS_CHUNKS; ++u) {
                 const int64_t e = gb + u * 64 + lane;
-                c += (uint32_t)__popcll(__ballot(e < e1 && hs_pass(p, st, tsv[u])));
+                const uint32_t cu = (uint32_t)__popcll(__ballot(e < e1 && hs_pass(p, st, tsv[u])));
+                c += cu;
+                per_chunk |= (uint64_t)cu << (8 * u);
             }
-            if (lane == 0) p.gcount[g] = c;
+            if (lane == 0) {
+                p.gcount[g] = c;
+                p.gchunk[g] = per_chunk;
+            }
         }
     }
 }
@@ -112,6 +159,7 @@ __global__ void hs_count_kernel(const HopScanParams p) {
 // wavefront per frontier vertex.  Per wavefront in LDS: ranks[k] (the ranks to fetch, slot order) and, for fan-outs
 // above 64, the ticket chain's displaced entries keys[k] / vals[k].
 constexpr int HS_MAX_FANOUT = 1024;
+constexpr int HS_LOCATE = 8; // slots whose chunk reads are in flight together
 __global__ void hs_select_kernel(const HopScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,11 +236,13 @@ __global__ void hs_select_kernel(const HopScanParams p) {
             }
         }
         wave_lds_handoff();
-        // locate every kept rank: binary search over the vertex's groups, then re-read that group
+        // locate every kept rank.  Lane = slot: binary search over the vertex's groups, then the group's per-chunk counts
+        // name the 64-edge chunk and the rank inside it -- all slots side by side.  Then the wavefront reads the chunks of
+        // HS_LOCATE slots at once (one load per lane and slot, all in flight together) and a ballot names each edge.
         if (cnt_sel > 0) {
             const int64_t st = p.states[v];
             const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
-            for (uint32_t s = 0; s < cnt_sel; ++s) {
+            for (uint32_t s = lane; s < cnt_sel; s += 64) {
                 const int64_t target = base_rank + (int64_t)ranks[s];
                 int64_t lo = gfirst, hi = glast - 1; // last group g with gpref[g] <= target
                 while (lo < hi) {
@@ -202,26 +252,37 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                     else
                         hi = mid - 1;
                 }
-                const int64_t gb = e0 + (lo - gfirst) * HS_GROUP;
-                int64_t seen = p.gpref[lo];
-                int64_t tsv[HS_CHUNKS];
+                uint32_t r = (uint32_t)(target - p.gpref[lo]);
+                const uint64_t per_chunk = p.gchunk[lo];
+                uint32_t u = 0;
 #pragma unroll
-                for (int u = 0; u < HS_CHUNKS; ++u) {
-                    const int64_t e = gb + u * 64 + lane;
-                    tsv[u] = (e < e1) ? p.timestamps[e] : 0;
+                for (int c = 0; c < HS_CHUNKS - 1; ++c) {
+                    const uint32_t cu = (uint32_t)(per_chunk >> (8 * c)) & 0xffu;
+                    const bool next = (u == (uint32_t)c) && r >= cu;
+                    r -= next ? cu : 0u;
+                    u += next ? 1u : 0u;
                 }
-                bool found = false;
+                keys[s] = (uint32_t)(lo - gfirst) * HS_CHUNKS + u; // chunk of the column
+                vals[s] = r;                                        // rank among the chunk's admissible edges
+            }
+            wave_lds_handoff();
+            for (uint32_t s0 = 0; s0 < cnt_sel; s0 += HS_LOCATE) {
+                int64_t tsv[HS_LOCATE];
 #pragma unroll
-                for (int u = 0; u < HS_CHUNKS; ++u) {
-                    const int64_t e = gb + u * 64 + lane;
-                    const bool ok = e < e1 && hs_pass(p, st, tsv[u]);
-                    const uint64_t mask = __ballot(ok);
-                    const int64_t c = __popcll(mask);
-                    if (!found && target - seen < c) {
-                        if (ok && seen + (int64_t)__popcll(mask & lt_mask) == target) p.park[v * k + s] = e;
-                        found = true;
+                for (int j = 0; j < HS_LOCATE; ++j) {
+                    const uint32_t s = min(s0 + (uint32_t)j, cnt_sel - 1u);
+                    const int64_t e = e0 + (int64_t)keys[s] * 64 + lane;
+                    tsv[j] = (e < e1) ? p.timestamps[e] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < HS_LOCATE; ++j) {
+                    const uint32_t s = s0 + (uint32_t)j;
+                    if (s < cnt_sel) {
+                        const int64_t e = e0 + (int64_t)keys[s] * 64 + lane;
+                        const bool ok = e < e1 && hs_pass(p, st, tsv[j]);
+                        const uint64_t mask = __ballot(ok);
+                        if (ok && (uint32_t)__popcll(mask & lt_mask) == vals[s]) p.park[v * k + s] = e;
                     }
-                    seen += c;
                 }
             }
         }
@@ -307,20 +368,14 @@ __global__ void hw_select_kernel(const HopScanParams p) {
     }
 }
 
-// thread per output edge: owner vertex by binary search over offsets, slot from the difference
+// thread per (frontier vertex, slot): the slot's output position is offsets[v] + s -- no search, two rounds of loads
 __global__ void hs_emit_kernel(const HopScanParams p) {
-    const int64_t total = p.offsets[p.m];
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        int64_t lo = 0, hi = p.m - 1; // last v with offsets[v] <= o
-        while (lo < hi) {
-            const int64_t mid = (lo + hi + 1) >> 1;
-            if (p.offsets[mid] <= o)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        const int64_t v = lo, s = o - p.offsets[v];
-        const int64_t ep = p.park[v * p.k + s];
+    const int64_t n = p.m * p.k;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = t / p.k, s = t - v * p.k;
+        if (s >= p.cnt[v]) continue;
+        const int64_t o = p.offsets[v] + s;
+        const int64_t ep = p.park[t];
         p.neighbors[o] = p.indices[ep];
         p.edge_ptrs[o] = ep;
         p.parents[o] = v;
@@ -345,7 +400,8 @@ extern "C" int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t
     TG_REQUIRE(m >= 0 && fanout >= 1 && group_cap >= 1 && bytes, "tg_ns_hop_scan_workspace_bytes: bad arguments");
     using namespace tg;
     const int64_t big = group_cap + 1 > m + 1 ? group_cap + 1 : m + 1;
-    *bytes = (int64_t)(hs_align(8 * (size_t)(m + 1)) + hs_align(4 * (size_t)group_cap) + hs_align(8 * (size_t)(group_cap + 1)) +
+    *bytes = (int64_t)(hs_align(8 * (size_t)(m + 1)) + hs_align(4 * (size_t)group_cap) + hs_align(8 * (size_t)group_cap) +
+                       hs_align(8 * (size_t)(group_cap + 1)) +
                        hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(hs_scan_temp(big)) + 512);
     return TG_OK;
 }
@@ -403,6 +459,7 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
     };
     p.vgroups = reinterpret_cast<int64_t *>(take(8 * (size_t)(p.m + 1)));
     p.gcount = reinterpret_cast<uint32_t *>(take(4 * (size_t)group_cap));
+    p.gchunk = reinterpret_cast<uint64_t *>(take(8 * (size_t)group_cap));
     p.gpref = reinterpret_cast<int64_t *>(take(8 * (size_t)(group_cap + 1)));
     p.park = reinterpret_cast<int64_t *>(take(8 * (size_t)p.m * p.k));
     void *temp = base + off;
@@ -421,21 +478,35 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
         if (g > 256 * 32) g = 256 * 32;
         return dim3((unsigned)g);
     };
-    hipLaunchKernelGGL(hs_groups_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
+    // short frontiers (the per-call operators): every prefix sum is one single-workgroup launch and nothing is memset
+    const bool short_m = p.m <= SCAN1_MAX, short_g = group_cap <= SCAN1_MAX;
     size_t st = temp_bytes;
-    TG_HIP(rocprim::inclusive_scan(temp, st, p.vgroups + 1, p.vgroups + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
-                                   false));
-    hipLaunchKernelGGL(hs_check_kernel, dim3(1), dim3(64), 0, stream, p);
-    TG_HIP(hipMemsetAsync(p.gcount, 0, 4 * (size_t)group_cap, stream)); // groups beyond the frontier's count as empty
+    if (short_m) {
+        hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(hs_groups_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
+        TG_HIP(rocprim::inclusive_scan(temp, st, p.vgroups + 1, p.vgroups + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
+                                       false));
+        hipLaunchKernelGGL(hs_check_kernel, dim3(1), dim3(64), 0, stream, p);
+    }
+    if (!short_g) TG_HIP(hipMemsetAsync(p.gcount, 0, 4 * (size_t)group_cap, stream)); // groups beyond the frontier's count as empty
     hipLaunchKernelGGL(hs_count_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
-    st = temp_bytes;
-    TG_HIP(rocprim::exclusive_scan(temp, st, p.gcount, p.gpref, (int64_t)0, (size_t)group_cap, rocprim::plus<int64_t>(),
-                                   stream, false));
+    if (short_g) {
+        hipLaunchKernelGGL(hs_gscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+    } else {
+        st = temp_bytes;
+        TG_HIP(rocprim::exclusive_scan(temp, st, p.gcount, p.gpref, (int64_t)0, (size_t)group_cap, rocprim::plus<int64_t>(),
+                                       stream, false));
+    }
     // the frontier uses fewer than group_cap groups (else status = 1), so gpref[n_groups] is inside the scanned range
     hipLaunchKernelGGL(hs_select_kernel, grid(p.m * 64, 256), dim3(256), (size_t)4 * 3 * p.k * sizeof(uint32_t), stream, p);
-    TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
-    st = temp_bytes;
-    TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
+    if (short_m) {
+        hipLaunchKernelGGL(hs_oscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+    } else {
+        TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
+        st = temp_bytes;
+        TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
+    }
     hipLaunchKernelGGL(hs_emit_kernel, grid(p.m * p.k, 256), dim3(256), 0, stream, p);
     TG_LAUNCH_CHECK();
     return TG_OK;
@@ -492,6 +563,7 @@ extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, cons
     };
     p.vgroups = reinterpret_cast<int64_t *>(take(8 * (size_t)(p.m + 1)));
     p.gcount = reinterpret_cast<uint32_t *>(take(4));
+    p.gchunk = reinterpret_cast<uint64_t *>(take(8));
     p.gpref = reinterpret_cast<int64_t *>(take(16));
     p.park = reinterpret_cast<int64_t *>(take(8 * (size_t)p.m * p.k));
     void *temp = base + off;
@@ -509,9 +581,13 @@ extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, cons
     int64_t blocks = (p.m + n_waves - 1) / n_waves;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
-    TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
-    size_t st = temp_bytes;
-    TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
+    if (p.m <= SCAN1_MAX) {
+        hipLaunchKernelGGL(hs_oscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+    } else {
+        TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
+        size_t st = temp_bytes;
+        TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
+    }
     int64_t g = (p.m * p.k + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     hipLaunchKernelGGL(hs_emit_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);

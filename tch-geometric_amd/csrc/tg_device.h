@@ -94,6 +94,19 @@ template <typename T> __device__ __forceinline__ T wave_inclusive_scan(T v) {
     }
     return v;
 }
+// Inclusive prefix sum of one u32 per lane with DPP row shifts / row broadcasts: six v_add_u32 with a DPP operand
+// instead of six ds_bpermute round trips through the LDS crossbar.  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32_dpp(uint32_t v) {
+    // row_shr:n = 0x110 + n (inside each row of 16 lanes; lanes without a source keep `old` = 0)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    // row_bcast:15 (0x142) into rows 1 and 3, then row_bcast:31 (0x143) into rows 2 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
