@@ -242,7 +242,7 @@ TG_API int tg_ns_hetero_batched(const tg_het_problem *problem, int64_t n_batches
 /* Device-side bookkeeping for neighbor_sampling_heterogenous (neighbor_sampling.rs:292-352) when its (hop, relation)
  * steps run as flat hops -- temporal filters, the weighted sampler, sizes beyond the fused launch: list lengths,
  * frontier slices and edge counts live in `meta` (device, tg_het_meta_words int64 words:
- * len[T] | fbeg[T] | fend[T] | ne[R] | layer_offsets[R][H][3] | 4 scratch words; the caller initialises len = fend =
+ * len[T] | fbeg[T] | fend[T] | ne[R] | layer_offsets[R][H][3] | scratch words; the caller initialises len = fend =
  * number of inputs, fbeg = 0, ne = 0), so a call needs no read-back between steps.  Per hop, per relation in
  * `edge_types` order: tg_het_step_begin (frontier = list[dst][fbeg, fend) into a buffer of cap_f slots padded with -1,
  * draw ids = slot in the list, layer_offsets[rel][hop]) -> tg_ns_hop / tg_ns_hop_scan / tg_ns_hop_weighted with m =
@@ -257,6 +257,57 @@ TG_API int tg_het_step_end(const tg_hop_out *out, const int64_t *states_out, int
                            int64_t *state_src, int64_t cap_list, int64_t *rows, int64_t *cols, int64_t *edge_index,
                            int64_t cap_edges, int32_t *status, void *stream);
 TG_API int tg_het_hop_end(int64_t *meta, int32_t n_types, int32_t n_rels, int32_t n_hops, void *stream);
+
+/* The same hop with ALL its relations in one set of launches (a per-call operator is bound by its number of launches).
+ * A hop's frontier is fixed when the hop starts (neighbor_sampling.rs:345-348 advance the slices at its end), so the
+ * relations' frontiers are concatenated (entry j owns slots [begin, begin + cap) of the concatenation, cap = its
+ * worst-case frontier size), sampled by ONE tg_ns_hop_segments call, and their appends are replayed in relation order:
+ *   tg_het_hop_begin_all  snapshots lengths / edge counts / frontier starts; builds the concatenated frontier (-1
+ *                         padded), its draw ids and filter states.
+ *   tg_ns_hop_segments    the flat filtered / weighted hop over a frontier made of up to TG_HOP_MAX_SEGMENTS segments,
+ *                         each with its own graph, fan-out and draw tag (hop_in.fanout / rng_tag are ignored;
+ *                         hop_in.sampler = TG_SAMPLER_WEIGHTED takes tg_ns_hop_weighted's algorithm, the unweighted
+ *                         samplers tg_ns_hop_scan's and need a filter).  Outputs are compact over the concatenation, so a
+ *                         segment's samples are contiguous; `parents` index the concatenation.  Workspace:
+ *                         tg_ns_hop_scan_workspace_bytes(m, largest fan-out, group_cap).
+ *   tg_het_hop_end_all    for the entries in order: layer_offsets[rel][hop], append samples / states / edges, advance
+ *                         lengths and edge counts; `last` != 0 also sets the next hop's frontier slices.  out_cap: an
+ *                         upper bound of the hop's samples (sizes the launch).
+ * layout_dev (device, [segments + 1], NULL = none): the frontier WITHOUT its padding -- tg_het_hop_begin_all packs the
+ * segments' real frontiers back to back and writes their starts and the total there; tg_ns_hop_segments and
+ * tg_het_hop_end_all then work on the real length (the host-side begin / cap / m stay the worst case that sizes the
+ * launches).  Needs m <= 2^17 and group_cap <= 2^20.
+ * Entries list EVERY relation sampled in the hop, in `edge_types` order, also those whose frontier is necessarily empty
+ * (segment = -1: only their layer offset is recorded).  More than TG_HET_HOP_MAX_ENTRIES relations or
+ * TG_HOP_MAX_SEGMENTS segments: several begin / sample / end rounds, `last` on the final one. */
+#define TG_HOP_MAX_SEGMENTS 8
+#define TG_HET_HOP_MAX_ENTRIES 16
+typedef struct {
+    const tg_graph *graph;
+    int64_t begin;    /* first frontier slot of the segment; ascending, segment 0 starts at 0 */
+    int32_t fanout;
+    uint32_t rng_tag; /* 0 = TG_TAG_NS_HOMO */
+} tg_hop_segment;
+typedef struct {
+    int32_t rel, src, dst;
+    int32_t segment;                      /* >= 0: the relation has a frontier segment in this round; -1: none */
+    int64_t begin, cap;                   /* its slots in the concatenated frontier */
+    const int64_t *list_dst, *state_dst;  /* sample list / filter states of the dst type (the frontier is read there) */
+    int64_t *list_src, *state_src;        /* sample list / filter states of the src type (samples are appended) */
+    int64_t cap_list_src;
+    int64_t *rows, *cols, *edge_index;    /* the relation's edge lists */
+    int64_t cap_edges;
+} tg_het_entry;
+TG_API int tg_ns_hop_segments(const tg_hop_segment *segments, int32_t n_segments, const tg_hop_in *in,
+                              const int64_t *layout_dev, const tg_hop_filter *filter, const tg_rng *rng,
+                              const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                              int64_t workspace_bytes, int64_t group_cap, void *stream);
+TG_API int tg_het_hop_begin_all(const tg_het_entry *entries, int32_t n_entries, int64_t *meta, int32_t n_types, int32_t n_rels,
+                                int32_t n_hops, int64_t m_total, int64_t *frontier, int64_t *fstate, int64_t *ids,
+                                int64_t *layout_dev, void *stream);
+TG_API int tg_het_hop_end_all(const tg_het_entry *entries, int32_t n_entries, const tg_hop_out *out, const int64_t *states_out,
+                              int64_t m_total, int64_t out_cap, const int64_t *layout_dev, int64_t *meta, int32_t n_types,
+                              int32_t n_rels, int32_t n_hops, int32_t hop, int32_t last, int32_t *status, void *stream);
 
 /* neighbor_sampling_homogenous over a RANGE-PARTITIONED CSC (graphs beyond one GPU's HBM; host protocol in
  * tch_geometric/partitioned.py; SURVEY.md 8(e) mode 2).  The origin rank keeps ordinary

@@ -27,15 +27,28 @@ constexpr int HS_GROUP = 512;  // edges per group = 8 chunks of 64
 constexpr int HS_RUN = 32;     // groups per wavefront work unit, at most (fewer when the frontier has few groups)
 constexpr int HS_CHUNKS = 8;
 
-struct HopScanParams {
+// The frontier may be the concatenation of up to HS_MAX_SEG SEGMENTS, each with its own graph, fan-out and draw tag
+// (all relations of one heterogeneous hop in one set of launches): vertex i belongs to the last segment whose `begin`
+// is <= i.  The single-graph entry points use one segment.
+constexpr int HS_MAX_SEG = TG_HOP_MAX_SEGMENTS;
+struct HsSeg {
     const int64_t *ptrs, *indices, *timestamps;
     const double *weights;
+    int64_t begin;
+    int32_t k;
+    uint32_t tag;
+};
+struct HopScanParams {
+    HsSeg seg[HS_MAX_SEG];
+    int32_t n_seg;
+    // optional device-side layout [n_seg + 1]: the segments' real starts, then the frontier's real length (<= m); the
+    // host-side `begin`s and `m` are then only the worst case the launches are sized for
+    const int64_t *layout_dev;
     const int64_t *vertices, *states, *ids, *call_ids;
     int64_t m, id_base;
-    int32_t k, replace;
+    int32_t k, replace; // k: the largest fan-out of the segments = the stride of `park`
     int32_t filter_mode, forward;
     int64_t win_lo, win_hi;
-    uint32_t tag;
     uint64_t seed, call_id;
     int64_t group_cap;
     // workspace
@@ -49,6 +62,27 @@ struct HopScanParams {
     int64_t *cnt, *offsets, *neighbors, *edge_ptrs, *parents, *states_out;
 };
 
+// the segment table goes from the kernel arguments to LDS once per workgroup (dynamic indexing of by-value kernel
+// arguments would go through scratch memory)
+__device__ __forceinline__ int64_t hs_m(const HopScanParams &p) { // the frontier's length
+    return p.layout_dev ? min(p.m, p.layout_dev[p.n_seg]) : p.m;
+}
+__device__ __forceinline__ int64_t hs_load_segs(const HopScanParams &p, HsSeg *S) {
+#pragma unroll
+    for (int j = 0; j < HS_MAX_SEG; ++j)
+        if ((int)threadIdx.x == j && j < p.n_seg) {
+            S[j] = p.seg[j];
+            if (p.layout_dev) S[j].begin = p.layout_dev[j];
+        }
+    __syncthreads();
+    return hs_m(p);
+}
+__device__ __forceinline__ int hs_seg_of(const HsSeg *S, int n_seg, int64_t v) {
+    int s = 0;
+    for (int j = 1; j < n_seg; ++j) s += (v >= S[j].begin) ? 1 : 0;
+    return s;
+}
+
 __device__ __forceinline__ bool hs_pass(const HopScanParams &p, int64_t state, int64_t t) { // neighbor_sampling.rs:55-67
     if (p.filter_mode == TG_FILTER_NONE) return true;
     const int64_t x = (p.filter_mode == TG_FILTER_STATIC) ? t : (p.forward ? (t - state) : -(t - state));
@@ -56,68 +90,81 @@ __device__ __forceinline__ bool hs_pass(const HopScanParams &p, int64_t state, i
 }
 
 __global__ void hs_groups_kernel(const HopScanParams p) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.m; i += (int64_t)gridDim.x * blockDim.x) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t w = p.vertices[i];
         int64_t g = 0;
-        if (w >= 0) g = (p.ptrs[w + 1] - p.ptrs[w] + HS_GROUP - 1) / HS_GROUP;
+        if (w >= 0) {
+            const int64_t *ptrs = S[hs_seg_of(S, p.n_seg, i)].ptrs;
+            g = (ptrs[w + 1] - ptrs[w] + HS_GROUP - 1) / HS_GROUP;
+        }
         p.vgroups[i + 1] = g;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) p.vgroups[0] = 0;
 }
 // after the inclusive scan: vgroups[i] = first group of vertex i, vgroups[m] = number of groups
 __global__ void hs_check_kernel(const HopScanParams p) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && p.vgroups[p.m] >= p.group_cap) p.status[0] = 1;
+    const int64_t m = hs_m(p);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && p.vgroups[m] >= p.group_cap) p.status[0] = 1;
 }
 
 // The three prefix sums of a hop in one launch each when the frontier is short (tg_scan.h): a per-call hop is bound by
 // its number of launches.  groups1 = hs_groups_kernel + scan + hs_check_kernel.
 __global__ void __launch_bounds__(SCAN1_THREADS) hs_groups1_kernel(const HopScanParams p) {
-    for (int64_t i0 = threadIdx.x; i0 < p.m; i0 += 8 * SCAN1_THREADS) { // eight independent gathers in flight per lane
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    for (int64_t i0 = threadIdx.x; i0 < m; i0 += 8 * SCAN1_THREADS) { // eight independent gathers in flight per lane
         int64_t w[8], a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t i = i0 + (int64_t)u * SCAN1_THREADS;
-            w[u] = (i < p.m) ? p.vertices[i] : -1;
+            w[u] = (i < m) ? p.vertices[i] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            a[u] = (w[u] >= 0) ? p.ptrs[w[u]] : 0;
-            b[u] = (w[u] >= 0) ? p.ptrs[w[u] + 1] : 0;
+            const int64_t *ptrs = S[hs_seg_of(S, p.n_seg, i0 + (int64_t)u * SCAN1_THREADS)].ptrs;
+            a[u] = (w[u] >= 0) ? ptrs[w[u]] : 0;
+            b[u] = (w[u] >= 0) ? ptrs[w[u] + 1] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t i = i0 + (int64_t)u * SCAN1_THREADS;
-            if (i < p.m) p.vgroups[i + 1] = (b[u] - a[u] + HS_GROUP - 1) / HS_GROUP;
+            if (i < m) p.vgroups[i + 1] = (b[u] - a[u] + HS_GROUP - 1) / HS_GROUP;
         }
     }
     __syncthreads();
-    block_scan_exclusive_plus1(p.m, [&](int64_t i) { return p.vgroups[i + 1]; }, p.vgroups);
+    block_scan_exclusive_plus1(m, [&](int64_t i) { return p.vgroups[i + 1]; }, p.vgroups);
     __syncthreads();
-    if (threadIdx.x == 0 && p.vgroups[p.m] >= p.group_cap) p.status[0] = 1;
+    if (threadIdx.x == 0 && p.vgroups[m] >= p.group_cap) p.status[0] = 1;
 }
 // gpref[0 .. n_groups]: only the groups the frontier really has are scanned (their number is on the device)
 __global__ void __launch_bounds__(SCAN1_THREADS) hs_gscan1_kernel(const HopScanParams p) {
-    const int64_t gt = p.vgroups[p.m];
+    const int64_t m = hs_m(p);
+    const int64_t gt = p.vgroups[m];
     if (gt >= p.group_cap) return;
     block_scan_exclusive_plus1(gt, [&](int64_t i) { return p.gcount[i]; }, p.gpref);
 }
 __global__ void __launch_bounds__(SCAN1_THREADS) hs_oscan1_kernel(const HopScanParams p) {
-    block_scan_exclusive_plus1(p.m, [&](int64_t i) { return p.cnt[i]; }, p.offsets);
+    const int64_t m = hs_m(p);
+    block_scan_exclusive_plus1(m, [&](int64_t i) { return p.cnt[i]; }, p.offsets);
 }
 
 // wavefront per run of consecutive groups
 __global__ void hs_count_kernel(const HopScanParams p) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
     const int lane = threadIdx.x & 63;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t gt = p.vgroups[p.m];
+    const int64_t gt = p.vgroups[m];
     if (gt >= p.group_cap) return;
     // a run's groups are read one after the other (each a dependent chain of loads): long runs only when there are
     // more groups than wavefronts to spread them over
     const int64_t run = max((int64_t)1, min((int64_t)HS_RUN, (gt + n_waves - 1) / n_waves));
     for (int64_t g0 = wave_id * run; g0 < gt; g0 += n_waves * run) {
         // vertex owning group g0: last v with vgroups[v] <= g0
-        int64_t lo = 0, hi = p.m - 1;
+        int64_t lo = 0, hi = m - 1;
         while (lo < hi) {
             const int64_t mid = (lo + hi + 1) >> 1;
             if (p.vgroups[mid] <= g0)
@@ -131,13 +178,14 @@ __global__ void hs_count_kernel(const HopScanParams p) {
             while (g >= p.vgroups[v + 1]) ++v; // skip to the owner (vertices without groups own nothing)
             const int64_t w = p.vertices[v];
             const int64_t st = p.states[v];
-            const int64_t e1 = p.ptrs[w + 1];
-            const int64_t gb = p.ptrs[w] + (g - p.vgroups[v]) * HS_GROUP;
+            const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+            const int64_t e1 = sg.ptrs[w + 1];
+            const int64_t gb = sg.ptrs[w] + (g - p.vgroups[v]) * HS_GROUP;
             int64_t tsv[HS_CHUNKS];
 #pragma unroll
             for (int u = 0; u < HS_CHUNKS; ++u) {
                 const int64_t e = gb + u * 64 + lane;
-                tsv[u] = (e < e1) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
+                tsv[u] = (e < e1) ? __builtin_nontemporal_load(&sg.timestamps[e]) : 0;
             }
             uint32_t c = 0;
             uint64_t per_chunk = 0;
@@ -166,12 +214,15 @@ __global__ void hs_select_kernel(const HopScanParams p) {
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const bool overflow = p.vgroups[p.m] >= p.group_cap;
-    const CallKey ck0 = call_key(p.seed, p.call_id, p.tag);
-    const int k = p.k;
-    uint32_t *ranks = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * 3 * k, *keys = ranks + k, *vals = keys + k;
-    for (int64_t v = wave_id; v < p.m; v += n_waves) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    const bool overflow = p.vgroups[m] >= p.group_cap;
+    const int kmax = p.k;
+    uint32_t *ranks = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * 3 * kmax, *keys = ranks + kmax, *vals = keys + kmax;
+    for (int64_t v = wave_id; v < m; v += n_waves) {
         const int64_t w = p.vertices[v];
+        const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+        const int k = sg.k;
         const int64_t gfirst = p.vgroups[v], glast = p.vgroups[v + 1];
         uint32_t n = 0;
         int64_t base_rank = 0;
@@ -183,7 +234,7 @@ __global__ void hs_select_kernel(const HopScanParams p) {
         if (lane == 0) p.cnt[v] = cnt_sel;
         if (cnt_sel > 0) {
             const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
-            const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[v], p.tag) : ck0;
+            const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
             if (p.replace) { // sampling.rs:57-69
                 for (uint32_t s = lane; s < (uint32_t)k; s += 64)
                     ranks[s] = bounded32(draw(ck, did, s >> 1, D1_REPLACE).half(s & 1), n);
@@ -241,7 +292,7 @@ __global__ void hs_select_kernel(const HopScanParams p) {
         // HS_LOCATE slots at once (one load per lane and slot, all in flight together) and a ballot names each edge.
         if (cnt_sel > 0) {
             const int64_t st = p.states[v];
-            const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
+            const int64_t e0 = sg.ptrs[w], e1 = sg.ptrs[w + 1];
             for (uint32_t s = lane; s < cnt_sel; s += 64) {
                 const int64_t target = base_rank + (int64_t)ranks[s];
                 int64_t lo = gfirst, hi = glast - 1; // last group g with gpref[g] <= target
@@ -272,7 +323,7 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                 for (int j = 0; j < HS_LOCATE; ++j) {
                     const uint32_t s = min(s0 + (uint32_t)j, cnt_sel - 1u);
                     const int64_t e = e0 + (int64_t)keys[s] * 64 + lane;
-                    tsv[j] = (e < e1) ? p.timestamps[e] : 0;
+                    tsv[j] = (e < e1) ? sg.timestamps[e] : 0;
                 }
 #pragma unroll
                 for (int j = 0; j < HS_LOCATE; ++j) {
@@ -281,12 +332,12 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                         const int64_t e = e0 + (int64_t)keys[s] * 64 + lane;
                         const bool ok = e < e1 && hs_pass(p, st, tsv[j]);
                         const uint64_t mask = __ballot(ok);
-                        if (ok && (uint32_t)__popcll(mask & lt_mask) == vals[s]) p.park[v * k + s] = e;
+                        if (ok && (uint32_t)__popcll(mask & lt_mask) == vals[s]) p.park[v * kmax + s] = e;
                     }
                 }
             }
         }
-        for (uint32_t s = cnt_sel + lane; s < (uint32_t)k; s += 64) p.park[v * k + s] = -1;
+        for (uint32_t s = cnt_sel + lane; s < (uint32_t)kmax; s += 64) p.park[v * kmax + s] = -1;
         wave_lds_handoff();
     }
 }
@@ -298,24 +349,27 @@ __global__ void hs_select_kernel(const HopScanParams p) {
 __global__ void hw_select_kernel(const HopScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = p.k;
-    int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem) + (size_t)wave * (2 * k + 64);
-    uint32_t *slot_rank = reinterpret_cast<uint32_t *>(slot_ptr + k);
-    double *pbuf = reinterpret_cast<double *>(slot_ptr + 2 * k); // 64 doubles for the serial prefix
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    const int kmax = p.k;
+    int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem) + (size_t)wave * (2 * kmax + 64);
+    uint32_t *slot_rank = reinterpret_cast<uint32_t *>(slot_ptr + kmax);
+    double *pbuf = reinterpret_cast<double *>(slot_ptr + 2 * kmax); // 64 doubles for the serial prefix
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const CallKey ck0 = call_key(p.seed, p.call_id, p.tag);
-    for (int64_t v = wave_id; v < p.m; v += n_waves) {
+    for (int64_t v = wave_id; v < m; v += n_waves) {
         const int64_t w = p.vertices[v];
+        const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+        const int k = sg.k;
         uint32_t n = 0;
         for (int sl = lane; sl < k; sl += 64) slot_rank[sl] = 0;
         wave_lds_handoff();
         if (w >= 0) {
             const int64_t st = p.states ? p.states[v] : 0;
-            const int64_t e0 = p.ptrs[w], e1 = p.ptrs[w + 1];
+            const int64_t e0 = sg.ptrs[w], e1 = sg.ptrs[w + 1];
             const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
-            const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[v], p.tag) : ck0;
+            const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
             double w_sum = 0.0;
             for (int64_t gbase = e0; gbase < e1; gbase += 64 * HS_CHUNKS) {
                 int64_t tsv[HS_CHUNKS];
@@ -323,8 +377,8 @@ __global__ void hw_select_kernel(const HopScanParams p) {
 #pragma unroll
                 for (int u = 0; u < HS_CHUNKS; ++u) {
                     const int64_t e = gbase + u * 64 + lane;
-                    tsv[u] = (p.filter_mode != TG_FILTER_NONE && e < e1) ? __builtin_nontemporal_load(&p.timestamps[e]) : 0;
-                    wvv[u] = (e < e1) ? __builtin_nontemporal_load(&p.weights[e]) : 0.0;
+                    tsv[u] = (p.filter_mode != TG_FILTER_NONE && e < e1) ? __builtin_nontemporal_load(&sg.timestamps[e]) : 0;
+                    wvv[u] = (e < e1) ? __builtin_nontemporal_load(&sg.weights[e]) : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < HS_CHUNKS; ++u) {
@@ -363,24 +417,27 @@ __global__ void hw_select_kernel(const HopScanParams p) {
         wave_lds_handoff();
         const uint32_t cnt_sel = min(n, (uint32_t)k);
         if (lane == 0) p.cnt[v] = cnt_sel;
-        for (int sl = lane; sl < k; sl += 64) p.park[v * k + sl] = ((uint32_t)sl < cnt_sel) ? slot_ptr[sl] : -1;
+        for (int sl = lane; sl < kmax; sl += 64) p.park[v * kmax + sl] = ((uint32_t)sl < cnt_sel) ? slot_ptr[sl] : -1;
         wave_lds_handoff();
     }
 }
 
 // thread per (frontier vertex, slot): the slot's output position is offsets[v] + s -- no search, two rounds of loads
 __global__ void hs_emit_kernel(const HopScanParams p) {
-    const int64_t n = p.m * p.k;
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    const int64_t n = m * p.k;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t v = t / p.k, s = t - v * p.k;
         if (s >= p.cnt[v]) continue;
         const int64_t o = p.offsets[v] + s;
         const int64_t ep = p.park[t];
-        p.neighbors[o] = p.indices[ep];
+        const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+        p.neighbors[o] = sg.indices[ep];
         p.edge_ptrs[o] = ep;
         p.parents[o] = v;
         if (p.filter_mode != TG_FILTER_NONE)
-            p.states_out[o] = (p.filter_mode == TG_FILTER_DYNAMIC) ? p.timestamps[ep] : p.states[v]; // :69-76
+            p.states_out[o] = (p.filter_mode == TG_FILTER_DYNAMIC) ? sg.timestamps[ep] : p.states[v]; // :69-76
     }
 }
 
@@ -406,47 +463,48 @@ extern "C" int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t
     return TG_OK;
 }
 
-extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
-                              const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
-                              int64_t workspace_bytes, int64_t group_cap, void *stream_) {
-    using namespace tg;
-    TG_REQUIRE(csc && csc->ptrs && in && flt && rng && out && status, "tg_ns_hop_scan: null argument");
-    TG_REQUIRE(csc->timestamps, "tg_ns_hop_scan: the graph has no edge timestamps");
-    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= HS_MAX_FANOUT, "tg_ns_hop_scan: bad frontier size or fan-out (<= %d)",
+// ---------------------------------------------------------------- host side: one launcher for every entry point
+namespace tg {
+struct HsCall {
+    HsSeg seg[HS_MAX_SEG];
+    int n_seg;
+    int kmax;
+    bool weighted;
+    const int64_t *layout_dev;
+};
+
+static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
+                  const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace, int64_t workspace_bytes,
+                  int64_t group_cap, hipStream_t stream) {
+    const int filter_mode = flt ? flt->filter_mode : TG_FILTER_NONE;
+    TG_REQUIRE(in->m >= 0 && c.kmax >= 1 && c.kmax <= HS_MAX_FANOUT, "%s: bad frontier size or fan-out (<= %d)", who,
                HS_MAX_FANOUT);
-    TG_REQUIRE(in->sampler == TG_SAMPLER_UNIFORM || in->sampler == TG_SAMPLER_UNIFORM_REPL,
-               "tg_ns_hop_scan: only the unweighted samplers");
-    TG_REQUIRE(flt->filter_mode >= TG_FILTER_STATIC && flt->filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_scan: bad filter");
-    TG_REQUIRE(out->cnt && out->offsets && group_cap >= 1, "tg_ns_hop_scan: null outputs");
-    hipStream_t stream = (hipStream_t)stream_;
+    TG_REQUIRE(out->cnt && out->offsets && group_cap >= 1, "%s: null outputs", who);
     if (in->m == 0) {
         TG_HIP(hipMemsetAsync(out->offsets, 0, sizeof(int64_t), stream));
         return TG_OK;
     }
     int64_t need = 0;
-    int rc = tg_ns_hop_scan_workspace_bytes(in->m, in->fanout, group_cap, &need);
+    int rc = tg_ns_hop_scan_workspace_bytes(in->m, c.kmax, group_cap, &need);
     if (rc != TG_OK) return rc;
-    TG_REQUIRE(workspace && workspace_bytes >= need, "tg_ns_hop_scan: workspace too small");
-    TG_REQUIRE(in->vertices && flt->states && out->neighbors && out->edge_ptrs && out->parents && states_out,
-               "tg_ns_hop_scan: null buffers");
-    HopScanParams p;
-    p.ptrs = csc->ptrs;
-    p.indices = csc->indices;
-    p.timestamps = csc->timestamps;
-    p.weights = nullptr;
+    TG_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace too small", who);
+    TG_REQUIRE(in->vertices && out->neighbors && out->edge_ptrs && out->parents, "%s: null buffers", who);
+    HopScanParams p{};
+    for (int j = 0; j < c.n_seg; ++j) p.seg[j] = c.seg[j];
+    p.n_seg = c.n_seg;
+    p.layout_dev = c.layout_dev;
     p.vertices = in->vertices;
-    p.states = flt->states;
+    p.states = filter_mode == TG_FILTER_NONE ? nullptr : flt->states;
     p.ids = in->ids;
     p.call_ids = in->call_ids;
     p.m = in->m;
     p.id_base = in->id_base;
-    p.k = in->fanout;
+    p.k = c.kmax;
     p.replace = in->sampler == TG_SAMPLER_UNIFORM_REPL;
-    p.filter_mode = flt->filter_mode;
-    p.forward = flt->forward;
-    p.win_lo = flt->win_lo;
-    p.win_hi = flt->win_hi;
-    p.tag = in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO;
+    p.filter_mode = filter_mode;
+    p.forward = flt ? flt->forward : 0;
+    p.win_lo = flt ? flt->win_lo : 0;
+    p.win_hi = flt ? flt->win_hi : 0;
     p.seed = rng->seed;
     p.call_id = rng->call_id;
     p.group_cap = group_cap;
@@ -479,27 +537,40 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
         return dim3((unsigned)g);
     };
     // short frontiers (the per-call operators): every prefix sum is one single-workgroup launch and nothing is memset
-    const bool short_m = p.m <= SCAN1_MAX, short_g = group_cap <= SCAN1_MAX;
+    const bool short_m = p.m <= SCAN1_MAX, short_g = group_cap <= SCAN1_GROUPS_MAX;
+    TG_REQUIRE(!c.layout_dev || (short_m && (c.weighted || short_g)),
+               "%s: a device-side layout needs a frontier bound <= %lld and a group bound <= %lld", who, (long long)SCAN1_MAX,
+               (long long)SCAN1_GROUPS_MAX);
     size_t st = temp_bytes;
-    if (short_m) {
-        hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+    if (c.weighted) {
+        int n_waves = 4;
+        while (n_waves > 1 && (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t) > 60 * 1024) n_waves >>= 1;
+        const size_t lds = (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t);
+        int64_t blocks = (p.m + n_waves - 1) / n_waves;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
     } else {
-        hipLaunchKernelGGL(hs_groups_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
-        TG_HIP(rocprim::inclusive_scan(temp, st, p.vgroups + 1, p.vgroups + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
-                                       false));
-        hipLaunchKernelGGL(hs_check_kernel, dim3(1), dim3(64), 0, stream, p);
+        if (short_m) {
+            hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL(hs_groups_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
+            TG_HIP(rocprim::inclusive_scan(temp, st, p.vgroups + 1, p.vgroups + 1, (size_t)p.m, rocprim::plus<int64_t>(),
+                                           stream, false));
+            hipLaunchKernelGGL(hs_check_kernel, dim3(1), dim3(64), 0, stream, p);
+        }
+        if (!short_g) TG_HIP(hipMemsetAsync(p.gcount, 0, 4 * (size_t)group_cap, stream)); // groups beyond the frontier's count as empty
+        hipLaunchKernelGGL(hs_count_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+        if (short_g) {
+            hipLaunchKernelGGL(hs_gscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+        } else {
+            st = temp_bytes;
+            TG_HIP(rocprim::exclusive_scan(temp, st, p.gcount, p.gpref, (int64_t)0, (size_t)group_cap,
+                                           rocprim::plus<int64_t>(), stream, false));
+        }
+        // the frontier uses fewer than group_cap groups (else status = 1), so gpref[n_groups] is inside the scanned range
+        hipLaunchKernelGGL(hs_select_kernel, grid(p.m * 64, 256), dim3(256), (size_t)4 * 3 * p.k * sizeof(uint32_t), stream,
+                           p);
     }
-    if (!short_g) TG_HIP(hipMemsetAsync(p.gcount, 0, 4 * (size_t)group_cap, stream)); // groups beyond the frontier's count as empty
-    hipLaunchKernelGGL(hs_count_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
-    if (short_g) {
-        hipLaunchKernelGGL(hs_gscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
-    } else {
-        st = temp_bytes;
-        TG_HIP(rocprim::exclusive_scan(temp, st, p.gcount, p.gpref, (int64_t)0, (size_t)group_cap, rocprim::plus<int64_t>(),
-                                       stream, false));
-    }
-    // the frontier uses fewer than group_cap groups (else status = 1), so gpref[n_groups] is inside the scanned range
-    hipLaunchKernelGGL(hs_select_kernel, grid(p.m * 64, 256), dim3(256), (size_t)4 * 3 * p.k * sizeof(uint32_t), stream, p);
     if (short_m) {
         hipLaunchKernelGGL(hs_oscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
     } else {
@@ -511,86 +582,76 @@ extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
+} // namespace tg
+
+extern "C" int tg_ns_hop_scan(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
+                              const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                              int64_t workspace_bytes, int64_t group_cap, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(csc && csc->ptrs && in && flt && rng && out && status, "tg_ns_hop_scan: null argument");
+    TG_REQUIRE(csc->timestamps, "tg_ns_hop_scan: the graph has no edge timestamps");
+    TG_REQUIRE(in->sampler == TG_SAMPLER_UNIFORM || in->sampler == TG_SAMPLER_UNIFORM_REPL,
+               "tg_ns_hop_scan: only the unweighted samplers");
+    TG_REQUIRE(flt->filter_mode >= TG_FILTER_STATIC && flt->filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_scan: bad filter");
+    TG_REQUIRE(in->m == 0 || (flt->states && states_out), "tg_ns_hop_scan: null buffers");
+    HsCall c{};
+    c.seg[0] = HsSeg{csc->ptrs, csc->indices, csc->timestamps, nullptr, 0, in->fanout, in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO};
+    c.n_seg = 1;
+    c.kmax = in->fanout;
+    c.weighted = false;
+    return hs_run("tg_ns_hop_scan", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes, group_cap,
+                  (hipStream_t)stream_);
+}
 
 extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
                                   const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
                                   int64_t workspace_bytes, void *stream_) {
     using namespace tg;
-    TG_REQUIRE(csc && csc->ptrs && csc->weights && in && rng && out && status, "tg_ns_hop_weighted: null argument");
-    TG_REQUIRE(in->m >= 0 && in->fanout >= 1 && in->fanout <= HS_MAX_FANOUT,
-               "tg_ns_hop_weighted: bad frontier size or fan-out (<= %d)", HS_MAX_FANOUT);
+    TG_REQUIRE(csc && csc->ptrs && in && rng && out && status, "tg_ns_hop_weighted: null argument");
+    TG_REQUIRE(csc->weights, "tg_ns_hop_weighted: the graph has no edge weights");
     const int filter_mode = flt ? flt->filter_mode : TG_FILTER_NONE;
     TG_REQUIRE(filter_mode >= TG_FILTER_NONE && filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_weighted: bad filter");
     TG_REQUIRE(filter_mode == TG_FILTER_NONE || (csc->timestamps && flt->states && states_out),
                "tg_ns_hop_weighted: the filter needs edge timestamps and states");
-    TG_REQUIRE(out->cnt && out->offsets, "tg_ns_hop_weighted: null outputs");
-    hipStream_t stream = (hipStream_t)stream_;
-    if (in->m == 0) {
-        TG_HIP(hipMemsetAsync(out->offsets, 0, sizeof(int64_t), stream));
-        return TG_OK;
+    HsCall c{};
+    c.seg[0] = HsSeg{csc->ptrs, csc->indices, csc->timestamps, csc->weights, 0, in->fanout, in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO};
+    c.n_seg = 1;
+    c.kmax = in->fanout;
+    c.weighted = true;
+    return hs_run("tg_ns_hop_weighted", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes, 1,
+                  (hipStream_t)stream_);
+}
+
+extern "C" int tg_ns_hop_segments(const tg_hop_segment *segments, int32_t n_segments, const tg_hop_in *in,
+                                  const int64_t *layout_dev, const tg_hop_filter *flt, const tg_rng *rng,
+                                  const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                                  int64_t workspace_bytes, int64_t group_cap, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(segments && in && rng && out && status, "tg_ns_hop_segments: null argument");
+    TG_REQUIRE(n_segments >= 1 && n_segments <= HS_MAX_SEG, "tg_ns_hop_segments: 1 .. %d segments", HS_MAX_SEG);
+    const bool weighted = in->sampler == TG_SAMPLER_WEIGHTED;
+    const int filter_mode = flt ? flt->filter_mode : TG_FILTER_NONE;
+    TG_REQUIRE(filter_mode >= TG_FILTER_NONE && filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_segments: bad filter");
+    TG_REQUIRE(weighted || filter_mode != TG_FILTER_NONE,
+               "tg_ns_hop_segments: the unweighted samplers come here under a temporal filter only");
+    TG_REQUIRE(filter_mode == TG_FILTER_NONE || in->m == 0 || (flt->states && states_out),
+               "tg_ns_hop_segments: the filter needs states");
+    HsCall c{};
+    c.n_seg = n_segments;
+    c.weighted = weighted;
+    c.layout_dev = layout_dev;
+    for (int j = 0; j < n_segments; ++j) {
+        const tg_hop_segment &g = segments[j];
+        TG_REQUIRE(g.graph && g.graph->ptrs, "tg_ns_hop_segments: segment %d has no graph", j);
+        TG_REQUIRE(g.begin >= 0 && g.begin <= in->m && (j == 0 ? g.begin == 0 : g.begin >= segments[j - 1].begin),
+                   "tg_ns_hop_segments: segment starts are ascending from 0");
+        TG_REQUIRE(g.fanout >= 1 && g.fanout <= HS_MAX_FANOUT, "tg_ns_hop_segments: bad fan-out in segment %d", j);
+        TG_REQUIRE(!weighted || g.graph->weights, "tg_ns_hop_segments: segment %d has no edge weights", j);
+        TG_REQUIRE(filter_mode == TG_FILTER_NONE || g.graph->timestamps, "tg_ns_hop_segments: segment %d has no edge timestamps", j);
+        c.seg[j] = HsSeg{g.graph->ptrs, g.graph->indices, g.graph->timestamps, g.graph->weights, g.begin, g.fanout,
+                         g.rng_tag ? g.rng_tag : TG_TAG_NS_HOMO};
+        if (g.fanout > c.kmax) c.kmax = g.fanout;
     }
-    int64_t need = 0;
-    int rc = tg_ns_hop_scan_workspace_bytes(in->m, in->fanout, 1, &need);
-    if (rc != TG_OK) return rc;
-    TG_REQUIRE(workspace && workspace_bytes >= need, "tg_ns_hop_weighted: workspace too small");
-    TG_REQUIRE(in->vertices && out->neighbors && out->edge_ptrs && out->parents, "tg_ns_hop_weighted: null buffers");
-    HopScanParams p{};
-    p.ptrs = csc->ptrs;
-    p.indices = csc->indices;
-    p.timestamps = csc->timestamps;
-    p.weights = csc->weights;
-    p.vertices = in->vertices;
-    p.states = filter_mode == TG_FILTER_NONE ? nullptr : flt->states;
-    p.ids = in->ids;
-    p.call_ids = in->call_ids;
-    p.m = in->m;
-    p.id_base = in->id_base;
-    p.k = in->fanout;
-    p.filter_mode = filter_mode;
-    p.forward = flt ? flt->forward : 0;
-    p.win_lo = flt ? flt->win_lo : 0;
-    p.win_hi = flt ? flt->win_hi : 0;
-    p.tag = in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO;
-    p.seed = rng->seed;
-    p.call_id = rng->call_id;
-    p.group_cap = 1;
-    unsigned char *base = reinterpret_cast<unsigned char *>(workspace);
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        unsigned char *q = base + off;
-        off += hs_align(bytes);
-        return q;
-    };
-    p.vgroups = reinterpret_cast<int64_t *>(take(8 * (size_t)(p.m + 1)));
-    p.gcount = reinterpret_cast<uint32_t *>(take(4));
-    p.gchunk = reinterpret_cast<uint64_t *>(take(8));
-    p.gpref = reinterpret_cast<int64_t *>(take(16));
-    p.park = reinterpret_cast<int64_t *>(take(8 * (size_t)p.m * p.k));
-    void *temp = base + off;
-    size_t temp_bytes = (size_t)workspace_bytes - off;
-    p.status = status;
-    p.cnt = out->cnt;
-    p.offsets = out->offsets;
-    p.neighbors = out->neighbors;
-    p.edge_ptrs = out->edge_ptrs;
-    p.parents = out->parents;
-    p.states_out = states_out;
-    int n_waves = 4;
-    while (n_waves > 1 && (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t) > 60 * 1024) n_waves >>= 1;
-    const size_t lds = (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t);
-    int64_t blocks = (p.m + n_waves - 1) / n_waves;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
-    if (p.m <= SCAN1_MAX) {
-        hipLaunchKernelGGL(hs_oscan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
-    } else {
-        TG_HIP(hipMemsetAsync(p.offsets, 0, 8, stream));
-        size_t st = temp_bytes;
-        TG_HIP(rocprim::inclusive_scan(temp, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream, false));
-    }
-    int64_t g = (p.m * p.k + 255) / 256;
-    if (g > 256 * 32) g = 256 * 32;
-    hipLaunchKernelGGL(hs_emit_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);
-    TG_LAUNCH_CHECK();
-    return TG_OK;
+    return hs_run("tg_ns_hop_segments", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes,
+                  weighted ? 1 : group_cap, (hipStream_t)stream_);
 }

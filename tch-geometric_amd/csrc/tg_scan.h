@@ -8,7 +8,8 @@
 namespace tg {
 
 constexpr int SCAN1_THREADS = 1024;
-constexpr int64_t SCAN1_MAX = (int64_t)1 << 17; // above this a multi-block scan is the better tool
+constexpr int64_t SCAN1_MAX = (int64_t)1 << 17;        // above this a multi-block scan is the better tool
+constexpr int64_t SCAN1_GROUPS_MAX = (int64_t)1 << 20; // bound of a scan whose real length is on the device and usually far below
 
 // out[0] = 0, out[i + 1] = out[i] + load(i) for i in [0, n): every wavefront owns a contiguous segment, sums it with
 // coalesced loads, the 16 segment totals are scanned through LDS, then the segment is swept again with a running carry.

@@ -533,8 +533,9 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         }
         for (size_t t = 0; t < T; ++t) words += (double)cap_list[t] * (has_state ? 2 : 1);
         for (int r = 0; r < R; ++r) words += (double)cap_e[(size_t)r] * 3;
-        words += (double)max_f * 5 + (double)max_out * 4;
         const bool weighted = s.kind == TG_SAMPLER_WEIGHTED;
+        // (with a filter or weights the relations of a hop share one frontier buffer: up to R times the widest one)
+        words += ((double)max_f * 5 + (double)max_out * 4) * ((weighted || has_state) ? std::max(R, 1) : 1);
         if ((weighted || has_state) && max_k > 1024)
             throw py::value_error("num_neighbors above 1024 is not supported with a temporal filter or weights");
         if (affordable && words * 8 <= 8e9 && (weighted || has_state || max_k <= 4096)) {
@@ -561,59 +562,174 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                 CL[(size_t)r] = at::empty({c}, i64(dev));
                 EI[(size_t)r] = at::empty({c}, i64(dev));
             }
-            Tensor F = at::empty({max_f}, i64(dev)), ids = at::empty({max_f}, i64(dev)), fst = at::empty({max_f}, i64(dev));
-            Tensor cnt = at::empty({max_f}, i64(dev)), offsets = at::empty({max_f + 1}, i64(dev));
-            Tensor nbr = at::empty({max_out}, i64(dev)), ep = at::empty({max_out}, i64(dev)), par = at::empty({max_out}, i64(dev));
-            Tensor st_out = at::empty({max_out}, i64(dev));
+            // filters / weights: ALL relations of a hop go through one set of launches (concatenated frontier,
+            // tg_ns_hop_segments); the plain samplers beyond the fused launch keep one flat hop per relation
+            const bool all_at_once = weighted || has_state;
+            int64_t max_m = max_f, max_o = max_out;
+            std::vector<int64_t> hop_m((size_t)H, 0), hop_groups((size_t)H, 0), hop_k((size_t)H, 1);
+            for (int h = 0; h < H && all_at_once; ++h) {
+                int64_t o = 0;
+                for (int r = 0; r < R; ++r) {
+                    const Rel &rl = rels[(size_t)r];
+                    const int64_t cf = cap_f[(size_t)h][(size_t)r];
+                    if (!rl.active || cf == 0) continue;
+                    hop_m[(size_t)h] += cf;
+                    hop_groups[(size_t)h] += rl.idx.numel() / 512;
+                    hop_k[(size_t)h] = std::max(hop_k[(size_t)h], rl.fanout[(size_t)h]);
+                    o += cf * rl.fanout[(size_t)h];
+                }
+                max_m = std::max(max_m, hop_m[(size_t)h]);
+                max_o = std::max(max_o, o);
+            }
+            Tensor F = at::empty({max_m}, i64(dev)), ids = at::empty({max_m}, i64(dev)), fst = at::empty({max_m}, i64(dev));
+            Tensor cnt = at::empty({max_m}, i64(dev)), offsets = at::empty({max_m + 1}, i64(dev));
+            Tensor nbr = at::empty({max_o}, i64(dev)), ep = at::empty({max_o}, i64(dev)), par = at::empty({max_o}, i64(dev));
+            Tensor st_out = at::empty({max_o}, i64(dev));
             Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
             Tensor meta, mh, ws;
+            Tensor layout = at::empty({TG_HOP_MAX_SEGMENTS + 1}, i64(dev));
             int32_t status_h = 0;
+            std::vector<tg_graph> graphs((size_t)std::max(R, 1));
+            for (int r = 0; r < R; ++r) {
+                const Rel &rl = rels[(size_t)r];
+                tg_graph g{};
+                if (rl.active) {
+                    g.ptrs = rl.ptrs.data_ptr<int64_t>();
+                    g.indices = rl.idx.numel() ? rl.idx.data_ptr<int64_t>() : nullptr;
+                    g.timestamps = has_state ? rl.ts.data_ptr<int64_t>() : nullptr;
+                    g.weights = weighted ? rl.w.data_ptr<double>() : nullptr;
+                    g.n_major = rl.ptrs.numel() - 1;
+                    g.n_edges = rl.idx.numel();
+                }
+                graphs[(size_t)r] = g;
+            }
+            tg_hop_filter flt{};
+            flt.filter_mode = f.mode;
+            flt.forward = f.forward ? 1 : 0;
+            flt.win_lo = f.win_lo;
+            flt.win_hi = f.win_hi;
+            flt.states = has_state ? fst.data_ptr<int64_t>() : nullptr;
+            tg_hop_out out{cnt.data_ptr<int64_t>(), offsets.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(),
+                           ep.data_ptr<int64_t>(), par.data_ptr<int64_t>()};
             for (int64_t group_mult = 1;; group_mult *= 8) { // a retry only when a column-group guess was too low
+                auto groups_of_hop = [&](int h) {
+                    return weighted ? (int64_t)1
+                                    : group_mult * std::max<int64_t>(1024, hop_groups[(size_t)h] + 2 * hop_m[(size_t)h] + 2);
+                };
                 int64_t ws_max = 0; // one workspace for every step of the call
-                for (int h = 0; h < H; ++h)
+                for (int h = 0; h < H; ++h) {
+                    if (all_at_once) {
+                        int64_t b = 0;
+                        if (hop_m[(size_t)h])
+                            check_rc(tg_ns_hop_scan_workspace_bytes(hop_m[(size_t)h], (int32_t)hop_k[(size_t)h], groups_of_hop(h), &b));
+                        ws_max = std::max(ws_max, b);
+                        continue;
+                    }
                     for (int r = 0; r < R; ++r) {
                         const Rel &rl = rels[(size_t)r];
                         const int64_t cf = cap_f[(size_t)h][(size_t)r];
                         if (!rl.active || cf == 0) continue;
                         int64_t b = 0;
-                        if (!weighted && !has_state)
-                            check_rc(tg_ns_hop_workspace_bytes(cf, &b));
-                        else
-                            check_rc(tg_ns_hop_scan_workspace_bytes(
-                                cf, (int32_t)rl.fanout[(size_t)h],
-                                weighted ? 1 : group_mult * std::max<int64_t>(1024, rl.idx.numel() / 512 + 2 * cf + 2), &b));
+                        check_rc(tg_ns_hop_workspace_bytes(cf, &b));
                         ws_max = std::max(ws_max, b);
                     }
+                }
                 ws = at::empty({ws_max / 8 + 1}, i64(dev));
                 meta = meta_init.to(dev);
                 status.zero_();
                 for (int h = 0; h < H; ++h) {
+                    if (all_at_once) {
+                        std::vector<tg_het_entry> ent;
+                        std::vector<tg_hop_segment> segs;
+                        int64_t m_round = 0, o_round = 0;
+                        bool any = false;
+                        auto flush = [&](bool last) {
+                            if (ent.empty()) return;
+                            // the frontier without its padding whenever the single-workgroup scans apply (tchgeo.h)
+                            int64_t *lay = (m_round <= ((int64_t)1 << 17) && groups_of_hop(h) <= ((int64_t)1 << 20))
+                                               ? layout.data_ptr<int64_t>()
+                                               : nullptr;
+                            check_rc(tg_het_hop_begin_all(ent.data(), (int32_t)ent.size(), meta.data_ptr<int64_t>(), (int32_t)T, R,
+                                                          H, m_round, F.data_ptr<int64_t>(),
+                                                          has_state ? fst.data_ptr<int64_t>() : nullptr, ids.data_ptr<int64_t>(),
+                                                          lay, stream_of(dev)));
+                            if (!segs.empty()) {
+                                tg_hop_in in{};
+                                in.vertices = F.data_ptr<int64_t>();
+                                in.ids = ids.data_ptr<int64_t>();
+                                in.m = m_round;
+                                in.fanout = (int32_t)hop_k[(size_t)h];
+                                in.sampler = s.kind;
+                                int64_t ws_bytes = 0;
+                                check_rc(tg_ns_hop_scan_workspace_bytes(m_round, (int32_t)hop_k[(size_t)h], groups_of_hop(h), &ws_bytes));
+                                check_rc(tg_ns_hop_segments(segs.data(), (int32_t)segs.size(), &in, lay, &flt, &rng, &out,
+                                                            st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
+                                                            ws.data_ptr<int64_t>(), ws_bytes, groups_of_hop(h), stream_of(dev)));
+                            }
+                            check_rc(tg_het_hop_end_all(ent.data(), (int32_t)ent.size(), &out,
+                                                        has_state ? st_out.data_ptr<int64_t>() : nullptr, m_round, o_round, lay,
+                                                        meta.data_ptr<int64_t>(), (int32_t)T, R, H, h, last ? 1 : 0,
+                                                        status.data_ptr<int32_t>(), stream_of(dev)));
+                            ent.clear();
+                            segs.clear();
+                            m_round = o_round = 0;
+                        };
+                        int last_active = -1;
+                        for (int r = 0; r < R; ++r)
+                            if (rels[(size_t)r].active) last_active = r;
+                        for (int r = 0; r < R; ++r) {
+                            Rel &rl = rels[(size_t)r];
+                            if (!rl.active) continue;
+                            any = true;
+                            const int64_t cf = cap_f[(size_t)h][(size_t)r];
+                            if (ent.size() == TG_HET_HOP_MAX_ENTRIES || (cf > 0 && segs.size() == TG_HOP_MAX_SEGMENTS)) flush(false);
+                            tg_het_entry e{};
+                            e.rel = r;
+                            e.src = (int32_t)rl.src;
+                            e.dst = (int32_t)rl.dst;
+                            e.segment = -1;
+                            e.list_dst = lists[rl.dst].data_ptr<int64_t>();
+                            e.state_dst = has_state ? st_lists[rl.dst].data_ptr<int64_t>() : nullptr;
+                            e.list_src = lists[rl.src].data_ptr<int64_t>();
+                            e.state_src = has_state ? st_lists[rl.src].data_ptr<int64_t>() : nullptr;
+                            e.cap_list_src = lists[rl.src].numel();
+                            e.rows = RW[(size_t)r].data_ptr<int64_t>();
+                            e.cols = CL[(size_t)r].data_ptr<int64_t>();
+                            e.edge_index = EI[(size_t)r].data_ptr<int64_t>();
+                            e.cap_edges = RW[(size_t)r].numel();
+                            if (cf > 0) {
+                                e.segment = (int32_t)segs.size();
+                                e.begin = m_round;
+                                e.cap = cf;
+                                tg_hop_segment sg{};
+                                sg.graph = &graphs[(size_t)r];
+                                sg.begin = m_round;
+                                sg.fanout = (int32_t)rl.fanout[(size_t)h];
+                                sg.rng_tag = TG_TAG_NS_HETERO | ((uint32_t)r << 8);
+                                segs.push_back(sg);
+                                m_round += cf;
+                                o_round += cf * rl.fanout[(size_t)h];
+                            }
+                            ent.push_back(e);
+                            if (r == last_active) flush(true);
+                        }
+                        if (!any) check_rc(tg_het_hop_end(meta.data_ptr<int64_t>(), (int32_t)T, R, H, stream_of(dev)));
+                        continue;
+                    }
                     for (int r = 0; r < R; ++r) {
                         Rel &rl = rels[(size_t)r];
                         const int64_t cf = cap_f[(size_t)h][(size_t)r];
                         if (!rl.active) continue;
                         if (cf == 0) { // nothing can be in the frontier; the layer offset is still recorded (:314)
-                            check_rc(tg_het_step_begin(lists[rl.dst].data_ptr<int64_t>(),
-                                                       has_state ? st_lists[rl.dst].data_ptr<int64_t>() : nullptr,
-                                                       meta.data_ptr<int64_t>(), (int32_t)T, R, H, (int32_t)rl.src,
-                                                       (int32_t)rl.dst, r, h, 1, F.data_ptr<int64_t>(),
-                                                       has_state ? fst.data_ptr<int64_t>() : nullptr, ids.data_ptr<int64_t>(),
-                                                       stream_of(dev)));
+                            check_rc(tg_het_step_begin(lists[rl.dst].data_ptr<int64_t>(), nullptr, meta.data_ptr<int64_t>(),
+                                                       (int32_t)T, R, H, (int32_t)rl.src, (int32_t)rl.dst, r, h, 1,
+                                                       F.data_ptr<int64_t>(), nullptr, ids.data_ptr<int64_t>(), stream_of(dev)));
                             continue;
                         }
                         const int64_t k = rl.fanout[(size_t)h];
-                        check_rc(tg_het_step_begin(lists[rl.dst].data_ptr<int64_t>(),
-                                                   has_state ? st_lists[rl.dst].data_ptr<int64_t>() : nullptr,
-                                                   meta.data_ptr<int64_t>(), (int32_t)T, R, H, (int32_t)rl.src, (int32_t)rl.dst, r,
-                                                   h, cf, F.data_ptr<int64_t>(), has_state ? fst.data_ptr<int64_t>() : nullptr,
-                                                   ids.data_ptr<int64_t>(), stream_of(dev)));
-                        tg_graph g{};
-                        g.ptrs = rl.ptrs.data_ptr<int64_t>();
-                        g.indices = rl.idx.numel() ? rl.idx.data_ptr<int64_t>() : nullptr;
-                        g.timestamps = has_state ? rl.ts.data_ptr<int64_t>() : nullptr;
-                        g.weights = weighted ? rl.w.data_ptr<double>() : nullptr;
-                        g.n_major = rl.ptrs.numel() - 1;
-                        g.n_edges = rl.idx.numel();
+                        check_rc(tg_het_step_begin(lists[rl.dst].data_ptr<int64_t>(), nullptr, meta.data_ptr<int64_t>(),
+                                                   (int32_t)T, R, H, (int32_t)rl.src, (int32_t)rl.dst, r, h, cf,
+                                                   F.data_ptr<int64_t>(), nullptr, ids.data_ptr<int64_t>(), stream_of(dev)));
                         tg_hop_in in{};
                         in.vertices = F.data_ptr<int64_t>();
                         in.ids = ids.data_ptr<int64_t>();
@@ -621,37 +737,14 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                         in.fanout = (int32_t)k;
                         in.sampler = s.kind;
                         in.rng_tag = TG_TAG_NS_HETERO | ((uint32_t)r << 8);
-                        tg_hop_filter flt{};
-                        flt.filter_mode = f.mode;
-                        flt.forward = f.forward ? 1 : 0;
-                        flt.win_lo = f.win_lo;
-                        flt.win_hi = f.win_hi;
-                        flt.states = has_state ? fst.data_ptr<int64_t>() : nullptr;
-                        tg_hop_out out{cnt.data_ptr<int64_t>(), offsets.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(),
-                                       ep.data_ptr<int64_t>(), par.data_ptr<int64_t>()};
                         int64_t ws_bytes = 0;
-                        if (!weighted && !has_state) {
-                            check_rc(tg_ns_hop_workspace_bytes(cf, &ws_bytes));
-                            check_rc(tg_ns_hop(&g, &in, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
-                        } else if (weighted) {
-                            check_rc(tg_ns_hop_scan_workspace_bytes(cf, (int32_t)k, 1, &ws_bytes));
-                            check_rc(tg_ns_hop_weighted(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
-                                                        status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes,
-                                                        stream_of(dev)));
-                        } else {
-                            const int64_t group_cap = group_mult * std::max<int64_t>(1024, rl.idx.numel() / 512 + 2 * cf + 2);
-                            check_rc(tg_ns_hop_scan_workspace_bytes(cf, (int32_t)k, group_cap, &ws_bytes));
-                            check_rc(tg_ns_hop_scan(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
-                                                    status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes, group_cap,
-                                                    stream_of(dev)));
-                        }
-                        check_rc(tg_het_step_end(&out, has_state ? st_out.data_ptr<int64_t>() : nullptr, cf, (int32_t)k,
-                                                 meta.data_ptr<int64_t>(), (int32_t)T, R, H, (int32_t)rl.src, r,
-                                                 lists[rl.src].data_ptr<int64_t>(),
-                                                 has_state ? st_lists[rl.src].data_ptr<int64_t>() : nullptr, lists[rl.src].numel(),
-                                                 RW[(size_t)r].data_ptr<int64_t>(), CL[(size_t)r].data_ptr<int64_t>(),
-                                                 EI[(size_t)r].data_ptr<int64_t>(), RW[(size_t)r].numel(),
-                                                 status.data_ptr<int32_t>(), stream_of(dev)));
+                        check_rc(tg_ns_hop_workspace_bytes(cf, &ws_bytes));
+                        check_rc(tg_ns_hop(&graphs[(size_t)r], &in, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
+                        check_rc(tg_het_step_end(&out, nullptr, cf, (int32_t)k, meta.data_ptr<int64_t>(), (int32_t)T, R, H,
+                                                 (int32_t)rl.src, r, lists[rl.src].data_ptr<int64_t>(), nullptr,
+                                                 lists[rl.src].numel(), RW[(size_t)r].data_ptr<int64_t>(),
+                                                 CL[(size_t)r].data_ptr<int64_t>(), EI[(size_t)r].data_ptr<int64_t>(),
+                                                 RW[(size_t)r].numel(), status.data_ptr<int32_t>(), stream_of(dev)));
                     }
                     check_rc(tg_het_hop_end(meta.data_ptr<int64_t>(), (int32_t)T, R, H, stream_of(dev)));
                 }

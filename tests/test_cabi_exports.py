@@ -123,8 +123,15 @@ def test_round2_entry_points_reject_bad_arguments(lib):
     # heterogeneous step helpers
     words = C.c_int64(0)
     assert lib.tg_het_meta_words(C.c_int32(3), C.c_int32(5), C.c_int32(2), C.byref(words)) == 0
-    assert words.value == 3 * 3 + 5 + 5 * 2 * 3 + 4
+    assert words.value == 3 * 3 + 5 + 5 * 2 * 3 + (3 + 2 * 5)   # len, fbeg, fend | ne | layer offsets | snapshots
     assert lib.tg_het_meta_words(C.c_int32(0), C.c_int32(5), C.c_int32(2), C.byref(words)) == 1
     assert lib.tg_het_step_begin(None, None, None, C.c_int32(3), C.c_int32(5), C.c_int32(2), C.c_int32(0), C.c_int32(0),
                                  C.c_int32(0), C.c_int32(0), C.c_int64(8), None, None, None, None) == 1
     assert lib.tg_het_hop_end(None, C.c_int32(3), C.c_int32(5), C.c_int32(2), None) == 1
+    # all relations of a hop at once: no entries, too many segments
+    assert lib.tg_het_hop_begin_all(None, C.c_int32(0), None, C.c_int32(3), C.c_int32(5), C.c_int32(2), C.c_int64(0), None,
+                                    None, None, None, None) == 1
+    assert lib.tg_ns_hop_segments(None, C.c_int32(9), None, None, None, None, None, None, None, None, C.c_int64(0),
+                                  C.c_int64(1), None) == 1
+    assert lib.tg_het_hop_end_all(None, C.c_int32(1), None, None, C.c_int64(0), C.c_int64(0), None, None, C.c_int32(3),
+                                  C.c_int32(5), C.c_int32(2), C.c_int32(0), C.c_int32(1), None, None) == 1
