@@ -32,13 +32,13 @@
 
 #include "tg_device.h"
 #include "tg_host.h"
+#include "tg_scan.h"
 #include "tg_map.h"
 
 namespace tg {
 
 constexpr int HGT_MAX_NB = 50; // MAX_NEIGHBORS hgt_sampling.rs:10
 constexpr int64_t HGT_NAN_TS = -1;
-constexpr int64_t SORT_PAD = INT64_MAX;
 
 // device counters of one node type
 struct HgtTypeCtr {
@@ -89,6 +89,21 @@ __global__ void scan_i64_kernel(const int64_t *__restrict__ in, const int64_t *n
 }
 
 // total of a flag array after its exclusive scan
+// exclusive scan of flag[0 .. n) into rank[0 .. n] (rank[n] = the total, also written to *total) in one launch of one
+// workgroup (tg_scan.h): the scans of a call are short and the call is bound by its number of launches
+__global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_kernel(const int64_t *__restrict__ flag, int64_t n, int64_t *rank,
+                                                                  int64_t *total) {
+    block_scan_exclusive_plus1(n, [&](int64_t i) { return flag[i]; }, rank);
+    __syncthreads();
+    if (threadIdx.x == 0) total[0] = rank[n];
+}
+__global__ void fill2_i64_kernel(int64_t *a, int64_t na, int64_t va, int64_t *b, int64_t nb, int64_t vb) {
+    const int64_t n = na > nb ? na : nb;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < na) a[i] = va;
+        if (i < nb) b[i] = vb;
+    }
+}
 __global__ void scan_total_kernel(const int64_t *__restrict__ in, const int64_t *__restrict__ excl, int64_t n,
                                   int64_t *total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) total[0] = n > 0 ? excl[n - 1] + in[n - 1] : 0;
@@ -207,22 +222,26 @@ __global__ void hgt_new_slots_kernel(HgtType src, const int64_t *mc, const int64
         }
     }
 }
-__global__ void hgt_bump_budget_kernel(HgtTypeCtr *ctr, const int64_t *n_new) { ctr->n_budget += *n_new; }
 // sort input: key = entry (padding sorts last), value = contribution position
-__global__ void hgt_sort_input_kernel(const int64_t *mc, const int64_t *__restrict__ cslot, int64_t cap,
-                                      int64_t *skey, int64_t *sval) {
+// sort keys = budget slots; padding sorts last with key `pad` = the budget's capacity, one above every slot, so the sort
+// only has to look at the bits of `pad`.  Also the budget grows by the entries hgt_new_slots_kernel just placed (that
+// kernel, the only reader of the old length in this step, has completed).
+__global__ void hgt_sort_input_kernel(const int64_t *mc, const int64_t *__restrict__ cslot, int64_t cap, int64_t pad,
+                                      int64_t *skey, int64_t *sval, HgtTypeCtr *ctr, const int64_t *n_new) {
     const int64_t n = *mc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_budget += *n_new;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
-        skey[p] = (p < n && cslot[p] >= 0) ? cslot[p] : SORT_PAD;
+        skey[p] = (p < n && cslot[p] >= 0) ? cslot[p] : pad;
         sval[p] = p;
     }
 }
 // one lane per entry run: score += 1/deg in contribution order (:96), timestamp = the last one (:97)
 __global__ void hgt_accumulate_kernel(HgtType src, const int64_t *__restrict__ skey, const int64_t *__restrict__ sval,
-                                      int64_t cap, const double *__restrict__ cinv, const int64_t *__restrict__ cts) {
+                                      int64_t cap, int64_t pad, const double *__restrict__ cinv,
+                                      const int64_t *__restrict__ cts) {
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < cap; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t entry = skey[q];
-        if (entry == SORT_PAD) continue;
+        if (entry == pad) continue;
         if (q > 0 && skey[q - 1] == entry) continue; // not the head of its run
         double score = src.bscore[entry];
         int64_t lo = q, hi = cap; // the run is [q, end): keys are sorted, so its end is found by bisection
@@ -523,7 +542,7 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     b += align16(8 * (size_t)pl.max_layer) * 2;  // ccnt, coff
     b += align16(8 * (size_t)pl.mc_cap) * 8;     // ckey, cinv, cts, cslot, skey, sval, skey2, sval2
     b += align16(8 * (size_t)pl.tmp_cap) * 2;    // tmp map
-    b += align16(8 * (size_t)pl.scan_cap) * 2;   // flag, rank
+    b += align16(8 * (size_t)(pl.scan_cap + 1)) * 2; // flag, rank
     for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
     b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T * 2;                     // chosen + slot tables, per type
     b += align16(16 * (size_t)pl.T);                                           // n_live, n_chosen per type
@@ -590,10 +609,8 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         y.bm_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.bm_cap[t]));
         y.bm_mask = pl.bm_cap[t] - 1;
         y.ctr = ctr + t;
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tl_cap[t])), dim3(256), 0, stream, y.tl_keys, pl.tl_cap[t],
-                           MAP_EMPTY);
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tl_cap[t])), dim3(256), 0, stream, y.tl_vals, pl.tl_cap[t],
-                           (int64_t)-1);
+        hipLaunchKernelGGL(fill2_i64_kernel, dim3(grid_1d(pl.tl_cap[t])), dim3(256), 0, stream, y.tl_keys, pl.tl_cap[t],
+                           MAP_EMPTY, y.tl_vals, pl.tl_cap[t], (int64_t)-1);
         hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.bm_cap[t])), dim3(256), 0, stream, y.bm_keys, pl.bm_cap[t],
                            MAP_EMPTY);
     }
@@ -610,7 +627,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     int64_t *tmp_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
     int64_t *tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
     int64_t *flag = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
-    int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
+    int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.scan_cap + 1)));
     std::vector<int64_t *> live_t((size_t)T), chosen_t((size_t)T);
     for (int t = 0; t < T; ++t) live_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
     for (int t = 0; t < T; ++t) chosen_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
@@ -623,6 +640,10 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     void *scan_temp = take(pl.scan_temp_bytes);
     // exclusive scan of flag[0..n) into rank[], total into *total (device-wide, rocPRIM)
     auto device_scan = [&](int64_t n, int64_t *total) -> int {
+        if (n <= 16384) { // one workgroup beats the library's two launches + the total only up to about here
+            hipLaunchKernelGGL(hgt_scan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, flag, n, rank, total);
+            return TG_OK;
+        }
         size_t stb = pl.scan_temp_bytes;
         TG_HIP(rocprim::exclusive_scan(scan_temp, stb, flag, rank, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), stream,
                                        false));
@@ -643,10 +664,8 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             hipLaunchKernelGGL(hgt_contrib_gen_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[nt], ty[st],
                                g.ptrs, g.indices, g.timestamps, pb->has_timerange, pb->tr_lo, pb->tr_hi, ccnt, coff,
                                pl.max_layer, ckey, cinv, cts);
-            hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tmp_cap)), dim3(256), 0, stream, tmp_keys, pl.tmp_cap,
-                               MAP_EMPTY);
-            hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.tmp_cap)), dim3(256), 0, stream, tmp_vals, pl.tmp_cap,
-                               (int64_t)INT64_MAX);
+            hipLaunchKernelGGL(fill2_i64_kernel, dim3(grid_1d(pl.tmp_cap)), dim3(256), 0, stream, tmp_keys, pl.tmp_cap,
+                               MAP_EMPTY, tmp_vals, pl.tmp_cap, (int64_t)INT64_MAX);
             hipLaunchKernelGGL(hgt_contrib_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st],
                                scal + 0, ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1);
             hipLaunchKernelGGL(hgt_first_flags_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, ckey,
@@ -654,14 +673,16 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             if (int rcs = device_scan(pl.mc_cap, scal + 1)) return rcs;
             hipLaunchKernelGGL(hgt_new_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], scal + 0,
                                ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, rank);
-            hipLaunchKernelGGL(hgt_bump_budget_kernel, dim3(1), dim3(1), 0, stream, ctr + st, scal + 1);
+            const int64_t pad = pl.cap_budget[st]; // one above every budget slot
+            unsigned bits = 1;
+            while (bits < 64 && ((int64_t)1 << bits) <= pad) ++bits;
             hipLaunchKernelGGL(hgt_sort_input_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, cslot,
-                               pl.mc_cap, skey, sval);
+                               pl.mc_cap, pad, skey, sval, ctr + st, scal + 1);
             size_t stb = pl.sort_temp_bytes;
-            TG_HIP(rocprim::radix_sort_pairs(sort_temp, stb, skey, skey2, sval, sval2, (size_t)pl.mc_cap, 0, 64, stream,
+            TG_HIP(rocprim::radix_sort_pairs(sort_temp, stb, skey, skey2, sval, sval2, (size_t)pl.mc_cap, 0, bits, stream,
                                              false)); // stable: equal entries keep contribution order
             hipLaunchKernelGGL(hgt_accumulate_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], skey2,
-                               sval2, pl.mc_cap, cinv, cts);
+                               sval2, pl.mc_cap, pad, cinv, cts);
             TG_LAUNCH_CHECK();
         }
         return TG_OK;
