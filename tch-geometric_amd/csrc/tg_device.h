@@ -112,6 +112,13 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// 32-bit counts (every hot kernel's per-chunk scan) take the DPP form; call sites are wave-uniform
+template <> __device__ __forceinline__ uint32_t wave_inclusive_scan<uint32_t>(uint32_t v) {
+    return wave_inclusive_scan_u32_dpp(v);
+}
+template <> __device__ __forceinline__ uint32_t wave_sum<uint32_t>(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan_u32_dpp(v), 63);
+}
 // orders LDS traffic between lanes of ONE wave (the lanes run in lockstep; this
 // only stops the compiler from moving accesses across the hand-off)
 __device__ __forceinline__ void wave_lds_handoff() {
