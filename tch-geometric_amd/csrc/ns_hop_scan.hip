@@ -646,8 +646,10 @@ extern "C" int tg_ns_hop_segments(const tg_hop_segment *segments, int32_t n_segm
         TG_REQUIRE(g.begin >= 0 && g.begin <= in->m && (j == 0 ? g.begin == 0 : g.begin >= segments[j - 1].begin),
                    "tg_ns_hop_segments: segment starts are ascending from 0");
         TG_REQUIRE(g.fanout >= 1 && g.fanout <= HS_MAX_FANOUT, "tg_ns_hop_segments: bad fan-out in segment %d", j);
-        TG_REQUIRE(!weighted || g.graph->weights, "tg_ns_hop_segments: segment %d has no edge weights", j);
-        TG_REQUIRE(filter_mode == TG_FILTER_NONE || g.graph->timestamps, "tg_ns_hop_segments: segment %d has no edge timestamps", j);
+        const bool no_edges = g.graph->n_edges == 0; // an empty relation: its per-edge arrays are never touched
+        TG_REQUIRE(!weighted || g.graph->weights || no_edges, "tg_ns_hop_segments: segment %d has no edge weights", j);
+        TG_REQUIRE(filter_mode == TG_FILTER_NONE || g.graph->timestamps || no_edges,
+                   "tg_ns_hop_segments: segment %d has no edge timestamps", j);
         c.seg[j] = HsSeg{g.graph->ptrs, g.graph->indices, g.graph->timestamps, g.graph->weights, g.begin, g.fanout,
                          g.rng_tag ? g.rng_tag : TG_TAG_NS_HOMO};
         if (g.fanout > c.kmax) c.kmax = g.fanout;

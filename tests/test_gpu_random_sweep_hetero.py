@@ -81,6 +81,52 @@ def test_hetero_neighbor_sampling_random(tg, case):
         assert [tuple(x) for x in lo[k]] == o[4][k], k
 
 
+@pytest.mark.parametrize("variant", ["temporal", "weighted", "weighted+temporal"])
+def test_hetero_many_relations_take_several_rounds(tg, variant):
+    """23 relations over 3 node types under a filter / with weights: a hop's relations go through the segmented flat hop
+    in rounds of <= 16 entries and <= 8 frontier segments (tchgeo.h), and the rounds must add up to the reference's
+    relation-by-relation order (oracle, bit for bit) -- list positions, layer offsets, frontier slices."""
+    rs = np.random.default_rng(9100)
+    node_types = ["a", "b", "c"]
+    counts = {"a": 150, "b": 90, "c": 40}
+    edge_types, edges = [], {}
+    for r in range(23):
+        s, d = node_types[int(rs.integers(0, 3))], node_types[int(rs.integers(0, 3))]
+        if r in (4, 17):
+            d = "c"                                            # "c" has no inputs: empty frontier in hop 0
+        et = (s, "r%d" % r, d)
+        e = 0 if r == 9 else int(rs.integers(50, 900))        # one relation without edges
+        ei = np.stack([rs.integers(0, counts[s], e), rs.integers(0, counts[d], e)]).astype(np.int64).reshape(2, e)
+        edge_types.append(et)
+        edges[et] = ei
+    P, I = {}, {}
+    for et in edge_types:
+        P[rel_key(et)], I[rel_key(et)], _ = orc.to_csc(edges[et], (counts[et[0]], counts[et[2]]))
+    rels = [rel_key(et) for et in edge_types]
+    hops = 3
+    nn = {k: [int(rs.integers(1, 6)) for _ in range(hops)] for k in rels}
+    inputs = {"a": rs.integers(0, counts["a"], 12), "b": rs.integers(0, counts["b"], 7)}
+    sampler, flt, kw = None, None, {}
+    if "weighted" in variant:
+        W = {r: rs.uniform(0.1, 4.0, len(I[r])) for r in I}
+        sampler, kw = tg.WeightedEdgeSampler(_cuda(W)), dict(sampler=orc.SAMPLER_WEIGHTED, weights=W)
+    if "temporal" in variant:
+        TS = {r: rs.integers(0, 12, len(I[r])) for r in I}
+        ST = {t: rs.integers(0, 12, len(v)) for t, v in inputs.items()}
+        flt = (tg.TemporalEdgeFilter((0, 6), _cuda(TS), True, 2), _cuda(ST))   # dynamic: the states travel too
+        kw.update(filter_mode=2, forward=True, window=(0, 6), timestamps=TS, inputs_state=ST)
+    tg.seed(77)
+    s, r, c, e, lo = tg.neighbor_sampling_heterogenous(node_types, edge_types, _cuda(P), _cuda(I), _cuda(inputs), nn, hops,
+                                                       sampler, flt)
+    o = orc.ns_hetero(node_types, edge_types, P, I, inputs, nn, hops, orc.rng_philox(77, 0), **kw)
+    assert sum(len(o[1][k]) for k in rels) > 500 and sum(1 for k in rels if len(o[1][k])) > 16
+    _eq_dicts(s, o[0], node_types, "samples")
+    for name, got, want in (("rows", r, o[1]), ("cols", c, o[2]), ("edge_index", e, o[3])):
+        _eq_dicts(got, want, rels, name)
+    for k in rels:
+        assert [tuple(x) for x in lo[k]] == o[4][k], k
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_hgt_and_budget_random(tg, case):
     rs = np.random.default_rng(4000 + case)
