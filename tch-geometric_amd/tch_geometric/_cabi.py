@@ -70,6 +70,10 @@ class TgHopOut(C.Structure):
                 ("parents", C.c_void_p)]
 
 
+class TgHopSegment(C.Structure):
+    _fields_ = [("graph", C.c_void_p), ("begin", C.c_int64), ("fanout", C.c_int32), ("rng_tag", C.c_uint32)]
+
+
 class TgHopFilter(C.Structure):
     _fields_ = [("filter_mode", C.c_int32), ("forward", C.c_int32), ("win_lo", C.c_int64), ("win_hi", C.c_int64),
                 ("states", C.c_void_p)]
@@ -404,6 +408,42 @@ def ns_hop(graph, vertices, fanout, seed, call_id=0, sampler=SAMPLER_UNIFORM, id
     check(lib.tg_ns_hop(C.byref(graph), C.byref(hin), C.byref(rng), C.byref(hout), ptr(ws), C.c_int64(nbytes.value),
                         stream_ptr(dev)))
     return cnt[:m], offsets, nbr, ep, par
+
+
+def ns_hop_segments(segments, vertices, states, seed, filter_mode=FILTER_NONE, window=(0, 0), forward=False, call_id=0,
+                    sampler=SAMPLER_UNIFORM, ids=None, call_ids=None, id_base=0, layout=None, group_cap=None):
+    """One flat hop over a frontier made of segments (tg_ns_hop_segments).  segments: list of (graph view, begin,
+    fanout, rng_tag); layout: optional device tensor [len(segments) + 1] = real segment starts, then the real length.
+    -> (cnt[m], offsets[m+1], neighbors, edge_ptrs, parents, states_out, status) -- no host synchronisation."""
+    m, dev = vertices.numel(), vertices.device
+    o = dict(dtype=torch.int64, device=dev)
+    kmax = max(f for _, _, f, _ in segments)
+    if group_cap is None:
+        group_cap = max(1024, sum(g.n_edges for g, _, _, _ in segments) // 512 + 2 * m + 2)
+    cnt, offsets = torch.empty(max(m, 1), **o), torch.empty(m + 1, **o)
+    nbr, ep, par, st_out = (torch.empty(max(m * kmax, 1), **o) for _ in range(4))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    segs = (TgHopSegment * len(segments))()
+    for j, (g, begin, fanout, tag) in enumerate(segments):
+        segs[j].graph, segs[j].begin, segs[j].fanout, segs[j].rng_tag = C.addressof(g), begin, fanout, tag
+    hin, hout, flt = TgHopIn(), TgHopOut(), TgHopFilter()
+    hin.vertices = vertices.data_ptr() if m else None
+    hin.ids = ids.data_ptr() if ids is not None else None
+    hin.call_ids = call_ids.data_ptr() if call_ids is not None else None
+    hin.m, hin.id_base, hin.fanout, hin.sampler, hin.rng_tag = m, id_base, kmax, sampler, 0
+    hout.cnt, hout.offsets = cnt.data_ptr(), offsets.data_ptr()
+    hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+    flt.filter_mode, flt.forward = filter_mode, int(bool(forward))
+    flt.win_lo, flt.win_hi = window
+    flt.states = states.data_ptr() if (m and states is not None) else None
+    nbytes = C.c_int64(0)
+    check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(kmax), C.c_int64(group_cap), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, **o)
+    rng = TgRng(seed, call_id)
+    check(lib.tg_ns_hop_segments(segs, C.c_int32(len(segments)), C.byref(hin), ptr(layout) if layout is not None else None,
+                                 C.byref(flt), C.byref(rng), C.byref(hout), ptr(st_out), ptr(status), ptr(ws),
+                                 C.c_int64(nbytes.value), C.c_int64(group_cap), stream_ptr(dev)))
+    return cnt[:m], offsets, nbr, ep, par, st_out, status
 
 
 def ns_hop_scan(graph, vertices, states, fanout, seed, filter_mode, window, forward=False, call_id=0,

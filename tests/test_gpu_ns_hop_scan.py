@@ -67,3 +67,93 @@ def test_per_vertex_ids_empty_slots_and_overflow():
     # a workspace that cannot hold the frontier's groups reports it instead of sampling
     cnt, off, nbr, ep, par, st_out, status = cabi.ns_hop_scan(g, t(verts), t(st), 6, 3, 1, (0, 40), group_cap=8)
     assert int(status) == 1 and int(off[m]) == 0
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_segmented_hop_equals_one_hop_per_segment(weighted, packed):
+    """tg_ns_hop_segments over a frontier of three segments (two graphs, different fan-outs and draw tags) == the
+    single-graph hop run once per segment, concatenated; with the host-side (padded) layout and with a device-side
+    layout that packs the segments' real frontiers back to back."""
+    dev = torch.device("cuda:0")
+    cabi, ptrs, idx, ts, g, n = _setup(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = np.random.default_rng(5)
+    w_a = rs.uniform(0.1, 3.0, len(idx))
+    ga = cabi.graph_view(t(ptrs), t(idx), t(w_a), t(ts))
+    n2 = 1 << 11                                              # a second, smaller graph: ids of the frontier stay below n2
+    row, col = orc.rmat_edges(11, n2 * 8, 0x77)
+    p2, i2, _ = orc.to_csc(np.stack([row, col]), n2)
+    ts2, w2 = rs.integers(0, 100, len(i2)), rs.uniform(0.1, 3.0, len(i2))
+    gb = cabi.graph_view(t(p2), t(i2), t(w2), t(ts2))
+    caps, real, fans, tags = [300, 200, 260], [300, 120, 0], [7, 12, 4], [0x11, 0x2200 | 0x11, 0x3300 | 0x11]
+    graphs = [ga, gb, ga]
+    sampler = 2 if weighted else 0
+    mode, window = (1, (0, 40))
+    # per segment: vertices, states, draw ids; segment 2's real frontier is empty
+    verts = [rs.integers(0, n2, c) for c in caps]
+    states = [rs.integers(20, 80, c) for c in caps]
+    idsv = [rs.integers(0, 1 << 30, c) for c in caps]
+    if packed:      # real frontiers back to back; what follows them is never read
+        begins = np.concatenate([[0], np.cumsum(real)])
+        tail = np.zeros(sum(caps) - sum(real), np.int64)
+        V, S, IDS = (np.concatenate([a[:r] for a, r in zip(arrs, real)] + [tail]) for arrs in (verts, states, idsv))
+        layout = t(begins.astype(np.int64))
+    else:           # every segment padded to its capacity with -1
+        begins = np.concatenate([[0], np.cumsum(caps)])
+        padded = []
+        for v, r in zip(verts, real):
+            v = v.copy()
+            v[r:] = -1
+            padded.append(v)
+        V, S, IDS = np.concatenate(padded), np.concatenate(states), np.concatenate(idsv)
+        layout = None
+    host_begins = np.concatenate([[0], np.cumsum(caps)])
+    segs = [(graphs[j], int(host_begins[j]), fans[j], tags[j]) for j in range(3)]
+    cnt, off, nbr, ep, par, st_out, status = cabi.ns_hop_segments(segs, t(V), t(S), 5, filter_mode=mode, window=window,
+                                                                  call_id=9, sampler=sampler, ids=t(IDS), layout=layout)
+    assert int(status) == 0
+    m_eff = int(begins[-1])
+    off_h = off.cpu().numpy()
+    for j in range(3):
+        r = real[j]
+        if r == 0:
+            continue
+        if weighted:
+            c1, o1, n1, e1, p1, s1, st1 = _one(cabi, graphs[j], t(verts[j][:r]), t(states[j][:r]), fans[j], mode, window,
+                                               t(idsv[j][:r]), tags[j], weighted=True)
+        else:
+            c1, o1, n1, e1, p1, s1, st1 = cabi.ns_hop_scan(graphs[j], t(verts[j][:r]), t(states[j][:r]), fans[j], 5, mode,
+                                                           window, call_id=9, ids=t(idsv[j][:r]), rng_tag=tags[j])
+        assert int(st1) == 0
+        tot = int(o1[r])
+        b = int(begins[j])
+        lo, hi = int(off_h[b]), int(off_h[b + r])
+        assert hi - lo == tot and tot > 0, j
+        assert torch.equal(cnt[b:b + r], c1[:r])
+        assert torch.equal(nbr[lo:hi], n1[:tot]) and torch.equal(ep[lo:hi], e1[:tot]), j
+        assert torch.equal(par[lo:hi] - b, p1[:tot]) and torch.equal(st_out[lo:hi], s1[:tot]), j
+    assert int(off_h[m_eff]) == int(off_h[int(begins[2])])      # the empty third segment adds nothing
+
+
+def _one(cabi, graph, verts, states, k, mode, window, ids, tag, weighted):
+    """tg_ns_hop_weighted for one segment (the wrapper of the unweighted hop is cabi.ns_hop_scan)"""
+    import ctypes as C
+    m, dev = verts.numel(), verts.device
+    o = dict(dtype=torch.int64, device=dev)
+    cnt, offsets = torch.empty(m, **o), torch.empty(m + 1, **o)
+    nbr, ep, par, st_out = (torch.empty(m * k, **o) for _ in range(4))
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hin, hout, flt = cabi.TgHopIn(), cabi.TgHopOut(), cabi.TgHopFilter()
+    hin.vertices, hin.ids, hin.m, hin.fanout, hin.sampler, hin.rng_tag = verts.data_ptr(), ids.data_ptr(), m, k, 2, tag
+    hout.cnt, hout.offsets = cnt.data_ptr(), offsets.data_ptr()
+    hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+    flt.filter_mode, flt.forward, flt.win_lo, flt.win_hi, flt.states = mode, 0, window[0], window[1], states.data_ptr()
+    nbytes = C.c_int64(0)
+    cabi.check(cabi.lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(k), C.c_int64(1), C.byref(nbytes)))
+    ws = torch.empty(nbytes.value // 8 + 1, **o)
+    rng = cabi.TgRng(5, 9)
+    cabi.check(cabi.lib.tg_ns_hop_weighted(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
+                                           cabi.ptr(st_out), cabi.ptr(status), cabi.ptr(ws), C.c_int64(nbytes.value),
+                                           cabi.stream_ptr(dev)))
+    return cnt, offsets, nbr, ep, par, st_out, status
