@@ -544,6 +544,11 @@ TG_API int tg_coo_to_csx(const int64_t *row, const int64_t *col, int64_t nnz, in
  * outside [lo, hi).  The samplers index `ptrs` with their inputs and do NOT check them (the reference panics on an
  * out-of-range node id; a device kernel would fault). */
 TG_API int tg_check_range(const int64_t *values, int64_t n, int64_t lo, int64_t hi, int32_t *flag, void *stream);
+/* The same check without a read-back before the sampler runs: out[i] = values[i] if it lies in [lo, hi) else lo (a valid
+ * id, so the sampler cannot fault), flag[0] |= 1 (device int64 word, zeroed by the caller -- e.g. the last word of the
+ * array the host reads back anyway when the call ends) if any did not.  The host raises after that one read-back. */
+TG_API int tg_sanitize_range(const int64_t *values, int64_t n, int64_t lo, int64_t hi, int64_t *out, int64_t *flag,
+                             void *stream);
 
 /* ind2ptr (src/data/storage.rs:67-101) on the device: sorted `ind` [numel] -> out [m+1]. */
 TG_API int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t *out, void *stream);

@@ -67,6 +67,19 @@ __global__ void check_range_kernel(const int64_t *__restrict__ v, int64_t n, int
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// out[i] = v[i] when it lies in [lo, hi), else lo; flag[0] |= 1 if any did not
+__global__ void sanitize_range_kernel(const int64_t *__restrict__ v, int64_t n, int64_t lo, int64_t hi, int64_t *out,
+                                      int64_t *flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = v[i];
+        const bool b = (x < lo) | (x >= hi);
+        out[i] = b ? lo : x;
+        bad |= b;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<unsigned long long *>(flag), 1ull);
+}
+
 static inline unsigned grid_for(int64_t n, int threads) {
     int64_t g = (n + threads - 1) / threads;
     if (g < 1) g = 1;
@@ -112,6 +125,16 @@ extern "C" int tg_ind2ptr(const int64_t *ind, int64_t numel, int64_t m, int64_t 
     TG_REQUIRE(numel >= 0 && m >= 0 && out && (ind || numel == 0), "tg_ind2ptr: bad arguments");
     hipLaunchKernelGGL(tg::ind2ptr_kernel, dim3(tg::grid_for(m + 1, 256)), dim3(256), 0, (hipStream_t)stream, ind,
                        numel, m, out);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_sanitize_range(const int64_t *values, int64_t n, int64_t lo, int64_t hi, int64_t *out, int64_t *flag,
+                                 void *stream) {
+    TG_REQUIRE(n >= 0 && flag && lo < hi && ((values && out) || n == 0), "tg_sanitize_range: bad arguments (empty range?)");
+    if (n == 0) return TG_OK;
+    hipLaunchKernelGGL(tg::sanitize_range_kernel, dim3(tg::grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, values, n,
+                       lo, hi, out, flag);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -122,6 +122,25 @@ struct RangeCheck {
     }
 };
 
+// The same validation WITHOUT its own read-back, for the per-call fast paths (a blocking copy costs as much as the
+// sampling kernel there): the ids are copied with out-of-range ones replaced by 0, `flag` (a device int64 word that
+// travels in the call's final read-back) records that it happened, and the caller raises after that read-back.
+inline Tensor sanitized_ids(const Tensor &values, int64_t hi, int64_t *flag, const c10::Device &dev, const char *what) {
+    if (values.numel() == 0) return values;
+    if (hi <= 0)
+        throw py::index_error(std::string(what) + ": a node id is outside the graph (the reference panics with an index "
+                                                  "out of bounds here)");
+    Tensor out = at::empty_like(values);
+    check_rc(tg_sanitize_range(values.data_ptr<int64_t>(), values.numel(), 0, hi, out.data_ptr<int64_t>(), flag,
+                               stream_of(dev)));
+    return out;
+}
+inline void raise_if_flagged(int64_t flag, const char *what) {
+    if (flag != 0)
+        throw py::index_error(std::string(what) + ": a node id is outside the graph (the reference panics with an index "
+                                                  "out of bounds here)");
+}
+
 // The values of an adjacency's `indices` become `ptrs[w]` look-ups one hop later (neighbor_sampling.rs:197-198,
 // random_walk.rs:41), where the reference panics on an id beyond the table and an unchecked kernel would read out of
 // bounds.  One pass over `indices` per graph, remembered by (address, length, bound) so that calls on a resident

@@ -90,12 +90,137 @@ struct NsResult {
     std::vector<std::tuple<int64_t, int64_t, int64_t>> layer_offsets;
     int64_t n_samples = 0, n_edges = 0;
 };
+// The same operator with NO read-back between hops: sample list, frontier slice and edge count stay on the device
+// (csrc/het_steps.hip with one node type and one relation: tg_het_hop_begin_all packs the frontier, tg_ns_hop_segments
+// samples it with the homogeneous draw tag, tg_het_hop_end_all appends), one array read when the call ends.  Worst-case
+// buffers, so only for calls whose fan-out product stays small; `unchecked_seeds` as in run_ns.
+bool run_ns_filtered_device(NsResult &r, const c10::Device &dev, const tg_graph &g, const Tensor &seeds,
+                            const Tensor &seeds_state, const std::vector<int64_t> &fanout, const SamplerArg &s,
+                            const FilterArg &f, const tg_rng &rng, uint32_t tag, const char *unchecked_seeds) {
+    const int64_t n_seeds = seeds.numel();
+    const bool weighted = s.kind == TG_SAMPLER_WEIGHTED, filtered = f.mode != TG_FILTER_NONE;
+    const int H = (int)fanout.size();
+    if (H < 1 || H > TG_MAX_HOPS || n_seeds == 0) return false;
+    std::vector<int64_t> cap_f((size_t)H);
+    int64_t cap_list = n_seeds, cap_e = 0, fr = n_seeds, max_m = 1, max_o = 1, max_k = 1;
+    for (int h = 0; h < H; ++h) {
+        const int64_t k = fanout[(size_t)h];
+        if (k > 1024 || fr > ((int64_t)1 << 17) || fr * k > ((int64_t)1 << 22)) return false;
+        cap_f[(size_t)h] = fr;
+        max_m = std::max(max_m, fr);
+        max_o = std::max(max_o, fr * k);
+        max_k = std::max(max_k, k);
+        fr *= k;
+        cap_list += fr;
+        cap_e += fr;
+    }
+    int64_t meta_words = 0;
+    check_rc(tg_het_meta_words(1, 1, H, &meta_words));
+    Tensor meta_init = at::zeros({meta_words}, at::TensorOptions().dtype(at::kLong));
+    meta_init.data_ptr<int64_t>()[0] = n_seeds; // len
+    meta_init.data_ptr<int64_t>()[2] = n_seeds; // fend (fbeg = 0)
+    // lengths and layer offsets | status | "a seed was out of range": what the call reads back when it ends
+    Tensor flags = at::zeros({2}, i64(dev));
+    Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+    const Tensor seeds_ok =
+        unchecked_seeds ? sanitized_ids(seeds, g.n_major, flags.data_ptr<int64_t>() + 1, dev, unchecked_seeds) : seeds;
+    Tensor list = at::empty({cap_list}, i64(dev)), st_list;
+    list.narrow(0, 0, n_seeds).copy_(seeds_ok);
+    if (filtered) {
+        st_list = at::empty({cap_list}, i64(dev));
+        st_list.narrow(0, 0, n_seeds).copy_(seeds_state);
+    }
+    Tensor RW = at::empty({std::max<int64_t>(cap_e, 1)}, i64(dev)), CL = at::empty_like(RW), EI = at::empty_like(RW);
+    Tensor F = at::empty({max_m}, i64(dev)), ids = at::empty({max_m}, i64(dev)), fst = at::empty({max_m}, i64(dev));
+    Tensor cnt = at::empty({max_m}, i64(dev)), offsets = at::empty({max_m + 1}, i64(dev));
+    Tensor nbr = at::empty({max_o}, i64(dev)), ep = at::empty({max_o}, i64(dev)), par = at::empty({max_o}, i64(dev));
+    Tensor st_out = at::empty({max_o}, i64(dev));
+    Tensor layout = at::empty({2}, i64(dev));
+    tg_hop_filter flt{};
+    flt.filter_mode = f.mode;
+    flt.forward = f.forward ? 1 : 0;
+    flt.win_lo = f.win_lo;
+    flt.win_hi = f.win_hi;
+    flt.states = filtered ? fst.data_ptr<int64_t>() : nullptr;
+    tg_hop_out out{cnt.data_ptr<int64_t>(), offsets.data_ptr<int64_t>(), nbr.data_ptr<int64_t>(), ep.data_ptr<int64_t>(),
+                   par.data_ptr<int64_t>()};
+    Tensor mh;
+    int64_t status_h = 0;
+    for (int64_t group_mult = 1;; group_mult *= 8) { // a retry only when the column-group guess was too low
+        auto groups = [&](int h) {
+            return weighted ? (int64_t)1 : group_mult * std::max<int64_t>(1024, g.n_edges / 512 + 2 * cap_f[(size_t)h] + 2);
+        };
+        int64_t ws_max = 0;
+        for (int h = 0; h < H; ++h) {
+            int64_t b = 0;
+            check_rc(tg_ns_hop_scan_workspace_bytes(cap_f[(size_t)h], (int32_t)fanout[(size_t)h], groups(h), &b));
+            ws_max = std::max(ws_max, b);
+        }
+        Tensor ws = at::empty({ws_max / 8 + 1}, i64(dev));
+        Tensor meta = meta_init.to(dev);
+        status.zero_();
+        for (int h = 0; h < H; ++h) {
+            tg_het_entry e{};
+            e.segment = 0;
+            e.cap = cap_f[(size_t)h];
+            e.list_dst = e.list_src = list.data_ptr<int64_t>();
+            e.state_dst = e.state_src = filtered ? st_list.data_ptr<int64_t>() : nullptr;
+            e.cap_list_src = cap_list;
+            e.rows = RW.data_ptr<int64_t>();
+            e.cols = CL.data_ptr<int64_t>();
+            e.edge_index = EI.data_ptr<int64_t>();
+            e.cap_edges = RW.numel();
+            int64_t *lay = groups(h) <= ((int64_t)1 << 20) ? layout.data_ptr<int64_t>() : nullptr;
+            check_rc(tg_het_hop_begin_all(&e, 1, meta.data_ptr<int64_t>(), 1, 1, H, e.cap, F.data_ptr<int64_t>(),
+                                          filtered ? fst.data_ptr<int64_t>() : nullptr, ids.data_ptr<int64_t>(), lay,
+                                          stream_of(dev)));
+            tg_hop_segment sg{};
+            sg.graph = &g;
+            sg.fanout = (int32_t)fanout[(size_t)h];
+            sg.rng_tag = tag;
+            tg_hop_in in{};
+            in.vertices = F.data_ptr<int64_t>();
+            in.ids = ids.data_ptr<int64_t>();
+            in.m = e.cap;
+            in.fanout = sg.fanout;
+            in.sampler = s.kind;
+            int64_t ws_bytes = 0;
+            check_rc(tg_ns_hop_scan_workspace_bytes(e.cap, sg.fanout, groups(h), &ws_bytes));
+            check_rc(tg_ns_hop_segments(&sg, 1, &in, lay, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
+                                        status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes, groups(h),
+                                        stream_of(dev)));
+            check_rc(tg_het_hop_end_all(&e, 1, &out, filtered ? st_out.data_ptr<int64_t>() : nullptr, e.cap,
+                                        e.cap * sg.fanout, lay, meta.data_ptr<int64_t>(), 1, 1, H, h, 1,
+                                        status.data_ptr<int32_t>(), stream_of(dev)));
+        }
+        mh = to_host(at::cat({meta, status.to(at::kLong), flags})); // the call's only synchronisation
+        status_h = mh.data_ptr<int64_t>()[meta_words];
+        if (unchecked_seeds) raise_if_flagged(mh.data_ptr<int64_t>()[meta_words + 2], unchecked_seeds);
+        if ((status_h & 1) && group_mult < 4096) continue;
+        break;
+    }
+    if (status_h & 1) throw std::runtime_error("neighbor sampling: column-group workspace overflow");
+    if (status_h & 2) // sampling.rs:49: gen_range over an empty float range panics in the reference
+        throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+    if (status_h & 4) throw std::runtime_error("neighbor sampling: internal capacity error");
+    const int64_t *m = mh.data_ptr<int64_t>();
+    r.n_samples = m[0];
+    r.n_edges = m[3];
+    r.samples = list;
+    if (filtered) r.states = st_list;
+    r.rows = RW;
+    r.cols = CL;
+    r.edge_index = EI;
+    for (int h = 0; h < H; ++h) r.layer_offsets.emplace_back(m[4 + 3 * h], m[4 + 3 * h + 1], m[4 + 3 * h + 2]);
+    return true;
+}
+
 // Uniform samplers under a temporal filter: hop by hop through tg_ns_hop_scan, which spreads the column scans
 // over the whole device (the one-workgroup-per-batch kernel needs many batches in one launch to do that).
 NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const Tensor &indices, const Tensor &weights,
                               const Tensor &timestamps, const Tensor &seeds, const Tensor &seeds_state,
                               const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f,
-                              const tg_rng &rng, uint32_t tag, int64_t id_base) {
+                              const tg_rng &rng, uint32_t tag, int64_t id_base, const char *unchecked_seeds = nullptr) {
     NsResult r;
     const int64_t n_seeds = seeds.numel();
     const bool weighted = s.kind == TG_SAMPLER_WEIGHTED, filtered = f.mode != TG_FILTER_NONE;
@@ -106,6 +231,14 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
     g.weights = weighted ? weights.data_ptr<double>() : nullptr;
     g.n_major = ptrs.numel() - 1;
     g.n_edges = indices.numel();
+    if ((weighted || filtered) && id_base == 0 &&
+        run_ns_filtered_device(r, dev, g, seeds, seeds_state, fanout, s, f, rng, tag, unchecked_seeds))
+        return r;
+    if (unchecked_seeds) {
+        RangeCheck rc(dev);
+        rc.add(seeds, ptrs.numel() - 1);
+        rc.verify(unchecked_seeds);
+    }
     std::vector<Tensor> samples{seeds}, states, rows, cols, eidx;
     if (filtered) states.push_back(seeds_state);
     Tensor frontier = seeds, fstate = seeds_state;
@@ -189,15 +322,18 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
 NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indices, const Tensor &weights,
                 const Tensor &timestamps, const Tensor &seeds, const Tensor &seeds_state,
                 const std::vector<int64_t> &fanout, const SamplerArg &s, const FilterArg &f, const tg_rng &rng,
-                uint32_t tag, int64_t id_base) {
+                uint32_t tag, int64_t id_base, const char *unchecked_seeds = nullptr) {
+    // unchecked_seeds: the seeds have not been range-checked yet (the string names the operator in the error); the
+    // one-launch path checks them without a read-back of its own (host_common.h sanitized_ids)
     // whole-device flat hops: always for filters / weights (column scans), and for the plain samplers when ONE call
     // brings more seeds than a workgroup should walk alone (the batched kernel gives a batch one workgroup) or a
     // fan-out above 128 (the batched kernel keeps its ticket strips in LDS; tg_ns_hop takes up to 4096)
     int64_t max_k = 1;
     for (int64_t k : fanout) max_k = std::max(max_k, k);
-    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || seeds.numel() > 2048 || max_k > 128)
+    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || seeds.numel() > 2048 || max_k > 128) {
         return run_ns_filtered_flat(dev, ptrs, indices, weights, timestamps, seeds, seeds_state, fanout, s, f, rng, tag,
-                                    id_base);
+                                    id_base, unchecked_seeds);
+    }
     const int32_t H = (int32_t)fanout.size();
     int64_t cap_nodes = 0, cap_edges = 0;
     check_rc(tg_ns_homo_capacity(seeds.numel(), fanout.data(), H, &cap_nodes, &cap_edges));
@@ -206,8 +342,12 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
     r.rows = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
     r.cols = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
     r.edge_index = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
-    Tensor lo = at::zeros({std::max<int32_t>(H, 1) * 3}, i64(dev));
-    Tensor counts = at::zeros({2}, i64(dev));
+    // layer offsets | counts | "a seed was out of range": ONE array, one read-back when the call ends
+    const int64_t lo_words = (int64_t)std::max<int32_t>(H, 1) * 3;
+    Tensor tail = at::zeros({lo_words + 3}, i64(dev));
+    int64_t *tail_p = tail.data_ptr<int64_t>();
+    const Tensor seeds_ok =
+        unchecked_seeds ? sanitized_ids(seeds, ptrs.numel() - 1, tail_p + lo_words + 2, dev, unchecked_seeds) : seeds;
     if (f.mode != TG_FILTER_NONE) r.states = at::empty({std::max<int64_t>(cap_nodes, 1)}, i64(dev));
 
     tg_graph g{};
@@ -231,21 +371,21 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
     out.rows = r.rows.data_ptr<int64_t>();
     out.cols = r.cols.data_ptr<int64_t>();
     out.edge_index = r.edge_index.data_ptr<int64_t>();
-    out.layer_offsets = lo.data_ptr<int64_t>();
-    out.counts = counts.data_ptr<int64_t>();
+    out.layer_offsets = tail_p;
+    out.counts = tail_p + lo_words;
     out.states = r.states.defined() ? r.states.data_ptr<int64_t>() : nullptr;
     out.cap_nodes = r.samples.numel();
     out.cap_edges = r.rows.numel();
-    check_rc(tg_ns_homo_batched(&g, seeds.numel() ? seeds.data_ptr<int64_t>() : nullptr, 1, seeds.numel(),
+    check_rc(tg_ns_homo_batched(&g, seeds_ok.numel() ? seeds_ok.data_ptr<int64_t>() : nullptr, 1, seeds_ok.numel(),
                                 fanout.data(), H, &cfg, &rng, &out, stream_of(dev)));
-    Tensor c = to_host(counts), l = to_host(lo); // the only synchronisation of the call
-    r.n_samples = c[0].item<int64_t>();
-    r.n_edges = c[1].item<int64_t>();
+    Tensor th = to_host(tail); // the only synchronisation of the call
+    const int64_t *l = th.data_ptr<int64_t>();
+    if (unchecked_seeds) raise_if_flagged(l[lo_words + 2], unchecked_seeds);
+    r.n_samples = l[lo_words];
+    r.n_edges = l[lo_words + 1];
     if (r.n_samples < 0) // sampling.rs:49: gen_range over an empty float range panics in the reference
         throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
-    for (int h = 0; h < H; ++h)
-        r.layer_offsets.emplace_back(l[3 * h].item<int64_t>(), l[3 * h + 1].item<int64_t>(),
-                                     l[3 * h + 2].item<int64_t>());
+    for (int h = 0; h < H; ++h) r.layer_offsets.emplace_back(l[3 * h], l[3 * h + 1], l[3 * h + 2]);
     return r;
 }
 
@@ -309,11 +449,9 @@ py::tuple neighbor_sampling_homogenous(const Tensor &col_ptrs, const Tensor &row
         st = on(as_homogeneous(f.state), dev, at::kLong).reshape({-1});
         if (st.numel() != seeds.numel()) throw py::value_error("filter state must have one entry per input");
     }
-    RangeCheck rc(dev);
-    rc.add(seeds, ptrs.numel() - 1);
-    rc.verify("neighbor_sampling_homogenous inputs");
     if (num_neighbors.size() > 1) check_graph_ids(idx, ptrs.numel() - 1, dev, "neighbor_sampling_homogenous row_indices");
-    NsResult r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0);
+    NsResult r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0,
+                        "neighbor_sampling_homogenous inputs");
     const c10::Device out_dev = inputs.device();
     return py::make_tuple(back(r.samples.narrow(0, 0, r.n_samples), out_dev),
                           back(r.rows.narrow(0, 0, r.n_edges), out_dev), back(r.cols.narrow(0, 0, r.n_edges), out_dev),
@@ -399,17 +537,6 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         if (has_state) st_chunks[t].push_back(frontier_st[t]);
         len[t] = frontier[t].numel();
     }
-    {
-        RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
-        for (const Rel &r : rels) rc.add(frontier[r.dst], r.ptrs.numel() - 1);
-        rc.verify("neighbor_sampling_heterogenous inputs");
-        if (num_hops > 1) // samples of relation a (src type s) are the next hop's frontier of every relation into s
-            for (const Rel &a : rels)
-                for (const Rel &b : rels)
-                    if (b.dst == a.src)
-                        check_graph_ids(a.idx, b.ptrs.numel() - 1, dev, "neighbor_sampling_heterogenous row_indices");
-    }
-
     // ---- default samplers without a filter: all hops and relations in ONE launch (tg_ns_hetero_batched), one read-back
     bool fused = !has_state && s.kind != TG_SAMPLER_WEIGHTED && T <= TG_HET_MAX_TYPES && rels.size() <= TG_HET_MAX_RELS &&
                  num_hops >= 0 && num_hops <= TG_MAX_HOPS;
@@ -418,6 +545,18 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
     int64_t total_inputs = 0; // the fused kernel gives the call ONE workgroup: large calls go hop by hop over the device
     for (size_t t = 0; t < T; ++t) total_inputs += frontier[t].numel();
     fused = fused && total_inputs <= 4096;
+    {
+        if (!fused) { // (the fused launch checks its inputs without a read-back of its own, below)
+            RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
+            for (const Rel &r : rels) rc.add(frontier[r.dst], r.ptrs.numel() - 1);
+            rc.verify("neighbor_sampling_heterogenous inputs");
+        }
+        if (num_hops > 1) // samples of relation a (src type s) are the next hop's frontier of every relation into s
+            for (const Rel &a : rels)
+                for (const Rel &b : rels)
+                    if (b.dst == a.src)
+                        check_graph_ids(a.idx, b.ptrs.numel() - 1, dev, "neighbor_sampling_heterogenous row_indices");
+    }
     if (fused) {
         const int R = (int)rels.size(), H = (int)num_hops;
         std::vector<int32_t> rel_src((size_t)std::max(R, 1)), rel_dst((size_t)std::max(R, 1));
@@ -435,9 +574,19 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
             graphs[(size_t)r] = g;
             for (int h = 0; h < H && rels[(size_t)r].active; ++h) fan[(size_t)(r * H + h)] = rels[(size_t)r].fanout[(size_t)h];
         }
+        // counts | layer offsets | "an input was out of range" in one tensor: one read-back for the call
+        const int64_t meta_words = (int64_t)T + R + (int64_t)std::max(R * H, 1) * 3;
+        Tensor meta = at::zeros({meta_words + 1}, i64(dev));
+        std::vector<Tensor> checked(T);
         for (size_t t = 0; t < T; ++t) {
             n_in[t] = frontier[t].numel();
-            in_ptr[t] = n_in[t] ? frontier[t].data_ptr<int64_t>() : nullptr;
+            int64_t bound = -1; // an input of type t indexes the columns of every relation whose dst is t
+            for (const Rel &rl : rels)
+                if (rl.dst == t) bound = bound < 0 ? rl.ptrs.numel() - 1 : std::min<int64_t>(bound, rl.ptrs.numel() - 1);
+            checked[t] = bound < 0 ? frontier[t]
+                                   : sanitized_ids(frontier[t], bound, meta.data_ptr<int64_t>() + meta_words, dev,
+                                                   "neighbor_sampling_heterogenous inputs");
+            in_ptr[t] = n_in[t] ? checked[t].data_ptr<int64_t>() : nullptr;
         }
         tg_het_problem pb{};
         pb.n_types = (int32_t)T;
@@ -466,8 +615,6 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
             c_ptr[(size_t)r] = CL[(size_t)r].data_ptr<int64_t>();
             e_ptr[(size_t)r] = EI[(size_t)r].data_ptr<int64_t>();
         }
-        // counts | layer offsets in one tensor: one read-back for the call
-        Tensor meta = at::zeros({(int64_t)T + R + (int64_t)std::max(R * H, 1) * 3}, i64(dev));
         tg_het_out out{};
         out.samples = s_ptr.data();
         out.cap_nodes = cap_n.data();
@@ -480,6 +627,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         check_rc(tg_ns_hetero_batched(&pb, 1, &rng, &out, stream_of(dev)));
         Tensor m = to_host(meta); // the call's only synchronisation
         const int64_t *mh = m.data_ptr<int64_t>();
+        raise_if_flagged(mh[meta_words], "neighbor_sampling_heterogenous inputs");
         py::dict samples, rows, cols, eidx, los;
         for (size_t t = 0; t < T; ++t) samples[py::str(node_types[t])] = back(S[t].narrow(0, 0, mh[t]), out_dev);
         for (int r = 0; r < R; ++r) {
