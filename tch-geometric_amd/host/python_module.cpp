@@ -545,12 +545,20 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
     int64_t total_inputs = 0; // the fused kernel gives the call ONE workgroup: large calls go hop by hop over the device
     for (size_t t = 0; t < T; ++t) total_inputs += frontier[t].numel();
     fused = fused && total_inputs <= 4096;
+    // an input of type t indexes the columns of every relation whose dst is t.  The one-launch form and the
+    // device-driven steps check without a read-back of their own (sanitized_ids); the host-driven loop checks first.
+    auto input_bound = [&](size_t t) {
+        int64_t bound = -1;
+        for (const Rel &rl : rels)
+            if (rl.dst == t) bound = bound < 0 ? rl.ptrs.numel() - 1 : std::min<int64_t>(bound, rl.ptrs.numel() - 1);
+        return bound;
+    };
+    auto verify_inputs_now = [&]() {
+        RangeCheck rc(dev);
+        for (const Rel &r : rels) rc.add(frontier[r.dst], r.ptrs.numel() - 1);
+        rc.verify("neighbor_sampling_heterogenous inputs");
+    };
     {
-        if (!fused) { // (the fused launch checks its inputs without a read-back of its own, below)
-            RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
-            for (const Rel &r : rels) rc.add(frontier[r.dst], r.ptrs.numel() - 1);
-            rc.verify("neighbor_sampling_heterogenous inputs");
-        }
         if (num_hops > 1) // samples of relation a (src type s) are the next hop's frontier of every relation into s
             for (const Rel &a : rels)
                 for (const Rel &b : rels)
@@ -580,9 +588,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         std::vector<Tensor> checked(T);
         for (size_t t = 0; t < T; ++t) {
             n_in[t] = frontier[t].numel();
-            int64_t bound = -1; // an input of type t indexes the columns of every relation whose dst is t
-            for (const Rel &rl : rels)
-                if (rl.dst == t) bound = bound < 0 ? rl.ptrs.numel() - 1 : std::min<int64_t>(bound, rl.ptrs.numel() - 1);
+            const int64_t bound = input_bound(t);
             checked[t] = bound < 0 ? frontier[t]
                                    : sanitized_ids(frontier[t], bound, meta.data_ptr<int64_t>() + meta_words, dev,
                                                    "neighbor_sampling_heterogenous inputs");
@@ -696,9 +702,15 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                 mi[2 * T + t] = frontier[t].numel();  // fend (fbeg = 0)
             }
             std::vector<Tensor> lists(T), st_lists(T), RW((size_t)R), CL((size_t)R), EI((size_t)R);
+            Tensor id_flag = at::zeros({1}, i64(dev)); // "an input was out of range": read back with the lengths
             for (size_t t = 0; t < T; ++t) {
                 lists[t] = at::empty({std::max<int64_t>(cap_list[t], 1)}, i64(dev));
-                if (frontier[t].numel()) lists[t].narrow(0, 0, frontier[t].numel()).copy_(frontier[t]);
+                const int64_t bound = input_bound(t);
+                if (frontier[t].numel())
+                    lists[t].narrow(0, 0, frontier[t].numel())
+                        .copy_(bound < 0 ? frontier[t]
+                                         : sanitized_ids(frontier[t], bound, id_flag.data_ptr<int64_t>(), dev,
+                                                         "neighbor_sampling_heterogenous inputs"));
                 if (has_state) {
                     st_lists[t] = at::empty({std::max<int64_t>(cap_list[t], 1)}, i64(dev));
                     if (frontier_st[t].numel()) st_lists[t].narrow(0, 0, frontier_st[t].numel()).copy_(frontier_st[t]);
@@ -897,8 +909,9 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                     check_rc(tg_het_hop_end(meta.data_ptr<int64_t>(), (int32_t)T, R, H, stream_of(dev)));
                 }
                 // the call's only synchronisation: lengths, layer offsets and the status word in one array
-                Tensor both = at::cat({meta, status.to(at::kLong)});
+                Tensor both = at::cat({meta, status.to(at::kLong), id_flag});
                 mh = to_host(both);
+                raise_if_flagged(mh.data_ptr<int64_t>()[meta_words + 1], "neighbor_sampling_heterogenous inputs");
                 status_h = (int32_t)mh.data_ptr<int64_t>()[meta_words];
                 if ((status_h & 1) && group_mult < 4096) continue;
                 break;
@@ -927,6 +940,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         }
     }
 
+    verify_inputs_now();
     for (int64_t ell = 0; ell < num_hops; ++ell) { // :292
         for (size_t t = 0; t < T; ++t) {
             new_chunks[t].clear();

@@ -185,6 +185,19 @@ def test_out_of_range_node_ids_raise_instead_of_faulting(tg):
     k = "a__to__a"
     with pytest.raises(IndexError):
         tg.neighbor_sampling_heterogenous(["a"], [et], {k: P}, {k: I}, {"a": bad}, {k: [2]}, 1)
+    # the filtered / weighted forms validate on the device and raise with the call's final read-back
+    ts, w = torch.tensor([5, 5]).cuda(), torch.tensor([1.0, 2.0], dtype=torch.float64).cuda()
+    flt = lambda st: (tg.TemporalEdgeFilter((0, 9), ts, False, tg.TEMPORAL_SAMPLE_STATIC), st)
+    with pytest.raises(IndexError, match="outside the graph"):
+        tg.neighbor_sampling_homogenous(P, I, bad, [2, 2], None, flt(torch.zeros(2, dtype=torch.int64).cuda()))
+    with pytest.raises(IndexError):
+        tg.neighbor_sampling_homogenous(P, I, bad, [2], tg.WeightedEdgeSampler(w))
+    with pytest.raises(IndexError, match="outside the graph"):
+        tg.neighbor_sampling_heterogenous(["a"], [et], {k: P}, {k: I}, {"a": bad}, {k: [2]}, 1, None,
+                                          (tg.TemporalEdgeFilter((0, 9), {k: ts}, False, tg.TEMPORAL_SAMPLE_STATIC),
+                                           {"a": torch.zeros(2, dtype=torch.int64).cuda()}))
+    with pytest.raises(IndexError):
+        tg.neighbor_sampling_heterogenous(["a"], [et], {k: P}, {k: I}, {"a": bad}, {k: [2]}, 1, tg.WeightedEdgeSampler({k: w}))
     with pytest.raises(IndexError):
         tg.hgt_sampling(["a"], [et], {k: P}, {k: I}, None, {"a": bad}, None, {"a": [2]}, 1)
     with pytest.raises(IndexError):
