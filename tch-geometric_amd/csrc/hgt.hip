@@ -187,30 +187,47 @@ __global__ void hgt_contrib_slots_kernel(HgtType src, const int64_t *mc, const i
         }
     }
 }
+// flags "p is the first contribution of a new key", kept per 64-position chunk: cmask[c] = the chunk's flags as a bit
+// mask, flag[c] = their number.  A scan over the few hundred chunk counts (one launch of one workgroup) then ranks any
+// position: rank(q) = prefix[q / 64] + popcount(cmask[q / 64] below bit q % 64).
 __global__ void hgt_first_flags_kernel(const int64_t *mc, const int64_t *__restrict__ ckey,
                                        const int64_t *__restrict__ cslot, const int64_t *tmp_keys,
-                                       const int64_t *tmp_vals, int64_t tmp_mask, int64_t cap, int64_t *flag) {
+                                       const int64_t *tmp_vals, int64_t tmp_mask, int64_t cap, int64_t *flag,
+                                       uint64_t *cmask) {
     const int64_t n = *mc;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
-        int64_t f = 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (cap + 63) >> 6;
+    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks;
+         c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t p = (c << 6) + lane;
+        bool f = false;
         if (p < n && cslot[p] == -1) {
             const int64_t t = map_slot_find(tmp_keys, tmp_mask, ckey[p]);
             f = (tmp_vals[t] == p);
         }
-        flag[p] = f;
+        const uint64_t m = __ballot(f);
+        if (lane == 0) {
+            cmask[c] = m;
+            flag[c] = __popcll(m);
+        }
     }
+}
+__device__ __forceinline__ int64_t hgt_chunk_rank(const int64_t *__restrict__ chunk_prefix, const uint64_t *__restrict__ cmask,
+                                                  int64_t q) {
+    const uint64_t below = (q & 63) ? (cmask[q >> 6] & (~0ull >> (64 - (q & 63)))) : 0ull;
+    return chunk_prefix[q >> 6] + __popcll(below);
 }
 // new keys get entries n_budget + rank(first contribution); the entry order is the reference's insertion order
 __global__ void hgt_new_slots_kernel(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
                                      int64_t *cslot, const int64_t *tmp_keys, const int64_t *tmp_vals,
-                                     int64_t tmp_mask, const int64_t *__restrict__ rank) {
+                                     int64_t tmp_mask, const int64_t *__restrict__ rank, const uint64_t *__restrict__ cmask) {
     const int64_t n = *mc, nb = src.ctr->n_budget;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         if (cslot[p] != -1) continue;
         const int64_t v = ckey[p];
         const int64_t t = map_slot_find(tmp_keys, tmp_mask, v);
         const int64_t first = tmp_vals[t];
-        const int64_t entry = nb + rank[first];
+        const int64_t entry = nb + hgt_chunk_rank(rank, cmask, first);
         cslot[p] = entry;
         if (first == p) { // :95 entry(v).or_default()
             src.bkey[entry] = v;
@@ -268,16 +285,25 @@ __global__ void hgt_accumulate_kernel(HgtType src, const int64_t *__restrict__ s
 }
 
 // ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
-__global__ void hgt_live_flags_kernel(HgtType ty, int64_t cap, int64_t *flag) {
+__global__ void hgt_live_flags_kernel(HgtType ty, int64_t cap, int64_t *flag, uint64_t *cmask) { // per chunk, as above
     const int64_t n = ty.ctr->n_budget;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x)
-        flag[i] = (i < n) ? ty.balive[i] : 0;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (cap + 63) >> 6;
+    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks;
+         c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t i = (c << 6) + lane;
+        const uint64_t m = __ballot(i < n && ty.balive[i] != 0);
+        if (lane == 0) {
+            cmask[c] = m;
+            flag[c] = __popcll(m);
+        }
+    }
 }
-__global__ void hgt_live_list_kernel(HgtType ty, const int64_t *__restrict__ flag, const int64_t *__restrict__ rank,
+__global__ void hgt_live_list_kernel(HgtType ty, const uint64_t *__restrict__ cmask, const int64_t *__restrict__ rank,
                                      int64_t *live) {
     const int64_t n = ty.ctr->n_budget;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        if (flag[i]) live[rank[i]] = i;
+        if ((cmask[i >> 6] >> (i & 63)) & 1ull) live[hgt_chunk_rank(rank, cmask, i)] = i;
 }
 constexpr int64_t HGT_LDS_SLOTS = 8192; // samples per layer whose slot tables fit 64 KB of LDS
 // one wavefront: the reference's weighted reservoir over the live entries, weights score^2 (:110)
@@ -404,7 +430,8 @@ __global__ void hgt_empty_layer_kernel(HgtTypeCtr *ctr) { // a type without a bu
 // ballots over the lanes' displaced entries, then all slots gather and look up `to_local` in parallel.
 __global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
                                            const int64_t *__restrict__ indices, int64_t cap_nodes, uint64_t seed,
-                                           uint64_t call_id, uint32_t tag, int64_t *cand_j, int64_t *cand_ep) {
+                                           uint64_t call_id, uint32_t tag, int64_t *cand_j, int64_t *cand_ep,
+                                           int64_t *kept) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int64_t n_nodes = dst.ctr->n_nodes;
     const CallKey ck = call_key(seed, call_id, tag);
@@ -412,6 +439,7 @@ __global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64
         int64_t *cj = cand_j + i * HGT_MAX_NB, *ce = cand_ep + i * HGT_MAX_NB;
         if (i >= n_nodes) {
             if (lane < HGT_MAX_NB) cj[lane] = -1;
+            if (lane == 0) kept[i] = 0;
             continue;
         }
         const int64_t w = dst.nodes[i];
@@ -439,32 +467,37 @@ __global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64
             }
             pos = mypos;
         }
+        int64_t j = -1, ep = -1;
+        if (lane < k) {
+            ep = b + pos;
+            const int64_t v = indices[ep];
+            const int64_t h = map_slot_find(src.tl_keys, src.tl_mask, v); // :263
+            if (h >= 0) j = src.tl_vals[h];
+        }
         if (lane < HGT_MAX_NB) {
-            int64_t j = -1, ep = -1;
-            if (lane < k) {
-                ep = b + pos;
-                const int64_t v = indices[ep];
-                const int64_t h = map_slot_find(src.tl_keys, src.tl_mask, v); // :263
-                if (h >= 0) j = src.tl_vals[h];
-            }
             cj[lane] = j;
             ce[lane] = ep;
         }
+        const uint64_t m = __ballot(j >= 0);
+        if (lane == 0) kept[i] = __popcll(m); // edges of this destination node; their scan places them (:264 order)
     }
 }
-__global__ void hgt_edge_flags_kernel(const int64_t *__restrict__ cand_j, int64_t n, int64_t *flag) {
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x)
-        flag[q] = cand_j[q] >= 0;
-}
+// one wavefront per destination node: its kept candidates, in slot order, from off[i] on
 __global__ void hgt_edge_emit_kernel(const int64_t *__restrict__ cand_j, const int64_t *__restrict__ cand_ep,
-                                     const int64_t *__restrict__ rank, int64_t n, int64_t *rows, int64_t *cols,
+                                     const int64_t *__restrict__ off, int64_t n_nodes_cap, int64_t *rows, int64_t *cols,
                                      int64_t *eidx) {
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
-        if (cand_j[q] < 0) continue;
-        const int64_t e = rank[q];
-        rows[e] = cand_j[q];        // :264 j
-        cols[e] = q / HGT_MAX_NB;   //      i
-        eidx[e] = cand_ep[q];       //      edge_ptr
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int64_t i = (int64_t)blockIdx.x * n_waves + wave; i < n_nodes_cap; i += (int64_t)gridDim.x * n_waves) {
+        const int64_t q = i * HGT_MAX_NB + lane;
+        const int64_t j = (lane < HGT_MAX_NB) ? cand_j[q] : -1;
+        const uint64_t m = __ballot(j >= 0);
+        if (j >= 0) {
+            const int64_t e = off[i] + __popcll(m & lt_mask);
+            rows[e] = j;           // :264 j
+            cols[e] = i;           //      i
+            eidx[e] = cand_ep[q];  //      edge_ptr
+        }
     }
 }
 __global__ void hgt_copy_counts_kernel(const HgtTypeCtr *ctr, int n_types, int64_t *n_samples) {
@@ -543,6 +576,7 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     b += align16(8 * (size_t)pl.mc_cap) * 8;     // ckey, cinv, cts, cslot, skey, sval, skey2, sval2
     b += align16(8 * (size_t)pl.tmp_cap) * 2;    // tmp map
     b += align16(8 * (size_t)(pl.scan_cap + 1)) * 2; // flag, rank
+    b += align16(8 * (size_t)(pl.scan_cap / 64 + 2)); // chunk masks
     for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
     b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T * 2;                     // chosen + slot tables, per type
     b += align16(16 * (size_t)pl.T);                                           // n_live, n_chosen per type
@@ -628,6 +662,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     int64_t *tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
     int64_t *flag = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
     int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.scan_cap + 1)));
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(take(8 * (size_t)(pl.scan_cap / 64 + 2)));
     std::vector<int64_t *> live_t((size_t)T), chosen_t((size_t)T);
     for (int t = 0; t < T; ++t) live_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
     for (int t = 0; t < T; ++t) chosen_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
@@ -669,10 +704,10 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             hipLaunchKernelGGL(hgt_contrib_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st],
                                scal + 0, ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1);
             hipLaunchKernelGGL(hgt_first_flags_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, ckey,
-                               cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, pl.mc_cap, flag);
-            if (int rcs = device_scan(pl.mc_cap, scal + 1)) return rcs;
+                               cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, pl.mc_cap, flag, cmask);
+            if (int rcs = device_scan((pl.mc_cap + 63) / 64, scal + 1)) return rcs; // over the chunks' counts
             hipLaunchKernelGGL(hgt_new_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], scal + 0,
-                               ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, rank);
+                               ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, rank, cmask);
             const int64_t pad = pl.cap_budget[st]; // one above every budget slot
             unsigned bits = 1;
             while (bits < 64 && ((int64_t)1 << bits) <= pad) ++bits;
@@ -709,9 +744,9 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         for (int t = 0; t < T; ++t) { // :201 every type that owns a budget samples from it: first the live lists
             const int64_t k = pb->num_samples[(size_t)t * H + layer];
             hipLaunchKernelGGL(hgt_live_flags_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t],
-                               pl.cap_budget[t], flag);
-            if (int rcs = device_scan(pl.cap_budget[t], n_live_t + t)) return rcs;
-            hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], flag,
+                               pl.cap_budget[t], flag, cmask);
+            if (int rcs = device_scan((pl.cap_budget[t] + 63) / 64, n_live_t + t)) return rcs; // over the chunks' counts
+            hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], cmask,
                                rank, live_t[(size_t)t]);
             const size_t lds = (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 8 : 8;
             if (lds > lds_max) lds_max = lds;
@@ -753,14 +788,12 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         const int st = pb->rel_src[r], dt = pb->rel_dst[r];
         const tg_graph &g = pb->graphs[r];
         const int64_t cap_n = pl.cap_nodes[dt] > 0 ? pl.cap_nodes[dt] : 1;
-        const int64_t nq = cap_n * HGT_MAX_NB;
         hipLaunchKernelGGL(hgt_edge_candidates_kernel, dim3(grid_1d(cap_n * 64)), dim3(256), 0, stream, ty[dt], ty[st],
                            g.ptrs, g.indices, cap_n, rng->seed, rng->call_id, TAG_HGT | ((uint32_t)(r + 1) << 8), cand_j,
-                           cand_ep);
-        hipLaunchKernelGGL(hgt_edge_flags_kernel, dim3(grid_1d(nq)), dim3(256), 0, stream, cand_j, nq, flag);
-        if (int rcs = device_scan(nq, out->n_edges + r)) return rcs;
-        hipLaunchKernelGGL(hgt_edge_emit_kernel, dim3(grid_1d(nq)), dim3(256), 0, stream, cand_j, cand_ep, rank, nq,
-                           out->rows[r], out->cols[r], out->edge_index[r]);
+                           cand_ep, flag);
+        if (int rcs = device_scan(cap_n, out->n_edges + r)) return rcs; // over the nodes' kept-edge counts
+        hipLaunchKernelGGL(hgt_edge_emit_kernel, dim3(grid_1d(cap_n * 64)), dim3(256), 0, stream, cand_j, cand_ep, rank,
+                           cap_n, out->rows[r], out->cols[r], out->edge_index[r]);
         TG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(hgt_copy_counts_kernel, dim3(1), dim3(1024), 0, stream, ctr, T, out->n_samples);
