@@ -40,12 +40,14 @@ def main():
         objs.append(o)
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DTORCH_EXTENSION_NAME=tch_geometric",
                "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+               # c10's HIP layer (current stream, device guard) -- host-side headers only, nothing is compiled for the GPU
+               "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-isystem", "/opt/rocm/include",
                "-Wno-attributes"] + inc + ["-c", s, "-o", o]
         procs.append(subprocess.Popen(cmd))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("host compile failed")
-    link = ["g++", "-shared", "-o", OUT] + objs + ["-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python",
+    link = ["g++", "-shared", "-o", OUT] + objs + ["-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python",
                                                     "-L" + LIBDIR, "-ltchgeo_hip",
                                                     "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + tlib]
     subprocess.check_call(link)

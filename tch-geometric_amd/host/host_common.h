@@ -3,6 +3,10 @@
 #pragma once
 #include <torch/extension.h>
 
+#include <c10/hip/HIPFunctions.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
 #include <mutex>
 #include <random>
 #include <sstream>
@@ -65,26 +69,21 @@ inline void check_rc(int rc) {
 }
 
 // ---------------------------------------------------------------- devices and streams
+// (c10's HIP layer directly: no Python call per launch, and nothing here needs the GIL)
 inline c10::Device compute_device(std::initializer_list<const Tensor *> ts) {
     for (const Tensor *t : ts)
         if (t && t->defined() && t->is_cuda()) return t->device();
-    py::object cuda = py::module_::import("torch").attr("cuda");
-    if (!cuda.attr("is_available")().cast<bool>())
+    if (c10::hip::device_count() <= 0)
         throw std::runtime_error("tch_geometric (MI355X backend): no HIP device is visible and this build has no CPU "
                                  "path");
-    return c10::Device(c10::kCUDA, (c10::DeviceIndex)cuda.attr("current_device")().cast<int>());
+    return c10::Device(c10::kCUDA, c10::hip::current_device());
 }
-inline void *stream_of(const c10::Device &dev) {
-    py::object s = py::module_::import("torch").attr("cuda").attr("current_stream")(py::int_((int)dev.index()));
-    return reinterpret_cast<void *>(s.attr("cuda_stream").cast<uintptr_t>());
+inline void *stream_of(const c10::Device &dev) { // the calling thread's current stream on `dev` (torch.cuda.stream(...))
+    return reinterpret_cast<void *>(c10::hip::getCurrentHIPStream(dev.index()).stream());
 }
 struct DeviceGuard { // run the call with `dev` current (kernels launch on the current device)
-    py::object ctx;
-    explicit DeviceGuard(const c10::Device &dev) {
-        ctx = py::module_::import("torch").attr("cuda").attr("device")(py::int_((int)dev.index()));
-        ctx.attr("__enter__")();
-    }
-    ~DeviceGuard() { ctx.attr("__exit__")(py::none(), py::none(), py::none()); }
+    c10::hip::HIPGuard guard;
+    explicit DeviceGuard(const c10::Device &dev) : guard(dev.index()) {}
 };
 inline Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
     check_kind(t, want);
@@ -95,12 +94,22 @@ inline at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions(
 
 // Blocking read-backs run WITHOUT the GIL (libtorch does not need it), so DataLoader-style worker threads, each on its
 // own HIP stream, overlap their latency-bound calls.  The reference holds the GIL throughout (SURVEY 8(b) Threading).
+struct ReleaseGilIfHeld { // an operator body may already run without the GIL (NoGil below)
+    PyThreadState *state = nullptr;
+    ReleaseGilIfHeld() {
+        if (PyGILState_Check()) state = PyEval_SaveThread();
+    }
+    ~ReleaseGilIfHeld() {
+        if (state) PyEval_RestoreThread(state);
+    }
+};
+using NoGil = ReleaseGilIfHeld; // scope guard for the part of an operator between argument parsing and result building
 template <typename T> inline T read_scalar(const Tensor &t) {
-    py::gil_scoped_release nogil;
+    ReleaseGilIfHeld nogil;
     return t.item<T>();
 }
 inline Tensor to_host(const Tensor &t) {
-    py::gil_scoped_release nogil;
+    ReleaseGilIfHeld nogil;
     return t.cpu();
 }
 

@@ -17,6 +17,8 @@
 // entropy that Python cannot reseed (utils/random.rs:8-22).  Here the global
 // state is (seed, call counter); `seed(s)` (additive to the surface) makes
 // results reproducible, and equal to the CPU oracle's philox-mode.
+#include <optional>
+
 #include "host_common.h"
 
 using namespace tghost;
@@ -449,9 +451,14 @@ py::tuple neighbor_sampling_homogenous(const Tensor &col_ptrs, const Tensor &row
         st = on(as_homogeneous(f.state), dev, at::kLong).reshape({-1});
         if (st.numel() != seeds.numel()) throw py::value_error("filter state must have one entry per input");
     }
-    if (num_neighbors.size() > 1) check_graph_ids(idx, ptrs.numel() - 1, dev, "neighbor_sampling_homogenous row_indices");
-    NsResult r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0,
-                        "neighbor_sampling_homogenous inputs");
+    NsResult r;
+    { // nothing in here touches Python: worker threads (each on its own HIP stream) overlap their calls
+        NoGil nogil;
+        if (num_neighbors.size() > 1)
+            check_graph_ids(idx, ptrs.numel() - 1, dev, "neighbor_sampling_homogenous row_indices");
+        r = run_ns(dev, ptrs, idx, w, ts, seeds, st, num_neighbors, s, f, next_rng(), 0, 0,
+                   "neighbor_sampling_homogenous inputs");
+    }
     const c10::Device out_dev = inputs.device();
     return py::make_tuple(back(r.samples.narrow(0, 0, r.n_samples), out_dev),
                           back(r.rows.narrow(0, 0, r.n_edges), out_dev), back(r.cols.narrow(0, 0, r.n_edges), out_dev),
@@ -566,6 +573,8 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                         check_graph_ids(a.idx, b.ptrs.numel() - 1, dev, "neighbor_sampling_heterogenous row_indices");
     }
     if (fused) {
+        std::optional<NoGil> nogil; // no Python between here and the result dicts
+        nogil.emplace();
         const int R = (int)rels.size(), H = (int)num_hops;
         std::vector<int32_t> rel_src((size_t)std::max(R, 1)), rel_dst((size_t)std::max(R, 1));
         std::vector<tg_graph> graphs((size_t)std::max(R, 1));
@@ -633,6 +642,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         check_rc(tg_ns_hetero_batched(&pb, 1, &rng, &out, stream_of(dev)));
         Tensor m = to_host(meta); // the call's only synchronisation
         const int64_t *mh = m.data_ptr<int64_t>();
+        nogil.reset();
         raise_if_flagged(mh[meta_words], "neighbor_sampling_heterogenous inputs");
         py::dict samples, rows, cols, eidx, los;
         for (size_t t = 0; t < T; ++t) samples[py::str(node_types[t])] = back(S[t].narrow(0, 0, mh[t]), out_dev);
@@ -693,6 +703,8 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         if ((weighted || has_state) && max_k > 1024)
             throw py::value_error("num_neighbors above 1024 is not supported with a temporal filter or weights");
         if (affordable && words * 8 <= 8e9 && (weighted || has_state || max_k <= 4096)) {
+            std::optional<NoGil> nogil; // no Python between here and the result dicts
+            nogil.emplace();
             int64_t meta_words = 0;
             check_rc(tg_het_meta_words((int32_t)T, R, H, &meta_words));
             Tensor meta_init = at::zeros({meta_words}, at::TensorOptions().dtype(at::kLong));
@@ -916,6 +928,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                 if ((status_h & 1) && group_mult < 4096) continue;
                 break;
             }
+            nogil.reset();
             if (status_h & 1) throw std::runtime_error("neighbor_sampling_heterogenous: column-group workspace overflow");
             if (status_h & 2) // sampling.rs:49: gen_range over an empty float range panics in the reference
                 throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");

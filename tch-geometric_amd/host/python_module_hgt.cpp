@@ -1,4 +1,6 @@
 // Third translation unit of the host module: hgt_sampling (python.rs:399-482).
+#include <optional>
+
 #include "host_common.h"
 
 using namespace tghost;
@@ -85,6 +87,13 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
             }
         }
     }
+    std::pair<int64_t, int64_t> tr{0, 0};
+    const bool has_tr = !timerange.is_none();
+    if (has_tr) tr = timerange.cast<std::pair<int64_t, int64_t>>();
+    // ---- from here to the result dicts nothing touches Python: the GIL is released, so worker threads (each on its own
+    // HIP stream) overlap their calls
+    std::optional<NoGil> nogil;
+    nogil.emplace();
     {
         RangeCheck rc(dev); // an input of type t indexes the columns of every relation whose dst is t
         for (int r = 0; r < R; ++r)
@@ -102,8 +111,7 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
     pb.input_ts = has_its ? its_ptr.data() : nullptr;
     pb.n_inputs = n_in.data();
     pb.num_samples = ns.data();
-    if (!timerange.is_none()) {
-        auto tr = timerange.cast<std::pair<int64_t, int64_t>>();
+    if (has_tr) {
         pb.has_timerange = 1;
         pb.tr_lo = tr.first;
         pb.tr_hi = tr.second;
@@ -146,6 +154,7 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
     const tg_rng rng = next_rng();
     check_rc(tg_hgt_sample(&pb, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
     Tensor c = to_host(counts); // the call's only synchronisation
+    nogil.reset();
     if ((c[T + R].item<int64_t>() & 0xffffffff) != 0)
         throw std::runtime_error("hgt_sampling: num_samples has no entry for a node type that owns a budget, or a "
                                  "weight sum was not positive (the reference panics here)");
