@@ -101,6 +101,26 @@ def main():
     if args.mode == "partitioned":
         return partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanout)
 
+    form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
+
+    def alloc_slabs(G):  # 16 384 batches per launch need ~100 GB of slabs + workspace: on a GPU with less free HBM, halve
+        while True:
+            try:
+                out = _cabi.NsBatchedOut(G, B, fanout, dev)
+                ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
+                return out, ws, G
+            except torch.OutOfMemoryError:
+                out = ws = None
+                torch.cuda.empty_cache()
+                if G <= 256:
+                    raise
+                G //= 2
+
+    # the big arenas first, while the device's memory is still one piece (TG_BENCH_SLABS_FIRST=0: after the graph build)
+    slabs_first = os.environ.get("TG_BENCH_SLABS_FIRST", "1") == "1"
+    if slabs_first:
+        out, ws, G = alloc_slabs(G)
+
     # ---- graph: R-MAT edges -> CSC with the reference's sort key (storage.rs:118-123); resident in HBM
     t_build = time.time()
     row, col = _cabi.rmat_edges(args.scale, n_edges, 0x5EED0000 + args.scale, dev)
@@ -113,6 +133,8 @@ def main():
     idx32 = indices.to(torch.int32) if args.idx32 and n_nodes <= 2 ** 32 else None
     ptr32 = ptrs.to(torch.int32) if args.ptr32 and n_edges < 2 ** 32 else None
     graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32)
+    if not slabs_first:
+        out, ws, G = alloc_slabs(G)
 
     # ---- this rank's mini-batches: global batch ids [rank*(W+K)*G, (rank+1)*(W+K)*G); step i samples G of them with
     # call ids first + i*G ...  Seeds of up to 32 steps are kept resident (268 MB each); longer runs cycle through them
@@ -120,19 +142,6 @@ def main():
     first, _ = sharding.rank_batch_range(rank, world, (W + K) * G)
     n_pool = max(1, min(W + K, 32))
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
-    form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
-    while True:  # 16 384 batches per launch need ~100 GB of slabs + workspace: on a GPU with less free HBM, halve
-        try:
-            out = _cabi.NsBatchedOut(G, B, fanout, dev)
-            ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
-            break
-        except torch.OutOfMemoryError:
-            out = ws = None
-            torch.cuda.empty_cache()
-            if G <= 256:
-                raise
-            G //= 2
-            seeds = seeds[:n_pool * G].contiguous()
     acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled edges, frontier slots, launches
 
     def run(lo, hi, events=None):
