@@ -152,6 +152,58 @@ def test_cfg4_hgt_sampling(cabi, cfg4):
         assert np.array_equal(e[k].cpu().numpy(), o[4][k]), k
 
 
+@pytest.mark.parametrize("variant", ["temporal-dynamic", "weighted"])
+def test_cfg4_hetero_under_filter_and_weights(cabi, cfg4, variant):
+    """neighbor_sampling_heterogenous at cfg4 under a temporal filter (neighbor_sampling.rs:36-77, dynamic mode: the
+    sample's timestamp becomes its state) and with the weighted sampler (sampling.rs:28-55), through the operator
+    surface: all relations of a hop go through one segmented flat hop (hub columns of 10^4..10^5 edges included).
+    Window / membership properties on every relation, and the whole call replayed by the oracle."""
+    import tch_geometric as tg
+    dev, P, I = cfg4
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    seeds = cabi.seed_batches(0xBA7C4, 7000, 1, 1024, 1 << SCALES["A"], dev)[0].contiguous()
+    nn = {rel_key(et): [15, 10] for et in EDGE_TYPES}
+    sampler, flt, kw = None, None, {}
+    if variant == "weighted":
+        W = {k: torch.rand(I[k].numel(), device=dev, generator=g, dtype=torch.float64) + 0.1 for k in P}
+        sampler = tg.WeightedEdgeSampler(W)
+        kw = dict(sampler=orc.SAMPLER_WEIGHTED, weights={k: v.cpu().numpy() for k, v in W.items()})
+    else:
+        TS = {k: torch.randint(0, 100, (I[k].numel(),), device=dev, generator=g) for k in P}
+        ST = torch.full_like(seeds, 50)
+        flt = (tg.TemporalEdgeFilter((0, 30), TS, True, tg.TEMPORAL_SAMPLE_DYNAMIC), {"A": ST})
+        kw = dict(filter_mode=2, forward=True, window=(0, 30), timestamps={k: v.cpu().numpy() for k, v in TS.items()},
+                  inputs_state={"A": ST.cpu().numpy()})
+    tg.seed(6)
+    s, r, c, e, lo = tg.neighbor_sampling_heterogenous(NODE_TYPES, EDGE_TYPES, P, I, {"A": seeds}, nn, 2, sampler, flt)
+    torch.cuda.synchronize()
+    assert torch.equal(s["A"][:1024], seeds)
+    total = 0
+    for (sn, rn, dn) in EDGE_TYPES:
+        k = rel_key((sn, rn, dn))
+        rows, cols, eidx = r[k], c[k], e[k]
+        total += int(rows.numel())
+        if rows.numel() == 0:
+            continue
+        parent = s[dn][cols]
+        assert torch.equal(s[sn][rows], I[k][eidx])                                     # sample = indices[edge pointer]
+        assert bool(((eidx >= P[k][parent]) & (eidx < P[k][parent + 1])).all())         # in its parent's column
+        assert int(torch.unique(cols * (1 << 40) + eidx).numel()) == int(rows.numel())  # without replacement
+        assert int(torch.bincount(cols).max()) <= 15
+    assert total > 5_000
+    hP = {k: v.cpu().numpy() for k, v in P.items()}
+    hI = {k: v.cpu().numpy() for k, v in I.items()}
+    o = orc.ns_hetero(NODE_TYPES, EDGE_TYPES, hP, hI, {"A": seeds.cpu().numpy()}, nn, 2, orc.rng_philox(6, 0), **kw)
+    for t in NODE_TYPES:
+        assert np.array_equal(s[t].cpu().numpy(), o[0][t]), t
+    for et in EDGE_TYPES:
+        k = rel_key(et)
+        assert np.array_equal(r[k].cpu().numpy(), o[1][k]) and np.array_equal(c[k].cpu().numpy(), o[2][k]), k
+        assert np.array_equal(e[k].cpu().numpy(), o[3][k]), k
+        assert [tuple(x) for x in lo[k]] == o[4][k], k
+
+
 def test_cfg5_rmat27_partitioned_world8(cabi):
     from tch_geometric import partitioned
     dev = torch.device(DEV)
