@@ -13,7 +13,8 @@
 //                          batch, slot, output offset: 16 bytes, 24 for graphs / launches beyond 32-bit offsets).
 //   P1-3 win_hist / win_colscan / win_basescan / win_scatter: one counting-sort pass of the hop's items by WINDOW of
 //                          the column start (window = 2^shift edge pointers = a few hundred KB of `indices`), laid
-//                          out XCD-major (windows x, x+8, x+16 ... form queue x); no global atomics.
+//                          out XCD-major (windows x, x+8, x+16 ... form queue x); no global atomics.  Without
+//                          replacement a window has two buckets: columns taken whole, then columns that draw.
 //   K4  win_gather_kernel  (persistent; the blocks of one XCD sweep that XCD's queue in order, a block reserving the
 //                          next slice with one atomic): re-derives the item's positions (counter-addressed Philox:
 //                          the same draws as K1 and the fused kernel), gathers `indices[e0 + pos]` -- now L2 hits,
