@@ -1152,13 +1152,15 @@ PYBIND11_MODULE(tch_geometric, m) {
           py::arg("edge_types"), py::arg("col_ptrs"), py::arg("row_indices"), py::arg("inputs"),
           py::arg("num_neighbors"), py::arg("num_hops"), py::arg("sampler") = py::none(),
           py::arg("filter") = py::none());
+    // (tensor-only signatures: the whole body runs without the GIL)
     m.def("random_walk", &random_walk, py::arg("row_ptrs"), py::arg("col_indices"), py::arg("start"),
-          py::arg("walk_length"), py::arg("p"), py::arg("q"));
+          py::arg("walk_length"), py::arg("p"), py::arg("q"), py::call_guard<py::gil_scoped_release>());
     m.def("tempo_random_walk", &tempo_random_walk, py::arg("row_ptrs"), py::arg("col_indices"),
           py::arg("node_timestamps"), py::arg("edge_timestamps"), py::arg("start"), py::arg("start_timestamps"),
-          py::arg("walk_length"), py::arg("window"));
+          py::arg("walk_length"), py::arg("window"), py::call_guard<py::gil_scoped_release>());
     m.def("biased_tempo_random_walk", &biased_tempo_random_walk, py::arg("row_ptrs"), py::arg("col_indices"),
           py::arg("node_timestamps"), py::arg("edge_timestamps"), py::arg("start"), py::arg("start_timestamps"),
-          py::arg("walk_length"), py::arg("bias_type"), py::arg("forward"), py::arg("retry_count"));
+          py::arg("walk_length"), py::arg("bias_type"), py::arg("forward"), py::arg("retry_count"),
+          py::call_guard<py::gil_scoped_release>());
     register_more(m);
 }

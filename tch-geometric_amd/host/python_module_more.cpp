@@ -92,11 +92,15 @@ py::tuple negative_sample_neighbors_homogenous(const Tensor &row_ptrs, const Ten
     Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
     Tensor in = on(inputs, dev, at::kLong).reshape({-1});
     if (graph_size.second < 1) throw py::value_error("graph_size[1] must be >= 1 (the reference panics on an empty range)");
-    RangeCheck rc(dev);
-    rc.add(in, ptrs.numel() - 1);
-    rc.verify("negative_sample_neighbors_homogenous inputs");
-    NegRun r = run_neg(dev, 1, {0}, {0}, {ptrs}, {idx}, {graph_size.second}, {in}, {in.numel()}, num_neg, try_count,
-                       false, true);
+    NegRun r;
+    {
+        NoGil nogil; // nothing in here touches Python
+        RangeCheck rc(dev);
+        rc.add(in, ptrs.numel() - 1);
+        rc.verify("negative_sample_neighbors_homogenous inputs");
+        r = run_neg(dev, 1, {0}, {0}, {ptrs}, {idx}, {graph_size.second}, {in}, {in.numel()}, num_neg, try_count, false,
+                    true);
+    }
     const c10::Device out_dev = inputs.device();
     return py::make_tuple(back(r.samples[0].narrow(0, 0, r.n_samples[0]), out_dev),
                           back(r.rows[0].narrow(0, 0, r.n_edges[0]), out_dev),
