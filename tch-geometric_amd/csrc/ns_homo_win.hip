@@ -13,8 +13,7 @@
 //                          batch, slot, output offset: 16 bytes, 24 for graphs / launches beyond 32-bit offsets).
 //   P1-3 win_hist / win_colscan / win_basescan / win_scatter: one counting-sort pass of the hop's items by WINDOW of
 //                          the column start (window = 2^shift edge pointers = a few hundred KB of `indices`), laid
-//                          out XCD-major (windows x, x+8, x+16 ... form queue x); no global atomics.  Without
-//                          replacement a window has two buckets: columns taken whole, then columns that draw.
+//                          out XCD-major (windows x, x+8, x+16 ... form queue x); no global atomics.
 //   K4  win_gather_kernel  (persistent; the blocks of one XCD sweep that XCD's queue in order, a block reserving the
 //                          next slice with one atomic): re-derives the item's positions (counter-addressed Philox:
 //                          the same draws as K1 and the fused kernel), gathers `indices[e0 + pos]` -- now L2 hits,
@@ -70,7 +69,6 @@ struct WinParams {
     uint32_t *base; // [n_buckets + 1]
     WinQueues *queues;
     int32_t n_buckets, shift; // bucket count (multiple of 8), window = e0 >> shift
-    int32_t split;            // 1: two buckets per window (see win_bucket)
     int32_t slot_bits;        // narrow items: slot in the low bits, batch above
 };
 
@@ -99,14 +97,9 @@ struct WinItemW {
 };
 static_assert(sizeof(WinItemN) == 16 && sizeof(WinItemW) == 24, "item layouts");
 
-// Bucket of an item: its window, XCD-major; with `split_k` > 0 every window has two buckets -- columns of at most
-// split_k edges (taken whole: no draws) before longer ones (ticket draws) -- so that the gather kernel's wavefronts
-// are uniform in which path their lanes take: a wavefront pays the Philox blocks and the ticket chain if ONE lane needs
-// them, and in a degree-mixed frontier every wavefront has such a lane although about half the items do not.
-__device__ __forceinline__ uint32_t win_bucket(uint64_t e0, uint32_t deg, int shift, int n_buckets, int split_k) {
+__device__ __forceinline__ uint32_t win_bucket(uint64_t e0, int shift, int n_buckets) {
     const uint32_t w = (uint32_t)(e0 >> shift);
-    const uint32_t sub = split_k > 0 ? ((w >> 3) << 1) + (deg > (uint32_t)split_k ? 1u : 0u) : (w >> 3);
-    return (w & 7u) * (uint32_t)(n_buckets >> 3) + sub; // XCD-major
+    return (w & 7u) * (uint32_t)(n_buckets >> 3) + (w >> 3); // XCD-major
 }
 
 // ---------------------------------------------------------------- init: seeds -> samples, per-batch state and keys
@@ -346,7 +339,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist_kernel(const WinPar
     for (uint64_t t0 = (uint64_t)blockIdx.x * WIN_TILE; t0 < n; t0 += (uint64_t)gridDim.x * WIN_TILE) {
         for (uint64_t j = t0 + threadIdx.x; j < min(n, t0 + WIN_TILE); j += blockDim.x) {
             const Item it = items[j];
-            if (it.deg) atomicAdd(&h[win_bucket(it.col(), it.deg, p.shift, nb, p.split ? p.k : 0)], 1u);
+            if (it.deg) atomicAdd(&h[win_bucket(it.col(), p.shift, nb)], 1u);
         }
     }
     __syncthreads();
@@ -437,8 +430,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter_kernel(const Win
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (it[u].deg)
-                sorted[atomicAdd(&cur[win_bucket(it[u].col(), it[u].deg, p.shift, nb, p.split ? p.k : 0)], 1u)] = it[u];
+            if (it[u].deg) sorted[atomicAdd(&cur[win_bucket(it[u].col(), p.shift, nb)], 1u)] = it[u];
     }
 }
 
@@ -736,15 +728,10 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     const int elem = csc->indices32 ? 4 : 8;
     int shift = 0;
     while (((int64_t)elem << shift) < (int64_t)window_kib * 1024) ++shift;
-    static const int split_env = win_env_int("TG_WIN_SPLIT", 1);
-    const bool with_replacement = (cfg ? cfg->sampler : TG_SAMPLER_UNIFORM) == TG_SAMPLER_UNIFORM_REPL;
-    p.split = (split_env && !with_replacement) ? 1 : 0; // with replacement every column draws
-    const int64_t max_windows = (p.split ? WIN_MAX_BUCKETS / 2 : WIN_MAX_BUCKETS) - 8;
-    while (((csc->n_edges >> shift) + 1) > max_windows) ++shift;
+    while (((csc->n_edges >> shift) + 1) > WIN_MAX_BUCKETS - 8) ++shift;
     p.shift = shift;
     p.n_buckets = (int32_t)((((csc->n_edges >> shift) + 1) + 7) & ~(int64_t)7);
     if (p.n_buckets < 8) p.n_buckets = 8;
-    if (p.split) p.n_buckets *= 2;
     // narrow items: 32-bit edge pointers and offsets, (batch, slot) in one word
     int slot_bits = 1;
     while (((int64_t)1 << slot_bits) < out->cap_nodes) ++slot_bits;
