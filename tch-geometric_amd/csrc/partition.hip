@@ -627,13 +627,13 @@ extern "C" int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t
 
 static int part_owner_params(tg::PartOwnerParams &p, const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests,
                              const int64_t *m_dev, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
-                             int32_t fanout, int32_t sampler, uint64_t seed, bool general = false) {
+                             int32_t fanout, int32_t sampler, uint64_t seed, int64_t m_cap, bool general = false) {
     TG_REQUIRE(shard && shard->ptrs && (shard->indices || shard->n_edges == 0), "tg_part: null shard");
     TG_REQUIRE(fanout >= 1 && (general || fanout <= TG_MAX_FANOUT), "tg_part: fanout %d outside [1, %d]", fanout, TG_MAX_FANOUT);
     TG_REQUIRE(general || sampler == TG_SAMPLER_UNIFORM || sampler == TG_SAMPLER_UNIFORM_REPL,
                "tg_part_count / tg_part_sample: unweighted samplers only (filters and weights: tg_part_unpack + a flat hop + tg_part_pack)");
-    TG_REQUIRE(world >= 1 && world <= tg::PART_MAX_WORLD && seg_off && seg_call0 && m_dev && requests,
-               "tg_part: bad owner arguments");
+    TG_REQUIRE(world >= 1 && world <= tg::PART_MAX_WORLD && seg_off && seg_call0 && m_dev && (requests || m_cap == 0),
+               "tg_part: bad owner arguments"); // (a rank that received no request may pass no buffer)
     p.ptrs = shard->ptrs;
     p.indices = shard->indices;
     p.indices32 = shard->indices32;
@@ -656,7 +656,7 @@ extern "C" int tg_part_count(const tg_graph *shard, int64_t v_lo, const void *re
                              int32_t sampler, uint32_t *cnt, int64_t *off, int64_t *reply_counts, void *scan_tmp,
                              int64_t scan_tmp_bytes, void *stream) {
     tg::PartOwnerParams p;
-    int rc = part_owner_params(p, shard, v_lo, 0, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, 0);
+    int rc = part_owner_params(p, shard, v_lo, 0, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, 0, m_cap);
     if (rc != TG_OK) return rc;
     TG_REQUIRE(cnt && off && reply_counts && m_cap >= 0, "tg_part_count: null buffers");
     if (m_cap == 0) {
@@ -689,7 +689,7 @@ extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo,
                               int32_t fanout, int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off,
                               int64_t *reply, int32_t reply_format, void *stream) {
     tg::PartOwnerParams p;
-    int rc = part_owner_params(p, shard, v_lo, e_lo, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed);
+    int rc = part_owner_params(p, shard, v_lo, e_lo, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed, m_cap);
     if (rc != TG_OK) return rc;
     TG_REQUIRE(reply_format == TG_PART_REPLY_PAIRS || reply_format == TG_PART_REPLY_PACKED,
                "tg_part_sample: reply_format is TG_PART_REPLY_PAIRS or TG_PART_REPLY_PACKED");
@@ -714,8 +714,8 @@ extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo,
 extern "C" int tg_part_unpack(int64_t v_lo, int64_t n_major, const void *requests, const int64_t *m_dev, int64_t m_cap,
                               int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int64_t *vertices, int64_t *ids,
                               int64_t *call_ids, void *stream) {
-    TG_REQUIRE(requests && m_dev && seg_off && seg_call0 && vertices && ids && call_ids && m_cap >= 0 && world >= 1 &&
-                   world <= tg::PART_MAX_WORLD,
+    TG_REQUIRE(m_dev && seg_off && seg_call0 && m_cap >= 0 && world >= 1 && world <= tg::PART_MAX_WORLD &&
+                   (m_cap == 0 || (requests && vertices && ids && call_ids)),
                "tg_part_unpack: bad arguments");
     if (m_cap == 0) return TG_OK;
     tg::PartOwnerParams p{};

@@ -19,7 +19,7 @@ def random_graph(rs, n, e, hubs=2):
     row = rs.integers(0, n, e)
     col = rs.integers(0, n, e)
     for h in range(hubs):                                   # a few heavy columns and rows
-        m = rs.integers(e // 20, e // 8)
+        m = rs.integers(e // 20, max(e // 8, e // 20 + 1))  # (graphs of fewer than 8 edges: an empty range otherwise)
         col[rs.integers(0, e, m)] = rs.integers(0, n)
         row[rs.integers(0, e, m)] = rs.integers(0, n)
     return np.stack([row, col]).astype(np.int64)
