@@ -183,6 +183,26 @@ def test_device_kernels_with_an_emulated_world(world, packed):
             assert (x == y) if isinstance(x, list) else torch.equal(x, y)
 
 
+def test_ranks_without_requests():
+    """all seeds in one shard's vertex range, one hop: the other owners receive nothing and may be handed no request
+    buffer at all (tg_part_count / tg_part_sample with m = 0)"""
+    from helpers_part import emulated_world_sample
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n = _graph(dev)
+    world, fan = 4, [3]
+    seeds = torch.randint(0, n // world // 2, (2, 8), device=dev)
+    shards = [partitioned.CscShard.from_full(ptrs, idx, r, world) for r in range(world)]
+    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 9)
+    assert crossed == 0
+    ref = _cabi.NsBatchedOut(2, 8, fan, dev)
+    _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED, 9, ref)
+    torch.cuda.synchronize()
+    for b in range(2):
+        for x, y in zip(out.batch(b), ref.batch(b)):
+            assert (x == y) if isinstance(x, list) else torch.equal(x, y)
+
+
 def test_rccl_backend_gets_device_tensors_only(monkeypatch):
     """every tensor the device form hands to all_to_all_single under a non-gloo backend lives on the GPU (the
     collective is mocked as a loop-back: this rank's own buffers come back)"""
