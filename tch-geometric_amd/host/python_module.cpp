@@ -340,10 +340,14 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
     int64_t cap_nodes = 0, cap_edges = 0;
     check_rc(tg_ns_homo_capacity(seeds.numel(), fanout.data(), H, &cap_nodes, &cap_edges));
     NsResult r;
-    r.samples = at::empty({std::max<int64_t>(cap_nodes, 1)}, i64(dev));
-    r.rows = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
-    r.cols = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
-    r.edge_index = at::empty({std::max<int64_t>(cap_edges, 1)}, i64(dev));
+    { // one allocation for the four output lists (the views handed back keep it alive)
+        const int64_t cn = std::max<int64_t>(cap_nodes, 1), ce = std::max<int64_t>(cap_edges, 1);
+        Tensor arena = at::empty({cn + 3 * ce}, i64(dev));
+        r.samples = arena.narrow(0, 0, cn);
+        r.rows = arena.narrow(0, cn, ce);
+        r.cols = arena.narrow(0, cn + ce, ce);
+        r.edge_index = arena.narrow(0, cn + 2 * ce, ce);
+    }
     // layer offsets | counts | "a seed was out of range": ONE array, one read-back when the call ends
     const int64_t lo_words = (int64_t)std::max<int32_t>(H, 1) * 3;
     Tensor tail = at::zeros({lo_words + 3}, i64(dev));
@@ -617,15 +621,27 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         check_rc(tg_ns_hetero_capacity(&pb, cap_n.data(), cap_e.data()));
         std::vector<Tensor> S(T), RW((size_t)R), CL((size_t)R), EI((size_t)R);
         std::vector<int64_t *> s_ptr(T), r_ptr((size_t)std::max(R, 1)), c_ptr((size_t)std::max(R, 1)), e_ptr((size_t)std::max(R, 1));
+        // one allocation for every output list of the call (the views handed back keep it alive): an allocation costs
+        // a few microseconds, and there would be T + 3R of them in a call whose kernel takes ~150
+        int64_t arena_words = 0;
+        for (size_t t = 0; t < T; ++t) arena_words += std::max<int64_t>(cap_n[t], 1);
+        for (int r = 0; r < R; ++r) arena_words += 3 * std::max<int64_t>(cap_e[(size_t)r], 1);
+        Tensor arena = at::empty({arena_words}, i64(dev));
+        int64_t at_word = 0;
+        auto carve = [&](int64_t words) {
+            Tensor v = arena.narrow(0, at_word, words);
+            at_word += words;
+            return v;
+        };
         for (size_t t = 0; t < T; ++t) {
-            S[t] = at::empty({std::max<int64_t>(cap_n[t], 1)}, i64(dev));
+            S[t] = carve(std::max<int64_t>(cap_n[t], 1));
             s_ptr[t] = S[t].data_ptr<int64_t>();
         }
         for (int r = 0; r < R; ++r) {
             const int64_t c = std::max<int64_t>(cap_e[(size_t)r], 1);
-            RW[(size_t)r] = at::empty({c}, i64(dev));
-            CL[(size_t)r] = at::empty({c}, i64(dev));
-            EI[(size_t)r] = at::empty({c}, i64(dev));
+            RW[(size_t)r] = carve(c);
+            CL[(size_t)r] = carve(c);
+            EI[(size_t)r] = carve(c);
             r_ptr[(size_t)r] = RW[(size_t)r].data_ptr<int64_t>();
             c_ptr[(size_t)r] = CL[(size_t)r].data_ptr<int64_t>();
             e_ptr[(size_t)r] = EI[(size_t)r].data_ptr<int64_t>();
