@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true",
                     help="--mode partitioned with one rank: still run every collective of the protocol over RCCL (the rank "
                          "exchanges with itself) -- what a one-GPU box can exercise of the transport")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="--mode partitioned: super-batches in flight at once, each lane a PartitionedSampler of its own on "
+                         "its own HIP stream, host thread and process group (communicator), so that the exchange of one "
+                         "super-batch overlaps the sampling of the next (SURVEY.md 8(e))")
     ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
                     help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
     return ap.parse_args()
@@ -343,31 +347,62 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    ps = partitioned.PartitionedSampler(shard, G, B, fanout, group=None, force_exchange=args.force_exchange)
+    lanes = max(1, args.lanes)
+    exchanging = world > 1 or args.force_exchange
+    # a lane's collectives must meet the same lane's on every rank in the same order: one communicator per lane
+    groups = [dist.new_group(ranks=list(range(world))) if (exchanging and lanes > 1) else None for _ in range(lanes)]
+    pss = [partitioned.PartitionedSampler(shard, G, B, fanout, group=groups[j], force_exchange=args.force_exchange)
+           for j in range(lanes)]
+    ps = pss[0]
+    streams = [torch.cuda.Stream(device=dev) if lanes > 1 else torch.cuda.current_stream(dev) for _ in range(lanes)]
     firsts = [sharding.rank_batch_range(r, world, (W + K) * G)[0] for r in range(world)]
     first = firsts[rank]
-    acc = torch.zeros(1, dtype=torch.int64, device=dev)
+    accs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(lanes)]
     events = []
 
+    def run_lane(j, lo, hi, timed):
+        with torch.cuda.stream(streams[j]):
+            for i in range(lo + j, hi, lanes):
+                seeds = _cabi.seed_batches(0xBA7C4, first + i * G, G, B, n, dev)
+                if timed:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                out = pss[j].sample(seeds, 0, first + i * G, first_call_ids=[f + i * G for f in firsts])
+                if timed:
+                    ev1.record()
+                    events.append((ev0, ev1))
+                accs[j].add_(out.counts[:, 1].sum())
+
     def run(lo, hi, timed):
-        for i in range(lo, hi):
-            seeds = _cabi.seed_batches(0xBA7C4, first + i * G, G, B, n, dev)
-            if timed:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            out = ps.sample(seeds, 0, first + i * G, first_call_ids=[f + i * G for f in firsts])
-            if timed:
-                ev1.record()
-                events.append((ev0, ev1))
-            acc.add_(out.counts[:, 1].sum())
+        if lanes == 1:
+            return run_lane(0, lo, hi, timed)
+        import threading
+        errs = []
+
+        def guarded(j):
+            try:
+                torch.cuda.set_device(dev)
+                run_lane(j, lo, hi, timed)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(ex)
+        ts = [threading.Thread(target=guarded, args=(j,)) for j in range(lanes)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
 
     run(0, W, False)
-    acc.zero_()
+    torch.cuda.synchronize(dev)
+    for a in accs:
+        a.zero_()
     sharding.fence(dev)
     t0 = time.perf_counter()
     run(W, W + K, True)
     sharding.fence(dev)
     dt = time.perf_counter() - t0
+    acc = torch.stack(accs).sum(0)
     dt_max, tot = sharding.reduce_measurement(dt, torch.cat([acc, torch.zeros(2, dtype=torch.int64, device=dev)]))
     edges_all = int(tot.tolist()[0])
     ms = [a.elapsed_time(b) for a, b in events]
@@ -387,6 +422,7 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
                                                          "read-backs of the multi-rank protocol run)" if args.force_exchange
                                                          else "; one rank: no exchange, no host read-back")),
             "reply_entry_bytes": 8 * ps.reply_words,
+            "lanes": lanes,
             "avg_call_ms_this_rank": sum(ms) / len(ms),
             "shard_build_s": round(t_build, 2),
         },

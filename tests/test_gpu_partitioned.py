@@ -332,7 +332,40 @@ def _rccl_worker(port, q):
             for b in range(4):
                 x, y = got.batch(b, c), want.batch(b, c)
                 ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
-        q.put(("ok" if ok else "mismatch", calls, dist.get_backend()))
+        # two super-batches in flight: a sampler, a stream, a host thread and a communicator per lane (bench.py --lanes)
+        import threading
+        lanes = 2
+        groups = [dist.new_group(ranks=[0]) for _ in range(lanes)]
+        samplers = [partitioned.PartitionedSampler(shard, 4, B, [6, 4], group=groups[j], force_exchange=True) for j in range(lanes)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+        lane_seeds = [_cabi.seed_batches(33 + j, 900 + 10 * j, 4, B, n, dev) for j in range(lanes)]
+        results, errs = [None] * lanes, []
+
+        def lane(j):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(streams[j]):
+                    for _ in range(3):                      # the same call three times: buffers are reused under overlap
+                        results[j] = samplers[j].sample(lane_seeds[j], SEED, 900 + 10 * j)
+                    streams[j].synchronize()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        ts_ = [threading.Thread(target=lane, args=(j,)) for j in range(lanes)]
+        for t in ts_:
+            t.start()
+        for t in ts_:
+            t.join()
+        ok = ok and not errs
+        plain = dict(sampler=0, filter_mode=-1, forward=False, window=(0, 0))
+        for j in range(lanes):
+            want = _replicated_general(aptrs, aidx, ts, w, lane_seeds[j], states, [6, 4], 900 + 10 * j, plain)
+            c = want.counts.cpu()
+            ok = ok and results[j] is not None and torch.equal(results[j].counts.cpu(), c)
+            for b in range(4):
+                x, y = results[j].batch(b, c), want.batch(b, c)
+                ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+        q.put(("ok" if ok else "mismatch %r" % (errs,), calls, dist.get_backend()))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
         q.put(("error: %r" % (e,), 0, ""))
