@@ -165,6 +165,7 @@ def main():
     n_pool = max(1, min(W + K, 32))
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
     placement_ms = None
+    in_flight = None
     if len(candidates) > 1:
         # untimed set-up: the launch is timed on every combination of {samples slab} x {rows / cols / edge_index slabs} x
         # {workspace} of the placements (the gather kernel's time follows the first, the emit kernel's the second), one
@@ -191,6 +192,28 @@ def main():
             placement_ms["samples%d_streams%d_ws%d" % (a, b_, c)] = round(ms, 3)
             if best_ms is None or ms < best_ms:
                 best, best_ms = (a, b_, c), ms
+        # beside the line (never part of `value`): the same launches with TWO in flight, one per placement on its own
+        # stream -- what a caller that prefetches the next super-batch gets
+        in_flight = None
+        if n_c >= 2:
+            side = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            cur = torch.cuda.current_stream(dev)
+            for timed in (False, True):
+                torch.cuda.synchronize(dev)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for st_ in side:
+                    st_.wait_stream(cur)
+                for i in range(8):
+                    with torch.cuda.stream(side[i % 2]):
+                        _cabi.ns_homo_batched(graph, seeds[:G], fanout, 0, first + i * G, candidates[i % 2][0],
+                                              ws=candidates[i % 2][1], form=form)
+                for st_ in side:
+                    cur.wait_stream(st_)
+                ev1.record()
+                torch.cuda.synchronize(dev)
+                if timed:
+                    in_flight = {"launches": 8, "ms_per_launch": round(ev0.elapsed_time(ev1) / 8, 3)}
         out = copy.copy(candidates[best[0]][0])
         out.samples = candidates[best[0]][0].samples
         out.rows, out.cols, out.edge_index = (candidates[best[1]][0].rows, candidates[best[1]][0].cols,
@@ -275,6 +298,7 @@ def main():
             "step": "one launch over %d independent %d-seed mini-batches" % (G, B),
             "batches_per_launch": G,
             "placements_tried_ms_per_launch": placement_ms,
+            "two_launches_in_flight": in_flight,
             "hbm_layout": "CSC int64 ptrs/indices%s%s" % (" + u32 shadow of indices for the gathers" if args.idx32 else "",
                                                           " + u32 shadow of ptrs" if args.ptr32 else ""),
             "rng": "philox4x32-10 counter-addressed, seed 0, call_id = global batch id",
