@@ -9,7 +9,8 @@ for p in ("oracle", "tests", "tch-geometric_amd"):
 import tch_geometric as tg
 import test_gpu_random_sweep_hetero as T
 bad = 0
-for case in range(1000, 1400):
+MULT = int(os.environ.get("STRESS_MULT", "1"))   # widen every range by this factor
+for case in range(1000, 1000 + 400 * MULT):
     try:
         T.test_hetero_neighbor_sampling_random(tg, case)
     except Exception as e:  # noqa
@@ -17,7 +18,7 @@ for case in range(1000, 1400):
         print("FAIL hetero case", case, type(e).__name__, str(e)[:200], flush=True)
         if bad > 5:
             break
-for case in range(1000, 1120):
+for case in range(1000, 1000 + 120 * MULT):
     try:
         T.test_hgt_and_budget_random(tg, case)
     except Exception as e:  # noqa
@@ -32,7 +33,7 @@ for name, fn, lo, hi in (("neighbor sampling", S.test_neighbor_sampling_random_c
                          ("walks / negatives", S.test_walks_and_negatives_random_cases, 1000, 1100),
                          ("windowed launch", W.test_windowed_launch_random_cases, 1000, 1150),
                          ("partitioned", W.test_partitioned_random_cases, 1000, 1100)):
-    for case in range(lo, hi):
+    for case in range(lo, lo + (hi - lo) * MULT):
         try:
             fn(_cabi, case)
         except Exception as e:  # noqa
@@ -46,7 +47,7 @@ import numpy as np  # noqa: E402
 import orc  # noqa: E402
 import torch  # noqa: E402
 
-for case in range(400):
+for case in range(400 * MULT):
     rs = np.random.default_rng(20_000 + case)
     n = int(rs.integers(3, 3000))
     e = int(rs.integers(0, 40 * n))
@@ -84,7 +85,7 @@ print("surface homogeneous done", flush=True)
 # ---- many relations under filters / weights: several segmented rounds per hop (<= 16 entries, <= 8 segments each)
 from helpers import rel_key  # noqa: E402
 
-for case in range(90):
+for case in range(90 * MULT):
     rs = np.random.default_rng(30_000 + case)
     T_ = int(rs.integers(1, 6))
     node_types = ["t%d" % i for i in range(T_)]
