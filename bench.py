@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tch-geometric_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of BASELINE cfg3 / cfg4")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the (untimed) check of batches of the last timed step against the fused kernel and the oracle")
     ap.add_argument("--idx32", type=int, default=1, help="also keep a u32 shadow of `indices` for the gathers")
     ap.add_argument("--ptr32", type=int, default=1, help="also keep a u32 shadow of `ptrs`")
     ap.add_argument("--placements", type=int, default=2,
@@ -53,7 +55,7 @@ def parse_args():
                          "super-batch overlaps the sampling of the next (SURVEY.md 8(e))")
     ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
                     help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 _RESULT_FD = None
@@ -74,8 +76,44 @@ def print_result(result):
     os.write(_RESULT_FD if _RESULT_FD is not None else 1, line)
 
 
-def main():
-    args = parse_args()
+def self_launch_command(argv, n_gpus, port):
+    """`python bench.py --gpus N` without a launcher around it: the command this process starts as a CHILD (one rank per
+    GPU over RCCL; the contract's own spelling).  127.0.0.1: the container hostname may not resolve."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_self_launch(args, environ):
+    return args.gpus > 1 and "WORLD_SIZE" not in environ
+
+
+def self_launch(args, argv):
+    """Runs before torch is imported and before anything touches the GPU: starts torchrun as a child process (never an
+    exec), lets its stderr through, relays the ONE JSON line rank 0 printed and exits with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.run(self_launch_command(argv, args.gpus, port), env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and "\"metric\"" in ln]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the launched ranks printed no result line\n")
+        raise SystemExit(1)
+    raise SystemExit(proc.returncode)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if needs_self_launch(args, os.environ):
+        return self_launch(args, argv)
     keep_stdout_for_the_result()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
     import torch
@@ -88,8 +126,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
-                         % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # TG_BENCH_REHEARSE=1: rehearsal of the N > 1 path on a one-GPU box -- every rank uses cuda:0 and the timing
     # protocol's collectives go over gloo (RCCL refuses two ranks on one device).  Never set by the driver.
     rehearse = os.environ.get("TG_BENCH_REHEARSE", "0") == "1"
@@ -296,6 +333,10 @@ def main():
                         "batch %d, default sampler (uniform w/o replacement), no filter" %
                         (args.scale, n_nodes, n_edges, fanout, B),
             "step": "one launch over %d independent %d-seed mini-batches" % (G, B),
+            "placement_policy": ("the launch is timed on the FASTEST of the slab / workspace placements tried in untimed "
+                                 "set-up (all listed in placements_tried_ms_per_launch; --placements 1 = take the first)"
+                                 if placement_ms else "first allocation"),
+            "first_placement_ms_per_launch": (next(iter(placement_ms.values())) if placement_ms else None),
             "batches_per_launch": G,
             "placements_tried_ms_per_launch": placement_ms,
             "two_launches_in_flight": in_flight,
@@ -327,6 +368,14 @@ def main():
         },
     }
 
+    # ---- what was timed is checked (untimed): batches of the LAST timed step, as they lie in the slabs, against the
+    # fused per-batch kernel (another code path, on the device) and against the CPU oracle in philox-mode (the checker)
+    if not args.no_verify:
+        i_last = W + K - 1
+        result["config"]["verified_batches"] = verify_step(
+            torch, _cabi, graph, ptrs, indices, out, seeds[(i_last % n_pool) * G:(i_last % n_pool) * G + G], fanout,
+            first + i_last * G, sorted({0, G // 2, G - 1}), oracle=(rank == 0))
+
     if rank == 0 and world == 1 and not args.no_secondary:
         del out, ws
         torch.cuda.empty_cache()
@@ -337,6 +386,35 @@ def main():
         print_result(result)
     if world > 1:
         dist.destroy_process_group()
+
+
+def verify_step(torch, _cabi, graph, ptrs, indices, out, step_seeds, fanout, call0, batches, oracle=True):
+    """Batches of a step as bench.py left them in the slabs == the fused per-batch kernel on the same seeds and call ids ==
+    the oracle (philox-mode; neighbor_sampling.rs:188-223).  Raises on any difference; -> what was checked."""
+    dev = step_seeds.device
+    counts = out.counts.cpu()
+    checked = []
+    hp = hi = None
+    for j in batches:
+        got = out.batch(j, counts)
+        one = _cabi.NsBatchedOut(1, step_seeds.shape[1], fanout, dev)
+        _cabi.ns_homo_batched(graph, step_seeds[j:j + 1].contiguous(), fanout, 0, call0 + j, one, form=2)
+        ref = one.batch(0)
+        if got[4] != ref[4] or not all(torch.equal(a, b) for a, b in zip(got[:4], ref[:4])):
+            raise SystemExit("bench.py: batch %d of the last timed step differs from the fused kernel" % j)
+        entry = {"batch": j, "call_id": call0 + j, "sampled_edges": int(counts[j][1]), "equals": ["fused kernel"]}
+        if oracle:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import numpy as np
+            import orc  # the checker
+            if hp is None:
+                hp, hi = ptrs.cpu().numpy(), indices.cpu().numpy()
+            o = orc.ns_homo(hp, hi, step_seeds[j].cpu().numpy(), fanout, orc.rng_philox(0, call0 + j))
+            if got[4] != o[4] or not all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(got[:4], o[:4])):
+                raise SystemExit("bench.py: batch %d of the last timed step differs from the oracle" % j)
+            entry["equals"].append("oracle philox-mode")
+        checked.append(entry)
+    return checked
 
 
 def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanout):
@@ -630,14 +708,20 @@ def cpu_baseline(args, ptrs, indices, seeds, fanout):
     except Exception:
         pass
     threads = max(1, usable)
+    # -O3 -march=native.  The checker that travels with the repo is built -march=x86-64-v2 (it must run on
+    # whatever CPU the GPU box has); for the TIMED baseline the same source is compiled here, on this host, natively.
+    nat = orc.native_lib()
+    handle, cc, cflags = nat if nat else (None, "gcc (oracle/Makefile build)", orc.PORTABLE_CFLAGS)
     n0 = min(threads, hs.shape[0])
-    sec0, _ = orc.bench_ns_homo(hp, hi, hs[:n0], fanout, threads)          # calibration: one batch per thread
+    sec0, _ = orc.bench_ns_homo(hp, hi, hs[:n0], fanout, threads, handle)  # calibration: one batch per thread
     per_round = max(sec0, 1e-4)
     n = int(min(hs.shape[0], max(n0, threads * max(1, round(args.cpu_seconds / per_round)))))
-    sec, edges = orc.bench_ns_homo(hp, hi, hs[:n], fanout, threads)
+    sec, edges = orc.bench_ns_homo(hp, hi, hs[:n], fanout, threads, handle)
     n1 = max(1, min(n // threads, 64))
-    sec1, edges1 = orc.bench_ns_homo(hp, hi, hs[:n1], fanout, 1)
+    sec1, edges1 = orc.bench_ns_homo(hp, hi, hs[:n1], fanout, 1, handle)
     return {
+        "cc": cc,
+        "cflags": cflags,
         "value": edges / sec,
         "unit": "edges/s",
         "cores": threads,

@@ -143,6 +143,32 @@ TG_API int tg_ns_homo_batched_ws(const tg_graph *csc, const int64_t *seeds, int6
                           const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                           const tg_ns_out *out, void *workspace, int64_t workspace_bytes, int32_t mode, void *stream);
 
+/* Which form a tg_ns_homo_batched_ws call with these arguments runs: *form = TG_NS_FORM_FUSED (the per-batch kernel; also
+ * reported for the weighted / filtered samplers, which take neither), _WINDOWED (16-byte work items) or _WINDOWED_WIDE;
+ * *n_windows (optional) = windows the hop's frontier is sorted into.  A pure query: nothing is launched. */
+TG_API int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                            int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out, int64_t workspace_bytes,
+                            int32_t mode, int32_t *form, int32_t *n_windows);
+
+/* Tuning of the window-ordered form (process-wide; defaults come from TG_WIN_* environment variables read once).
+ * Outputs never depend on it.  _set: a zero field (negative for the two flags) keeps the current value. */
+typedef struct {
+    int64_t window_bytes;    /* bytes of the gathered array per window (default 512 KiB) */
+    int32_t gather_blocks;   /* workgroups of the persistent gather kernel (default 256) */
+    int32_t gather_threads;  /* its workgroup size (default 512) */
+    int32_t emit_threads;    /* workgroup size of the emit kernels (default 256) */
+    int32_t direct_hop0;     /* hop 0 issues its gathers itself, unordered (default 1) */
+    int32_t fuse_first_hops; /* seeds + hop 0 + hop 1's emit pass in one kernel (default 1) */
+} tg_ns_win_tuning;
+TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
+TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);
+
+/* Per-stage times of the window-ordered launch: tg_ns_win_stage_timing(1) makes every later launch record HIP events
+ * between its kernels (on its stream); tg_ns_win_stage_times waits for the last launch and returns up to `cap` stage
+ * durations in ms with their names (24 bytes each, "<stage>.h<hop>").  Measurement only. */
+TG_API int tg_ns_win_stage_timing(int32_t enable);
+TG_API int tg_ns_win_stage_times(float *ms, char *names, int32_t cap, int32_t *n);
+
 /* One hop of the unweighted, unfiltered sampler over a flat frontier, spread over the whole device (the
  * per-vertex work of neighbor_sampling.rs:195-218 without the per-batch bookkeeping).  Used where the frontier
  * is not "one seed batch": the owner side of the range-partitioned sampler, relation-hops of the heterogeneous

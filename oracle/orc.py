@@ -359,11 +359,39 @@ def neg_hetero(node_types, edge_types, row_ptrs, col_indices, sizes, inputs, num
 
 
 # ---------------------------------------------------------------- CPU baseline
-def bench_ns_homo(ptrs, indices, seeds, fanout, n_threads):
-    """seeds: [n_batches, B] int64.  Returns (seconds, sampled_edges)."""
+PORTABLE_CFLAGS = "-O3 -march=x86-64-v2 -ffp-contract=off -std=gnu11"   # oracle/Makefile: the build that travels to the GPU box
+NATIVE_CFLAGS = "-O3 -march=native -ffp-contract=off -std=gnu11"          # the timed CPU baseline
+_native = None
+
+
+def native_lib():
+    """The oracle compiled ON THIS HOST with -O3 -march=native into a temporary directory -- only for
+    timing the CPU baseline: a -march=native object built in the build container must not travel to another CPU, which is
+    why the committed Makefile builds the checker with -march=x86-64-v2.  -> (CDLL, cc, cflags) or None if gcc fails."""
+    global _native
+    if _native is None:
+        import tempfile
+        out = os.path.join(tempfile.mkdtemp(prefix="tg_oracle_native_"), "libtg_oracle_native.so")
+        cc = os.environ.get("CC", "gcc")
+        cmd = [cc] + NATIVE_CFLAGS.split() + ["-fPIC", "-shared", "-o", out, os.path.join(_HERE, "tg_oracle.c"),
+                                               "-lpthread", "-lm"]
+        try:
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            h = C.CDLL(out)
+            h.orc_bench_ns_homo.restype = C.c_double
+            ver = subprocess.run([cc, "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+            _native = (h, ver, NATIVE_CFLAGS)
+        except Exception:  # noqa: BLE001
+            _native = False
+    return _native or None
+
+
+def bench_ns_homo(ptrs, indices, seeds, fanout, n_threads, handle=None):
+    """seeds: [n_batches, B] int64.  Returns (seconds, sampled_edges).  handle: a CDLL of another build of the oracle
+    (native_lib), default the checker's own."""
     ptrs, indices, seeds, fan = _i64(ptrs), _i64(indices), _i64(seeds), _i64(fanout)
     edges = C.c_int64(0)
-    sec = lib().orc_bench_ns_homo(_p(ptrs), _p(indices), _p(seeds), C.c_int64(seeds.shape[1]),
+    sec = (handle or lib()).orc_bench_ns_homo(_p(ptrs), _p(indices), _p(seeds), C.c_int64(seeds.shape[1]),
                                   C.c_int64(seeds.shape[0]), _p(fan), C.c_int32(fan.size), C.c_int32(n_threads),
                                   C.byref(edges))
     return float(sec), int(edges.value)

@@ -142,11 +142,12 @@ __host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
 // items, no sort, no K4.  That is the right form for hop 0: the seeds are arbitrary vertices, so a launch touches a
 // line of `indices` only ~1.4 times there (RMAT-24, 4 096 batches: 11.3 M gathers over 8.3 M lines) and ordering them
 // buys nothing; deeper frontiers are drawn by degree, repeat the hubs and touch every line ~13 times.
+// One hop of one batch by one workgroup; returns the batch's state after the hop.  `hop` / `k` are arguments (not
+// p.hop / p.k) so that one kernel can run consecutive hops of its batch back to back.
 template <typename Item, int KMAX, bool REPLACE, bool DIRECT>
-__global__ void win_emit_kernel(const WinParams p) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned char *smem, const int64_t b, const int hop,
+                                                 const int k, const WinState st, const CallKey ck) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    const int64_t b = blockIdx.x;
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
     const size_t off_bytes = (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
     int64_t *shared_fbase = reinterpret_cast<int64_t *>(smem + off_bytes);
@@ -162,19 +163,16 @@ __global__ void win_emit_kernel(const WinParams p) {
     int64_t *cols = p.cols + b * p.cap_edges;
     int64_t *eidx = p.edge_index + b * p.cap_edges;
     const int64_t n_seeds = p.n_seeds;
-    const int k = p.k;
-    const WinState st = p.state[b];
     const int64_t begin = st.begin, end = st.end;
     int64_t ne = st.ne;
-    const CallKey ck = p.call_keys[b];
 
     if (tid == 0) {
-        int64_t *lo = p.layer_offsets + (b * p.n_hops + p.hop) * 3; // :193
+        int64_t *lo = p.layer_offsets + (b * p.n_hops + hop) * 3; // :193
         lo[0] = n_seeds + ne;
         lo[1] = ne;
         lo[2] = n_seeds + ne;
         // this batch's range of the hop's flat item array (order between batches does not matter)
-        *shared_fbase = DIRECT ? 0 : (int64_t)atomicAdd(&p.n_items[p.hop], (unsigned long long)(end - begin));
+        *shared_fbase = DIRECT ? 0 : (int64_t)atomicAdd(&p.n_items[hop], (unsigned long long)(end - begin));
     }
     __syncthreads();
     const int64_t fbase = *shared_fbase;
@@ -279,7 +277,10 @@ __global__ void win_emit_kernel(const WinParams p) {
                 // the same bytes runs at 6.7 TB/s, this kernel at 4.4: tools/probe_write_bw.py.
                 typedef long long i64x2 __attribute__((ext_vector_type(2)));
                 const int64_t ea = e_chunk;
-                const uint32_t head = (uint32_t)(ea & 1); // an odd first element is stored alone: the pairs are 16-byte aligned
+                // an element at an address that is not 16-byte aligned is stored alone (rows / cols / edge_index share the
+                // parity: equal pitch, 16-byte aligned bases); taken from the ADDRESS -- with an odd cap_edges the slabs of
+                // odd batches start on an odd element
+                const uint32_t head = (uint32_t)(((uintptr_t)(rows + ea) >> 3) & 1);
                 if (head && lane == 0 && total > 0) {
                     __builtin_nontemporal_store(n_seeds + ea, &rows[ea]);
                     __builtin_nontemporal_store(i0 + (int64_t)slane[0], &cols[ea]);
@@ -318,14 +319,50 @@ __global__ void win_emit_kernel(const WinParams p) {
         ne += chunk_off[nc];
         __syncthreads();
     }
-    if (tid == 0) {
-        p.state[b] = WinState{end, n_seeds + ne, ne, fbase}; // :221-222
-        if (p.hop == p.n_hops - 1) {
-            p.counts[b * 2 + 0] = n_seeds + ne;
-            p.counts[b * 2 + 1] = ne;
+    return WinState{end, n_seeds + ne, ne, fbase}; // :221-222
+}
+
+__device__ __forceinline__ void win_store_state(const WinParams &p, int64_t b, int hop, const WinState &st) {
+    if (threadIdx.x == 0) {
+        p.state[b] = st;
+        if (hop == p.n_hops - 1) {
+            p.counts[b * 2 + 0] = st.end;
+            p.counts[b * 2 + 1] = st.ne;
         }
     }
 }
+
+template <typename Item, int KMAX, bool REPLACE, bool DIRECT>
+__global__ void win_emit_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t b = blockIdx.x;
+    const WinState st = win_emit_hop<Item, KMAX, REPLACE, DIRECT>(p, smem, b, p.hop, p.k, p.state[b], p.call_keys[b]);
+    win_store_state(p, b, p.hop, st);
+}
+
+// The first hops of a batch in ONE kernel: seeds -> samples (win_init's work), hop 0 DIRECT (its gathers issued here, in
+// batch order: bound by the rate of random line requests, ~55 G/s) and, when the launch has a second hop, that hop's
+// emit pass (bound by its three write streams) -- workgroups in different phases run side by side, so the random reads
+// of one batch's hop 0 hide under the streaming writes of another's hop 1, which two kernels one after the other cannot do.
+// The workgroup reads back the samples it wrote itself (workgroup barrier between the hops).
+template <typename Item, int KMAX, bool REPLACE>
+__global__ void win_first_hops_kernel(const WinParams p, const int k0, const int k1) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t b = blockIdx.x;
+    int64_t *samples = p.samples + b * p.cap_nodes;
+    for (int64_t i = threadIdx.x; i < p.n_seeds; i += blockDim.x) samples[i] = p.seeds[b * p.n_seeds + i]; // :184
+    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
+    if (threadIdx.x == 0) p.call_keys[b] = ck;
+    __syncthreads();
+    WinState st = win_emit_hop<Item, KMAX, REPLACE, true>(p, smem, b, 0, k0, WinState{0, p.n_seeds, 0, 0}, ck);
+    if (p.n_hops > 1) {
+        __syncthreads(); // hop 0's samples (plain stores of this workgroup) are the frontier read next
+        st = win_emit_hop<Item, KMAX, REPLACE, false>(p, smem, b, 1, k1, st, ck);
+        win_store_state(p, b, 1, st);
+    } else
+        win_store_state(p, b, 0, st);
+}
+
 
 // ---------------------------------------------------------------- P1: per-block bucket histogram of the hop's items
 template <typename Item>
@@ -566,6 +603,51 @@ static int win_env_int(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// Tuning of the window-ordered launch: defaults <- environment (read once) <- tg_ns_win_tuning_set (any time; tests use
+// it to force many small windows on a small graph).  Outputs never depend on any of these.
+struct WinTuning {
+    int64_t window_bytes;
+    int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops;
+};
+static WinTuning &win_tuning() {
+    static WinTuning t = {
+        (int64_t)win_env_int("TG_WIN_KIB", 512) * 1024,
+        win_env_int("TG_WIN_GATHER_BLOCKS", 256),
+        win_env_int("TG_WIN_GATHER_THREADS", 512),
+        win_env_int("TG_WIN_EMIT_THREADS", 256),
+        win_env_int("TG_WIN_DIRECT_HOP0", 1),
+        win_env_int("TG_WIN_FUSE_FIRST_HOPS", 1),
+    };
+    return t;
+}
+
+// Optional per-stage timing of the last launch (tg_ns_win_stage_timing): HIP events between the kernels, on the
+// launch's stream.  Off by default; when on, a launch records (stages + 1) events and nothing else changes.
+constexpr int WIN_MAX_STAGES = 8 * TG_MAX_HOPS + 2;
+struct WinStageClock {
+    bool enabled = false;
+    int n = 0;
+    hipEvent_t ev[WIN_MAX_STAGES + 1] = {};
+    char name[WIN_MAX_STAGES][24] = {};
+    void begin(hipStream_t s) {
+        n = 0;
+        if (!enabled) return;
+        if (!ev[0])
+            for (auto &e : ev) (void)hipEventCreate(&e);
+        (void)hipEventRecord(ev[0], s);
+    }
+    void mark(const char *what, int hop, hipStream_t s) {
+        if (!enabled || n >= WIN_MAX_STAGES) return;
+        snprintf(name[n], sizeof(name[n]), "%s.h%d", what, hop);
+        ++n;
+        (void)hipEventRecord(ev[n], s);
+    }
+};
+static WinStageClock &win_clock() {
+    static WinStageClock c;
+    return c;
+}
+
 struct WinLayout {
     size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, total;
     int64_t max_items;
@@ -599,43 +681,81 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
 
 template <typename Item, int KMAX, bool REPLACE>
 static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
-    static const int emit_threads = win_env_int("TG_WIN_EMIT_THREADS", 256);
-    static const int direct_hop0 = win_env_int("TG_WIN_DIRECT_HOP0", 1);
-    static const int gather_threads = win_env_int("TG_WIN_GATHER_THREADS", 512);
-    static const int gather_blocks = (win_env_int("TG_WIN_GATHER_BLOCKS", 256) + 7) & ~7; // 8 groups of equal size
-    hipLaunchKernelGGL(win_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, stream, p, n_batches);
-    TG_LAUNCH_CHECK();
-    for (int h = 0; h < n_hops; ++h) {
+    const WinTuning t = win_tuning();
+    WinStageClock &clk = win_clock();
+    const int gather_blocks = (t.gather_blocks + 7) & ~7; // 8 groups of equal size
+    auto emit_threads_for = [&]() {
+        int threads = t.emit_threads;
+        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
+        return threads;
+    };
+    clk.begin(stream);
+    int h0 = 0;
+    if (t.direct_hop0 && t.fuse_first_hops) { // seeds, hop 0 (direct) and hop 1's emit pass by one kernel
+        TG_HIP(hipMemsetAsync(p.n_items, 0, TG_MAX_HOPS * sizeof(unsigned long long), stream));
+        const int threads = emit_threads_for();
+        hipLaunchKernelGGL((win_first_hops_kernel<Item, KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
+                           win_emit_lds_bytes(p.kmax, threads / 64), stream, p, (int)fanout[0],
+                           n_hops > 1 ? (int)fanout[1] : 0);
+        TG_LAUNCH_CHECK();
+        clk.mark("first_hops", 0, stream);
+        h0 = 1;
+    } else {
+        hipLaunchKernelGGL(win_init_kernel, dim3((unsigned)n_batches), dim3(256), 0, stream, p, n_batches);
+        TG_LAUNCH_CHECK();
+        clk.mark("init", 0, stream);
+    }
+    for (int h = h0; h < n_hops; ++h) {
         p.hop = h;
         p.k = (int32_t)fanout[h];
-        int threads = emit_threads;
-        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
-        if (h == 0 && direct_hop0) { // arbitrary seeds: nothing to gain from ordering their gathers
-            hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, true>), dim3((unsigned)n_batches), dim3(threads),
+        const bool emitted = (h == 1 && h0 == 1); // the fused kernel already ran hop 1's emit pass
+        if (!emitted) {
+            const int threads = emit_threads_for();
+            if (h == 0 && t.direct_hop0) { // arbitrary seeds: nothing to gain from ordering their gathers
+                hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, true>), dim3((unsigned)n_batches), dim3(threads),
+                                   win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
+                TG_LAUNCH_CHECK();
+                clk.mark("emit_direct", h, stream);
+                continue;
+            }
+            hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, false>), dim3((unsigned)n_batches), dim3(threads),
                                win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
             TG_LAUNCH_CHECK();
-            continue;
+            clk.mark("emit", h, stream);
         }
-        hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, false>), dim3((unsigned)n_batches), dim3(threads),
-                           win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
-        TG_LAUNCH_CHECK();
         hipLaunchKernelGGL(win_hist_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
         TG_LAUNCH_CHECK();
+        clk.mark("hist", h, stream);
         hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
                            WIN_PART_BLOCKS);
         TG_LAUNCH_CHECK();
         hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
         TG_LAUNCH_CHECK();
+        clk.mark("scans", h, stream);
         hipLaunchKernelGGL(win_scatter_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
         TG_LAUNCH_CHECK();
-        int gthreads = gather_threads;
+        clk.mark("scatter", h, stream);
+        int gthreads = t.gather_threads;
         while (gthreads > 64 && (size_t)(gthreads / 64) * win_gather_wave_lds_bytes(p.kmax) > 64 * 1024)
             gthreads = ((gthreads >> 1) + 63) & ~63;
         hipLaunchKernelGGL((win_gather_kernel<Item, KMAX, REPLACE>), dim3(gather_blocks), dim3(gthreads),
                            (size_t)(gthreads / 64) * win_gather_wave_lds_bytes(p.kmax), stream, p);
         TG_LAUNCH_CHECK();
+        clk.mark("gather", h, stream);
     }
     return TG_OK;
+}
+
+// window size: a few hundred KB of the gathered array, at most WIN_MAX_BUCKETS windows
+static void win_window_geometry(const tg_graph *csc, int32_t *shift_out, int32_t *n_buckets_out) {
+    const int elem = csc->indices32 ? 4 : 8;
+    int shift = 0;
+    while (((int64_t)elem << shift) < win_tuning().window_bytes) ++shift;
+    while (((csc->n_edges >> shift) + 1) > WIN_MAX_BUCKETS - 8) ++shift;
+    int32_t nb = (int32_t)((((csc->n_edges >> shift) + 1) + 7) & ~(int64_t)7);
+    if (nb < 8) nb = 8;
+    *shift_out = shift;
+    *n_buckets_out = nb;
 }
 
 template <typename Item>
@@ -723,15 +843,7 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     p.base = reinterpret_cast<uint32_t *>(w + L.base);
     p.items_in = w + L.items_in;
     p.items_sorted = w + L.items_sorted;
-    // window size: a few hundred KB of the gathered array, at most WIN_MAX_BUCKETS windows
-    static const int window_kib = win_env_int("TG_WIN_KIB", 512);
-    const int elem = csc->indices32 ? 4 : 8;
-    int shift = 0;
-    while (((int64_t)elem << shift) < (int64_t)window_kib * 1024) ++shift;
-    while (((csc->n_edges >> shift) + 1) > WIN_MAX_BUCKETS - 8) ++shift;
-    p.shift = shift;
-    p.n_buckets = (int32_t)((((csc->n_edges >> shift) + 1) + 7) & ~(int64_t)7);
-    if (p.n_buckets < 8) p.n_buckets = 8;
+    win_window_geometry(csc, &p.shift, &p.n_buckets);
     // narrow items: 32-bit edge pointers and offsets, (batch, slot) in one word
     int slot_bits = 1;
     while (((int64_t)1 << slot_bits) < out->cap_nodes) ++slot_bits;
@@ -742,4 +854,77 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     const bool repl = (cfg ? cfg->sampler : TG_SAMPLER_UNIFORM) == TG_SAMPLER_UNIFORM_REPL;
     if (narrow && !force_wide) return win_dispatch<WinItemN>(p, repl, n_batches, fanout, n_hops, stream);
     return win_dispatch<WinItemW>(p, repl, n_batches, fanout, n_hops, stream);
+}
+
+extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
+    TG_REQUIRE(t, "tg_ns_win_tuning_get: null");
+    const tg::WinTuning &w = tg::win_tuning();
+    t->window_bytes = w.window_bytes;
+    t->gather_blocks = w.gather_blocks;
+    t->gather_threads = w.gather_threads;
+    t->emit_threads = w.emit_threads;
+    t->direct_hop0 = w.direct_hop0;
+    t->fuse_first_hops = w.fuse_first_hops;
+    return TG_OK;
+}
+
+extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
+    TG_REQUIRE(t, "tg_ns_win_tuning_set: null");
+    TG_REQUIRE(t->window_bytes == 0 || (t->window_bytes >= 64 && t->window_bytes <= ((int64_t)1 << 32)),
+               "tg_ns_win_tuning_set: window_bytes outside [64, 2^32]");
+    TG_REQUIRE(t->gather_threads == 0 || (t->gather_threads >= 64 && t->gather_threads <= 1024 && t->gather_threads % 64 == 0),
+               "tg_ns_win_tuning_set: gather_threads must be a multiple of 64 in [64, 1024]");
+    TG_REQUIRE(t->emit_threads == 0 || (t->emit_threads >= 64 && t->emit_threads <= 1024 && t->emit_threads % 64 == 0),
+               "tg_ns_win_tuning_set: emit_threads must be a multiple of 64 in [64, 1024]");
+    TG_REQUIRE(t->gather_blocks >= 0 && t->gather_blocks <= 65536, "tg_ns_win_tuning_set: gather_blocks outside [0, 65536]");
+    tg::WinTuning &w = tg::win_tuning();
+    if (t->window_bytes) w.window_bytes = t->window_bytes;
+    if (t->gather_blocks) w.gather_blocks = t->gather_blocks;
+    if (t->gather_threads) w.gather_threads = t->gather_threads;
+    if (t->emit_threads) w.emit_threads = t->emit_threads;
+    if (t->direct_hop0 >= 0) w.direct_hop0 = t->direct_hop0 != 0;
+    if (t->fuse_first_hops >= 0) w.fuse_first_hops = t->fuse_first_hops != 0;
+    return TG_OK;
+}
+
+extern "C" int tg_ns_win_stage_timing(int32_t enable) {
+    tg::win_clock().enabled = enable != 0;
+    return TG_OK;
+}
+
+extern "C" int tg_ns_win_stage_times(float *ms, char *names, int32_t cap, int32_t *n) {
+    TG_REQUIRE(n && (cap == 0 || (ms && names)), "tg_ns_win_stage_times: null arguments");
+    tg::WinStageClock &c = tg::win_clock();
+    *n = c.n;
+    if (c.n == 0) return TG_OK;
+    TG_HIP(hipEventSynchronize(c.ev[c.n]));
+    for (int i = 0; i < c.n && i < cap; ++i) {
+        TG_HIP(hipEventElapsedTime(&ms[i], c.ev[i], c.ev[i + 1]));
+        snprintf(names + (size_t)i * 24, 24, "%s", c.name[i]);
+    }
+    return TG_OK;
+}
+
+extern "C" int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                       int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out,
+                                       int64_t workspace_bytes, int32_t mode, int32_t *form, int32_t *n_windows) {
+    TG_REQUIRE(csc && out && form && (fanout || n_hops == 0), "tg_ns_homo_batched_form: null arguments");
+    TG_REQUIRE(n_hops >= 0 && n_hops <= TG_MAX_HOPS, "tg_ns_homo_batched_form: n_hops %d outside [0, %d]", n_hops, TG_MAX_HOPS);
+    *form = TG_NS_FORM_FUSED;
+    if (n_windows) *n_windows = 0;
+    const int sampler = cfg ? cfg->sampler : TG_SAMPLER_UNIFORM;
+    const int filter = cfg ? cfg->filter_mode : TG_FILTER_NONE;
+    if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE) return TG_OK; // the scanning kernels: neither form
+    if (workspace_bytes <= 0 || !tg_ns_homo_windowed_applicable(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, mode))
+        return TG_OK;
+    if ((int64_t)tg::win_layout(n_batches, n_seeds, fanout, n_hops).total > workspace_bytes) return TG_OK; // the launch would refuse
+    int32_t shift = 0, nb = 0;
+    tg::win_window_geometry(csc, &shift, &nb);
+    int slot_bits = 1;
+    while (((int64_t)1 << slot_bits) < out->cap_nodes) ++slot_bits;
+    const bool narrow = csc->n_edges < ((int64_t)1 << 32) && out->cap_edges < ((int64_t)1 << 32) && slot_bits < 32 &&
+                        n_batches <= ((int64_t)1 << (32 - slot_bits));
+    *form = (narrow && mode != TG_NS_FORM_WINDOWED_WIDE) ? TG_NS_FORM_WINDOWED : TG_NS_FORM_WINDOWED_WIDE;
+    if (n_windows) *n_windows = nb;
+    return TG_OK;
 }

@@ -27,7 +27,8 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_ns_hetero_batched", "tg_ns_homo_compact", "tg_part_workspace_bytes", "tg_part_begin",
            "tg_sanitize_range", "tg_ns_hop_segments", "tg_het_hop_begin_all", "tg_het_hop_end_all", "tg_part_requests", "tg_part_count", "tg_part_scan_workspace_bytes", "tg_part_sample", "tg_part_emit", "tg_part_unpack", "tg_part_pack", "tg_compact_rows", "tg_budget_capacity",
            "tg_budget_workspace_bytes", "tg_budget_sample", "tg_ns_homo_workspace_bytes", "tg_ns_homo_batched_ws", "tg_het_meta_words", "tg_het_step_begin",
-           "tg_het_step_end", "tg_het_hop_end"]
+           "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
+           "tg_ns_win_stage_timing", "tg_ns_win_stage_times"]
 
 
 class TgGraph(C.Structure):
@@ -182,6 +183,56 @@ def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UN
                                  fan, C.c_int32(len(fanout)), C.byref(cfg), C.byref(rng), C.byref(so),
                                  stream_ptr(seeds.device)))
     return out
+
+
+def ns_homo_batched_form(graph, out, n_batches, n_seeds, fanout, ws=None, form=0, sampler=SAMPLER_UNIFORM,
+                         filter_mode=FILTER_NONE):
+    """Which form ns_homo_batched(..., ws=ws, form=form) runs -> (form taken: 1 windowed / 2 fused / 3 windowed with wide
+    items, number of windows).  A query: nothing is launched."""
+    cfg = TgNsConfig()
+    cfg.sampler, cfg.filter_mode = sampler, filter_mode
+    fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
+    so = out.struct()
+    taken, n_win = C.c_int32(0), C.c_int32(0)
+    check(lib.tg_ns_homo_batched_form(C.byref(graph), C.c_int64(n_batches), C.c_int64(n_seeds), fan,
+                                      C.c_int32(len(fanout)), C.byref(cfg), C.byref(so),
+                                      C.c_int64(ws.numel() * 8 if ws is not None else 0), C.c_int32(form),
+                                      C.byref(taken), C.byref(n_win)))
+    return taken.value, n_win.value
+
+
+class TgNsWinTuning(C.Structure):
+    _fields_ = [("window_bytes", C.c_int64), ("gather_blocks", C.c_int32), ("gather_threads", C.c_int32),
+                ("emit_threads", C.c_int32), ("direct_hop0", C.c_int32), ("fuse_first_hops", C.c_int32)]
+
+
+def ns_win_tuning():
+    t = TgNsWinTuning()
+    check(lib.tg_ns_win_tuning_get(C.byref(t)))
+    return {k: getattr(t, k) for k, _ in TgNsWinTuning._fields_}
+
+
+def ns_win_tuning_set(**kw):
+    """Process-wide tuning of the window-ordered launch (outputs never depend on it); -> the previous values."""
+    before = ns_win_tuning()
+    t = TgNsWinTuning(0, 0, 0, 0, -1, -1)
+    for k, v in kw.items():
+        assert k in before, k
+        setattr(t, k, int(v))
+    check(lib.tg_ns_win_tuning_set(C.byref(t)))
+    return before
+
+
+def ns_win_stage_timing(enable):
+    check(lib.tg_ns_win_stage_timing(C.c_int32(int(bool(enable)))))
+
+
+def ns_win_stage_times():
+    """Stage durations (ms) of the last window-ordered launch recorded under ns_win_stage_timing(True); waits for it."""
+    cap = 80
+    ms, names, n = (C.c_float * cap)(), C.create_string_buffer(24 * cap), C.c_int32(0)
+    check(lib.tg_ns_win_stage_times(ms, names, C.c_int32(cap), C.byref(n)))
+    return [(names.raw[24 * i:24 * i + 24].split(b"\0", 1)[0].decode(), float(ms[i])) for i in range(min(n.value, cap))]
 
 
 def random_walk(graph, start, walk_length, p, q, seed, call_id):

@@ -1,0 +1,189 @@
+"""The launch form bench.py times, tested at the configuration it is timed on.
+
+bench.py's step is tg_ns_homo_batched_ws(form=auto) over thousands of 1 024-seed batches of RMAT-24 with the u32 shadows:
+the window-ordered form with ~2 056 windows, every one of the 8 XCD queues populated, several iterations of the bucket
+base scan.  Here that exact shape (2 048 batches; the launch code does not change with the batch count beyond it) is
+compared WORD FOR WORD, on the device, with the fused per-batch kernel (used prefixes of all four arrays, counts, layer
+offsets; the slabs are poison-filled first and everything beyond the used prefix must still be poison), and batches of
+it are replayed by the CPU oracle (neighbor_sampling.rs:188-223).  A mid-size case forces > 1 024 windows through the
+tuning hook so that the multi-window sort and the multi-iteration scans also run in the quick suite, and launches with an
+ODD slab pitch cover the 16-byte pair stores of the emit kernel on 8-byte-aligned slabs."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+AUTO, WINDOWED, FUSED, WINDOWED_WIDE = 0, 1, 2, 3
+POISON = -7
+
+
+@pytest.fixture(scope="module")
+def cabi():
+    from tch_geometric import _cabi
+    return _cabi
+
+
+def _rmat(cabi, scale, shadows=True):
+    dev = torch.device(DEV)
+    n = 1 << scale
+    row, col = cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
+    ptrs, idx, _ = cabi.coo_to_csx(row, col, n, n, True)
+    del row, col
+    i32 = idx.to(torch.int32) if shadows else None
+    p32 = ptrs.to(torch.int32) if shadows else None
+    return n, ptrs, idx, cabi.graph_view(ptrs, idx, indices32=i32, ptrs32=p32)
+
+
+def _poisoned(cabi, nb, B, fan):
+    o = cabi.NsBatchedOut(nb, B, fan, torch.device(DEV))
+    for t in (o.samples, o.rows, o.cols, o.edge_index):
+        t.fill_(POISON)
+    return o
+
+
+def assert_equal_on_device(a, b):
+    """every batch: counts, layer offsets, the used prefix of the four arrays equal; beyond it `a` is untouched"""
+    assert torch.equal(a.counts, b.counts) and torch.equal(a.layer_offsets, b.layer_offsets)
+    dev = a.samples.device
+    for name, col in (("samples", 0), ("rows", 1), ("cols", 1), ("edge_index", 1)):
+        x, y = getattr(a, name), getattr(b, name)
+        step = 256                                            # batches per comparison: bounds the temporaries
+        ar = torch.arange(x.shape[1], device=dev)[None, :]
+        for lo in range(0, x.shape[0], step):
+            used = ar < a.counts[lo:lo + step, col:col + 1]
+            xs, ys = x[lo:lo + step], y[lo:lo + step]
+            assert bool(((xs == ys) | ~used).all()), "%s differs in batches [%d, %d)" % (name, lo, lo + step)
+            assert bool(((xs == POISON) | used).all()), "%s written beyond its used prefix" % name
+
+
+def assert_oracle(cabi, out, ptrs, idx, seeds, fan, seed, call0, batches, sampler=0):
+    hp, hi = ptrs.cpu().numpy(), idx.cpu().numpy()
+    for j in batches:
+        o = orc.ns_homo(hp, hi, seeds[j].cpu().numpy(), fan, orc.rng_philox(seed, call0 + j), sampler=sampler)
+        x = out.batch(j)
+        assert x[4] == o[4]
+        for u, v in zip(x[:4], o[:4]):
+            assert np.array_equal(u.cpu().numpy(), v), j
+
+
+def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
+    """RMAT-24, u32 shadows, 2 048 batches x 1 024 seeds, [15, 10], form = auto: what bench.py launches"""
+    n, ptrs, idx, g = _rmat(cabi, 24)
+    nb, B, fan = 2048, 1024, [15, 10]
+    dev = torch.device(DEV)
+    seeds = cabi.seed_batches(0xBA7C4, 4096, nb, B, n, dev)
+    a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+    ws = cabi.ns_homo_workspace(nb, B, fan, dev)
+    taken, n_win = cabi.ns_homo_batched_form(g, a, nb, B, fan, ws=ws, form=AUTO)
+    assert taken == WINDOWED and n_win >= 2048, (taken, n_win)       # the 16-byte-item windowed form, ~2 056 windows
+    assert cabi.ns_win_tuning()["window_bytes"] == 512 * 1024
+    cabi.ns_homo_batched(g, seeds, fan, 0, 4096, a, ws=ws, form=AUTO)
+    cabi.ns_homo_batched(g, seeds, fan, 0, 4096, b, form=FUSED)
+    torch.cuda.synchronize()
+    assert int(a.counts[:, 1].sum()) > nb * 20000                     # ~29.5 K sampled edges per batch
+    assert_equal_on_device(a, b)
+    assert_oracle(cabi, a, ptrs, idx, seeds, fan, 0, 4096, (0, 1023, 2047))
+    # the other item form and the un-fused first hops on the same launch
+    c = _poisoned(cabi, nb, B, fan)
+    cabi.ns_homo_batched(g, seeds, fan, 0, 4096, c, ws=ws, form=WINDOWED_WIDE)
+    torch.cuda.synchronize()
+    assert_equal_on_device(c, b)
+    before = cabi.ns_win_tuning_set(fuse_first_hops=0)
+    try:
+        d = _poisoned(cabi, nb, B, fan)
+        cabi.ns_homo_batched(g, seeds, fan, 0, 4096, d, ws=ws, form=AUTO)
+        torch.cuda.synchronize()
+        assert_equal_on_device(d, b)
+    finally:
+        cabi.ns_win_tuning_set(**before)
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("shadows", [True, False])
+def test_many_windows_mid_size(cabi, sampler, shadows):
+    """RMAT-16 with 2-KiB (1-KiB without shadows... 4 KiB of i64) windows: > 2 048 windows, >= 256 per XCD queue, three
+    iterations of the base scan, 33 blocks of the column scan -- the code paths of the RMAT-24 launch in the quick suite"""
+    n, ptrs, idx, g = _rmat(cabi, 16, shadows)
+    nb, B, fan = 300, 256, [15, 10]
+    dev = torch.device(DEV)
+    seeds = cabi.seed_batches(0xBA7C4, 77, nb, B, n, dev)
+    before = cabi.ns_win_tuning_set(window_bytes=2048 if shadows else 4096)
+    try:
+        a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+        ws = cabi.ns_homo_workspace(nb, B, fan, dev)
+        taken, n_win = cabi.ns_homo_batched_form(g, a, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler)
+        assert taken == WINDOWED and n_win > 2048, (taken, n_win)
+        cabi.ns_homo_batched(g, seeds, fan, 9, 77, a, sampler=sampler, ws=ws, form=WINDOWED)
+        cabi.ns_homo_batched(g, seeds, fan, 9, 77, b, sampler=sampler, form=FUSED)
+        torch.cuda.synchronize()
+        assert_equal_on_device(a, b)
+        assert_oracle(cabi, a, ptrs, idx, seeds, fan, 9, 77, (0, 150, 299), sampler=sampler)
+        for knobs in (dict(direct_hop0=0), dict(fuse_first_hops=0), dict(gather_blocks=64, gather_threads=128)):
+            prev = cabi.ns_win_tuning_set(**knobs)
+            try:
+                c = _poisoned(cabi, nb, B, fan)
+                cabi.ns_homo_batched(g, seeds, fan, 9, 77, c, sampler=sampler, ws=ws, form=WINDOWED)
+                torch.cuda.synchronize()
+                assert_equal_on_device(c, b)
+            finally:
+                cabi.ns_win_tuning_set(**prev)
+    finally:
+        cabi.ns_win_tuning_set(**before)
+    assert cabi.ns_win_tuning() == before
+
+
+@pytest.mark.parametrize("fan,B", [([3], 3), ([3, 3, 3], 3), ([5], 7), ([1, 1, 1], 5), ([15, 9, 3], 1)])
+@pytest.mark.parametrize("direct", [1, 0])
+def test_odd_slab_pitch(cabi, fan, B, direct):
+    """odd cap_edges: the slabs of odd batches start on an odd element, i.e. 8-byte-aligned; the emit kernel's 16-byte pair
+    stores take their alignment from the address (ns_homo_win.hip)"""
+    n, ptrs, idx, g = _rmat(cabi, 12)
+    nb = 9
+    dev = torch.device(DEV)
+    assert cabi.ns_homo_capacity(B, fan)[1] % 2 == 1
+    seeds = cabi.seed_batches(0xBA7C4, 5, nb, B, n, dev)
+    seeds[:, 0] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))            # a hub in every batch: columns longer than the fan-out
+    before = cabi.ns_win_tuning_set(direct_hop0=direct)
+    try:
+        a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+        ws = cabi.ns_homo_workspace(nb, B, fan, dev)
+        assert cabi.ns_homo_batched_form(g, a, nb, B, fan, ws=ws, form=WINDOWED)[0] == WINDOWED
+        cabi.ns_homo_batched(g, seeds, fan, 2, 5, a, ws=ws, form=WINDOWED)
+        cabi.ns_homo_batched(g, seeds, fan, 2, 5, b, form=FUSED)
+        torch.cuda.synchronize()
+        assert_equal_on_device(a, b)
+        assert_oracle(cabi, a, ptrs, idx, seeds, fan, 2, 5, range(nb))
+    finally:
+        cabi.ns_win_tuning_set(**before)
+
+
+def test_form_query(cabi):
+    n, ptrs, idx, g = _rmat(cabi, 12)
+    dev = torch.device(DEV)
+    out = cabi.NsBatchedOut(4, 64, [15, 10], dev)
+    ws = cabi.ns_homo_workspace(4, 64, [15, 10], dev)
+    assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=None, form=WINDOWED)[0] == FUSED     # no workspace
+    assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=ws, form=AUTO)[0] == FUSED          # too small to pay
+    assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=ws, form=WINDOWED)[0] == WINDOWED
+    assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=ws, form=WINDOWED_WIDE)[0] == WINDOWED_WIDE
+    assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=ws, form=WINDOWED, sampler=2)[0] == FUSED
+    assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=ws[:8], form=WINDOWED)[0] == FUSED
+
+
+def test_stage_times(cabi):
+    n, ptrs, idx, g = _rmat(cabi, 14)
+    dev = torch.device(DEV)
+    nb, B, fan = 64, 128, [15, 10]
+    seeds = cabi.seed_batches(0xBA7C4, 0, nb, B, n, dev)
+    out, ws = cabi.NsBatchedOut(nb, B, fan, dev), cabi.ns_homo_workspace(nb, B, fan, dev)
+    cabi.ns_win_stage_timing(True)
+    try:
+        cabi.ns_homo_batched(g, seeds, fan, 0, 0, out, ws=ws, form=WINDOWED)
+        st = cabi.ns_win_stage_times()
+    finally:
+        cabi.ns_win_stage_timing(False)
+    names = [s for s, _ in st]
+    assert names[0].startswith("first_hops") and names[-1] == "gather.h1" and all(ms >= 0 for _, ms in st)
