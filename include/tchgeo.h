@@ -151,7 +151,7 @@ TG_API int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, int64
                             int32_t mode, int32_t *form, int32_t *n_windows);
 
 /* Tuning of the window-ordered form (process-wide; defaults come from TG_WIN_* environment variables read once).
- * Outputs never depend on it.  _set: a zero field (negative for the two flags) keeps the current value. */
+ * Outputs never depend on it.  _set: a zero field (negative for the three flags) keeps the current value. */
 typedef struct {
     int64_t window_bytes;    /* bytes of the gathered array per window (default 512 KiB) */
     int32_t gather_blocks;   /* workgroups of the persistent gather kernel (default 256) */
@@ -159,6 +159,9 @@ typedef struct {
     int32_t emit_threads;    /* workgroup size of the emit kernels (default 256) */
     int32_t direct_hop0;     /* hop 0 issues its gathers itself, unordered (default 1) */
     int32_t fuse_first_hops; /* seeds + hop 0 + hop 1's emit pass in one kernel (default 1) */
+    int32_t fold_hist;       /* emit kernels persistent, window histogram of the items kept in LDS instead of a pass of its
+                                own over the items (default 1; needs the two flags above and >= 2 hops) */
+    int32_t emit_blocks;     /* workgroups of the persistent emit kernels (default 768, at most 1024) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);
@@ -605,6 +608,13 @@ TG_API int tg_compact_rows(const int64_t *src, int64_t pitch, const int64_t *len
  * independent random 8-byte loads from table[0..n_table); sink: [n_threads]. */
 TG_API int tg_probe_random_gather(const int64_t *table, int64_t n_table, int64_t n_threads, int64_t per_thread,
                                   uint64_t seed, int64_t *sink, void *stream);
+
+/* Harness calibration: the speed of light of neighbor_sampling_homogenous's output contract.  Moves the ALGORITHMIC bytes
+ * of a finished launch `src` (per seed 8 B read + 8 B written, per expanded frontier slot 24 B read, per sampled edge 8 B
+ * read + 32 B written) as pure streams into the slabs `dst` (same pitch, other memory) -- precomputed contents,
+ * no draws, no random access, no ordering.  sink: [n_batches]. */
+TG_API int tg_probe_ns_sol(const tg_ns_out *src, const tg_ns_out *dst, const int64_t *seeds, int64_t n_batches,
+                           int64_t n_seeds, int32_t n_hops, int64_t *sink, void *stream);
 
 #ifdef __cplusplus
 }

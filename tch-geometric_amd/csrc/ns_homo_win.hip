@@ -26,6 +26,8 @@
 // path with the fused kernel and the oracle bit for bit).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ns_tickets.h"
 #include "tg_device.h"
 #include "tg_host.h"
@@ -36,6 +38,7 @@ constexpr int WIN_PART_BLOCKS = 512;  // blocks of the partition kernels = rows 
 constexpr int WIN_PART_THREADS = 512;
 constexpr int WIN_TILE = 4096;        // items per partition tile
 constexpr int WIN_MAX_BUCKETS = 8192; // windows per hop (LDS: 32 KB of counters)
+constexpr int WIN_MAX_ROWS = 1024;    // rows of the histogram matrix in the folded form (= persistent emit workgroups)
 
 struct WinState { // per batch, lives in the workspace
     int64_t begin, end, ne, fbase;
@@ -53,7 +56,7 @@ struct WinParams {
     const uint32_t *indices32;
     const uint32_t *ptrs32;
     const int64_t *seeds;
-    int64_t n_seeds;
+    int64_t n_seeds, n_batches;
     int32_t n_hops, hop, k, kmax;
     int64_t cap_nodes, cap_edges;
     int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts;
@@ -70,6 +73,10 @@ struct WinParams {
     WinQueues *queues;
     int32_t n_buckets, shift; // bucket count (multiple of 8), window = e0 >> shift
     int32_t slot_bits;        // narrow items: slot in the low bits, batch above
+    // folded histogram (win_tuning().fold_hist): the emit kernels are persistent -- workgroup r walks batches r, r + n_rows,
+    // ... and keeps the window histogram of their items in LDS (row r of `hist`); batch b's items lie at b * item_pitch
+    int32_t n_rows;
+    int64_t item_pitch;
 };
 
 // One frontier vertex with something to sample.  Narrow form: launches whose edge pointers and per-batch offsets fit 32
@@ -144,9 +151,10 @@ __host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
 // buys nothing; deeper frontiers are drawn by degree, repeat the hubs and touch every line ~13 times.
 // One hop of one batch by one workgroup; returns the batch's state after the hop.  `hop` / `k` are arguments (not
 // p.hop / p.k) so that one kernel can run consecutive hops of its batch back to back.
-template <typename Item, int KMAX, bool REPLACE, bool DIRECT>
+template <typename Item, int KMAX, bool REPLACE, bool DIRECT, bool FOLD = false>
 __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned char *smem, const int64_t b, const int hop,
-                                                 const int k, const WinState st, const CallKey ck) {
+                                                 const int k, const WinState st, const CallKey ck,
+                                                 uint32_t *lhist = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
     const size_t off_bytes = (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
@@ -172,10 +180,10 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
         lo[1] = ne;
         lo[2] = n_seeds + ne;
         // this batch's range of the hop's flat item array (order between batches does not matter)
-        *shared_fbase = DIRECT ? 0 : (int64_t)atomicAdd(&p.n_items[hop], (unsigned long long)(end - begin));
+        if (!FOLD) *shared_fbase = DIRECT ? 0 : (int64_t)atomicAdd(&p.n_items[hop], (unsigned long long)(end - begin));
     }
-    __syncthreads();
-    const int64_t fbase = *shared_fbase;
+    if (!FOLD) __syncthreads();
+    const int64_t fbase = FOLD ? b * p.item_pitch : *shared_fbase;
 
     for (int64_t round_begin = begin; round_begin < end; round_begin += WIN_ROUND_SLOTS) {
         const int64_t round_end = min(end, round_begin + (int64_t)WIN_ROUND_SLOTS);
@@ -218,9 +226,11 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
             const uint32_t excl = incl - cnt;
             const uint32_t total = __shfl(incl, 63, 64);
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
-            if (!DIRECT && i < round_end)
+            if (!DIRECT && i < round_end) {
                 items[fbase + (i - begin)] =
                     Item::make((uint64_t)e0, n, (uint32_t)b, (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
+                if (FOLD && n) atomicAdd(&lhist[win_bucket((uint64_t)e0, p.shift, p.n_buckets)], 1u);
+            }
             if (cnt > 0) {
                 if (REPLACE) { // sampling.rs:57-69
                     Draw d;
@@ -319,7 +329,7 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
         ne += chunk_off[nc];
         __syncthreads();
     }
-    return WinState{end, n_seeds + ne, ne, fbase}; // :221-222
+    return WinState{end, n_seeds + ne, ne, FOLD ? begin : fbase}; // :221-222  (FOLD: .fbase = where this hop's frontier began)
 }
 
 __device__ __forceinline__ void win_store_state(const WinParams &p, int64_t b, int hop, const WinState &st) {
@@ -363,6 +373,76 @@ __global__ void win_first_hops_kernel(const WinParams p, const int k0, const int
         win_store_state(p, b, 0, st);
 }
 
+
+// Folded-histogram forms (persistent): workgroup r walks batches r, r + gridDim.x, ...; the window histogram of the
+// items it writes accumulates in LDS and leaves as row r of `hist` -- the separate histogram pass over the items (and the
+// atomics that dealt out item ranges) are gone.  win_scatter_fold_kernel walks the same batches per row.
+template <typename Item, int KMAX, bool REPLACE>
+__global__ void win_emit_fold_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + win_emit_lds_bytes(p.kmax, blockDim.x >> 6));
+    for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) lhist[i] = 0;
+    __syncthreads();
+    for (int64_t b = blockIdx.x; b < p.n_batches; b += gridDim.x) {
+        const WinState st =
+            win_emit_hop<Item, KMAX, REPLACE, false, true>(p, smem, b, p.hop, p.k, p.state[b], p.call_keys[b], lhist);
+        win_store_state(p, b, p.hop, st);
+    }
+    __syncthreads();
+    uint32_t *row = p.hist + (size_t)blockIdx.x * p.n_buckets;
+    for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) row[i] = lhist[i];
+}
+
+template <typename Item, int KMAX, bool REPLACE>
+__global__ void win_first_hops_fold_kernel(const WinParams p, const int k0, const int k1) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + win_emit_lds_bytes(p.kmax, blockDim.x >> 6));
+    for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) lhist[i] = 0;
+    for (int64_t b = blockIdx.x; b < p.n_batches; b += gridDim.x) {
+        int64_t *samples = p.samples + b * p.cap_nodes;
+        for (int64_t i = threadIdx.x; i < p.n_seeds; i += blockDim.x) samples[i] = p.seeds[b * p.n_seeds + i]; // :184
+        const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
+        if (threadIdx.x == 0) p.call_keys[b] = ck;
+        __syncthreads();
+        WinState st = win_emit_hop<Item, KMAX, REPLACE, true>(p, smem, b, 0, k0, WinState{0, p.n_seeds, 0, 0}, ck);
+        __syncthreads();
+        st = win_emit_hop<Item, KMAX, REPLACE, false, true>(p, smem, b, 1, k1, st, ck, lhist);
+        win_store_state(p, b, 1, st);
+        __syncthreads(); // the LDS staging of this batch is done before the next batch reuses it
+    }
+    __syncthreads();
+    uint32_t *row = p.hist + (size_t)blockIdx.x * p.n_buckets;
+    for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) row[i] = lhist[i];
+}
+
+template <typename Item>
+__global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter_fold_kernel(const WinParams p) {
+    __shared__ uint32_t cur[WIN_MAX_BUCKETS];
+    const int nb = p.n_buckets;
+    const Item *items = static_cast<const Item *>(p.items_in);
+    Item *sorted = static_cast<Item *>(p.items_sorted);
+    const uint32_t *row = p.hist + (size_t)blockIdx.x * nb;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) cur[i] = p.base[i] + row[i];
+    __syncthreads();
+    constexpr int U = 4; // items per thread and round, all loads in flight together
+    for (int64_t b = blockIdx.x; b < p.n_batches; b += gridDim.x) {
+        const WinState st = p.state[b];
+        const int64_t n = st.begin - st.fbase; // the frontier the emit pass just walked
+        const Item *src = items + b * p.item_pitch;
+        for (int64_t t0 = 0; t0 < n; t0 += (int64_t)U * WIN_PART_THREADS) {
+            Item it[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = t0 + (int64_t)u * WIN_PART_THREADS + threadIdx.x;
+                it[u].deg = 0;
+                if (j < n) it[u] = src[j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (it[u].deg) sorted[atomicAdd(&cur[win_bucket(it[u].col(), p.shift, nb)], 1u)] = it[u];
+        }
+    }
+}
 
 // ---------------------------------------------------------------- P1: per-block bucket histogram of the hop's items
 template <typename Item>
@@ -607,7 +687,7 @@ static int win_env_int(const char *name, int dflt) {
 // it to force many small windows on a small graph).  Outputs never depend on any of these.
 struct WinTuning {
     int64_t window_bytes;
-    int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops;
+    int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -617,6 +697,8 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_EMIT_THREADS", 256),
         win_env_int("TG_WIN_DIRECT_HOP0", 1),
         win_env_int("TG_WIN_FUSE_FIRST_HOPS", 1),
+        win_env_int("TG_WIN_FOLD_HIST", 1),
+        win_env_int("TG_WIN_EMIT_BLOCKS", 768),
     };
     return t;
 }
@@ -671,7 +753,7 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
     L.call_keys = take((size_t)n_batches * sizeof(CallKey));
     L.n_items = take(TG_MAX_HOPS * sizeof(unsigned long long));
     L.queues = take(sizeof(WinQueues));
-    L.hist = take((size_t)WIN_PART_BLOCKS * WIN_MAX_BUCKETS * sizeof(uint32_t));
+    L.hist = take((size_t)WIN_MAX_ROWS * WIN_MAX_BUCKETS * sizeof(uint32_t));
     L.base = take((size_t)(WIN_MAX_BUCKETS + 1) * sizeof(uint32_t));
     L.items_in = take((size_t)L.max_items * sizeof(WinItemW)); // sized for the wide form
     L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
@@ -684,19 +766,36 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
     const WinTuning t = win_tuning();
     WinStageClock &clk = win_clock();
     const int gather_blocks = (t.gather_blocks + 7) & ~7; // 8 groups of equal size
+    // folded histogram: needs a second hop (hop 0 has no items) and the fused first hops
+    const bool fold = t.fold_hist && t.direct_hop0 && t.fuse_first_hops && n_hops > 1;
+    const size_t hist_lds = fold ? (size_t)p.n_buckets * sizeof(uint32_t) : 0;
     auto emit_threads_for = [&]() {
         int threads = t.emit_threads;
-        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
+        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) + hist_lds > 64 * 1024)
+            threads = ((threads >> 1) + 63) & ~63;
         return threads;
+    };
+    p.n_batches = n_batches;
+    p.n_rows = (int32_t)std::min<int64_t>(std::min(std::max(t.emit_blocks, 1), WIN_MAX_ROWS), n_batches);
+    auto pitch_of = [&](int h) { // worst-case frontier of hop h per batch
+        int64_t f = p.n_seeds;
+        for (int j = 0; j < h; ++j) f *= fanout[j];
+        return f;
     };
     clk.begin(stream);
     int h0 = 0;
     if (t.direct_hop0 && t.fuse_first_hops) { // seeds, hop 0 (direct) and hop 1's emit pass by one kernel
-        TG_HIP(hipMemsetAsync(p.n_items, 0, TG_MAX_HOPS * sizeof(unsigned long long), stream));
         const int threads = emit_threads_for();
-        hipLaunchKernelGGL((win_first_hops_kernel<Item, KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
-                           win_emit_lds_bytes(p.kmax, threads / 64), stream, p, (int)fanout[0],
-                           n_hops > 1 ? (int)fanout[1] : 0);
+        if (fold) {
+            p.item_pitch = pitch_of(1);
+            hipLaunchKernelGGL((win_first_hops_fold_kernel<Item, KMAX, REPLACE>), dim3((unsigned)p.n_rows), dim3(threads),
+                               win_emit_lds_bytes(p.kmax, threads / 64) + hist_lds, stream, p, (int)fanout[0], (int)fanout[1]);
+        } else {
+            TG_HIP(hipMemsetAsync(p.n_items, 0, TG_MAX_HOPS * sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL((win_first_hops_kernel<Item, KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
+                               win_emit_lds_bytes(p.kmax, threads / 64), stream, p, (int)fanout[0],
+                               n_hops > 1 ? (int)fanout[1] : 0);
+        }
         TG_LAUNCH_CHECK();
         clk.mark("first_hops", 0, stream);
         h0 = 1;
@@ -708,6 +807,7 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
     for (int h = h0; h < n_hops; ++h) {
         p.hop = h;
         p.k = (int32_t)fanout[h];
+        p.item_pitch = pitch_of(h);
         const bool emitted = (h == 1 && h0 == 1); // the fused kernel already ran hop 1's emit pass
         if (!emitted) {
             const int threads = emit_threads_for();
@@ -718,21 +818,30 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
                 clk.mark("emit_direct", h, stream);
                 continue;
             }
-            hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, false>), dim3((unsigned)n_batches), dim3(threads),
-                               win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
+            if (fold)
+                hipLaunchKernelGGL((win_emit_fold_kernel<Item, KMAX, REPLACE>), dim3((unsigned)p.n_rows), dim3(threads),
+                                   win_emit_lds_bytes(p.kmax, threads / 64) + hist_lds, stream, p);
+            else
+                hipLaunchKernelGGL((win_emit_kernel<Item, KMAX, REPLACE, false>), dim3((unsigned)n_batches),
+                                   dim3(threads), win_emit_lds_bytes(p.kmax, threads / 64), stream, p);
             TG_LAUNCH_CHECK();
             clk.mark("emit", h, stream);
         }
-        hipLaunchKernelGGL(win_hist_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
-        TG_LAUNCH_CHECK();
-        clk.mark("hist", h, stream);
+        if (!fold) {
+            hipLaunchKernelGGL(win_hist_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
+            TG_LAUNCH_CHECK();
+            clk.mark("hist", h, stream);
+        }
         hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
-                           WIN_PART_BLOCKS);
+                           fold ? p.n_rows : WIN_PART_BLOCKS);
         TG_LAUNCH_CHECK();
         hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
         TG_LAUNCH_CHECK();
         clk.mark("scans", h, stream);
-        hipLaunchKernelGGL(win_scatter_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
+        if (fold)
+            hipLaunchKernelGGL(win_scatter_fold_kernel<Item>, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL(win_scatter_kernel<Item>, dim3(WIN_PART_BLOCKS), dim3(WIN_PART_THREADS), 0, stream, p);
         TG_LAUNCH_CHECK();
         clk.mark("scatter", h, stream);
         int gthreads = t.gather_threads;
@@ -865,6 +974,8 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->emit_threads = w.emit_threads;
     t->direct_hop0 = w.direct_hop0;
     t->fuse_first_hops = w.fuse_first_hops;
+    t->fold_hist = w.fold_hist;
+    t->emit_blocks = w.emit_blocks;
     return TG_OK;
 }
 
@@ -884,6 +995,8 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->emit_threads) w.emit_threads = t->emit_threads;
     if (t->direct_hop0 >= 0) w.direct_hop0 = t->direct_hop0 != 0;
     if (t->fuse_first_hops >= 0) w.fuse_first_hops = t->fuse_first_hops != 0;
+    if (t->fold_hist >= 0) w.fold_hist = t->fold_hist != 0;
+    if (t->emit_blocks > 0) w.emit_blocks = t->emit_blocks;
     return TG_OK;
 }
 

@@ -28,7 +28,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_sanitize_range", "tg_ns_hop_segments", "tg_het_hop_begin_all", "tg_het_hop_end_all", "tg_part_requests", "tg_part_count", "tg_part_scan_workspace_bytes", "tg_part_sample", "tg_part_emit", "tg_part_unpack", "tg_part_pack", "tg_compact_rows", "tg_budget_capacity",
            "tg_budget_workspace_bytes", "tg_budget_sample", "tg_ns_homo_workspace_bytes", "tg_ns_homo_batched_ws", "tg_het_meta_words", "tg_het_step_begin",
            "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
-           "tg_ns_win_stage_timing", "tg_ns_win_stage_times"]
+           "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol"]
 
 
 class TgGraph(C.Structure):
@@ -203,7 +203,8 @@ def ns_homo_batched_form(graph, out, n_batches, n_seeds, fanout, ws=None, form=0
 
 class TgNsWinTuning(C.Structure):
     _fields_ = [("window_bytes", C.c_int64), ("gather_blocks", C.c_int32), ("gather_threads", C.c_int32),
-                ("emit_threads", C.c_int32), ("direct_hop0", C.c_int32), ("fuse_first_hops", C.c_int32)]
+                ("emit_threads", C.c_int32), ("direct_hop0", C.c_int32), ("fuse_first_hops", C.c_int32),
+                ("fold_hist", C.c_int32), ("emit_blocks", C.c_int32)]
 
 
 def ns_win_tuning():
@@ -215,7 +216,7 @@ def ns_win_tuning():
 def ns_win_tuning_set(**kw):
     """Process-wide tuning of the window-ordered launch (outputs never depend on it); -> the previous values."""
     before = ns_win_tuning()
-    t = TgNsWinTuning(0, 0, 0, 0, -1, -1)
+    t = TgNsWinTuning(0, 0, 0, 0, -1, -1, -1, 0)
     for k, v in kw.items():
         assert k in before, k
         setattr(t, k, int(v))
@@ -434,6 +435,15 @@ def probe_random_gather(table, n_threads, per_thread, seed=1):
     sink = torch.empty(n_threads, dtype=torch.int64, device=table.device)
     check(lib.tg_probe_random_gather(ptr(table), C.c_int64(table.numel()), C.c_int64(n_threads),
                                      C.c_int64(per_thread), C.c_uint64(seed), ptr(sink), stream_ptr(table.device)))
+    return sink
+
+
+def probe_ns_sol(src, dst, seeds, n_hops):
+    """The algorithmic bytes of the finished launch `src` moved as pure streams into `dst` (tg_probe_ns_sol)."""
+    sink = torch.zeros(seeds.shape[0], dtype=torch.int64, device=seeds.device)
+    a, b = src.struct(), dst.struct()
+    check(lib.tg_probe_ns_sol(C.byref(a), C.byref(b), ptr(seeds), C.c_int64(seeds.shape[0]), C.c_int64(seeds.shape[1]),
+                              C.c_int32(n_hops), ptr(sink), stream_ptr(seeds.device)))
     return sink
 
 

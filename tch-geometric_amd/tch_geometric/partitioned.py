@@ -135,8 +135,9 @@ class PartitionedSampler:
 
     Per hop: tg_part_requests -> [sizes, requests all-to-all] -> tg_part_count / tg_part_sample (owner: compact replies
     = per-request counts + (neighbour, global edge pointer) pairs) -> [counts, reply sizes, replies all-to-all] ->
-    tg_part_emit.  Every size lives on the device; with world == 1 nothing is read back at all, with world > 1 the host
-    reads only the all-to-all split sizes (two small read-backs per hop).  The returned `_cabi.NsBatchedOut` equals
+    tg_part_emit.  Every size lives on the device; with world == 1 the plain samplers read nothing back at all (filters /
+    weights: one status word when the call ends), with world > 1 the host reads only the all-to-all split sizes (two small
+    read-backs per hop).  The returned `_cabi.NsBatchedOut` equals
     the replicated-graph sampler's bit for bit."""
 
     def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None,
@@ -179,6 +180,8 @@ class PartitionedSampler:
         self.send_counts = torch.zeros(self.world + 1, **i64)
         self.reply_counts = torch.zeros(self.world + 1, **i64)
         self._bufs = {}
+        self._status_acc = torch.zeros(1, dtype=torch.int32, device=self.dev)   # OR of every hop's status word of a call
+        self._group_mult = 1                                                     # column-group workspace guess, x8 on overflow
         self.exchange = self.world > 1 or bool(force_exchange)
         if force_exchange and not (dist.is_available() and dist.is_initialized()):
             raise ValueError("force_exchange needs an initialised process group")
@@ -248,37 +251,68 @@ class PartitionedSampler:
         flt.states = got_states.data_ptr() if self.filtered else None
         rng = _cabi.TgRng(seed, 0)
         nbytes = C.c_int64(0)
-        mult = 1
-        while True:
-            status.zero_()
-            weighted = self.sampler == _cabi.SAMPLER_WEIGHTED
-            group_cap = 1 if weighted else mult * max(1024, graph.n_edges // 512 + 2 * m_cap + 2)
-            _cabi.check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m_cap), C.c_int32(k), C.c_int64(group_cap),
-                                                           C.byref(nbytes)))
-            ws = self._buf("g_ws", nbytes.value // 8 + 1, i64)
-            if weighted:
-                _cabi.check(lib.tg_ns_hop_weighted(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
-                                                   ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), stream))
-                break
+        weighted = self.sampler == _cabi.SAMPLER_WEIGHTED
+        # the column-group workspace is a guess (a vertex requested many times counts its groups every time); a hop whose
+        # guess was too low raises status bit 1 and samples nothing -- sample() sees it in the call's ONE read-back,
+        # enlarges the guess (kept for later calls) and runs the call again: no read-back per hop
+        group_cap = 1 if weighted else self._group_mult * max(1024, graph.n_edges // 512 + 2 * m_cap + 2)
+        _cabi.check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m_cap), C.c_int32(k), C.c_int64(group_cap),
+                                                       C.byref(nbytes)))
+        ws = self._buf("g_ws", nbytes.value // 8 + 1, i64)
+        status.zero_()
+        if weighted:
+            _cabi.check(lib.tg_ns_hop_weighted(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
+                                               ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), stream))
+        else:
             _cabi.check(lib.tg_ns_hop_scan(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
                                            ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), C.c_int64(group_cap),
                                            stream))
-            if int(status[0]) & 1 and mult < 4096:   # the column-group guess was too low (rare): larger workspace
-                mult *= 8
-                continue
-            break
+        self._status_acc.bitwise_or_(status)          # on the device: every hop's word survives to the end of the call
         cnt = self._buf("cnt", m_cap, torch.int32)
         reply = self._buf("reply", m_cap * k, i64, self.reply_words)
         _cabi.check(lib.tg_part_pack(C.byref(hout), ptr(st_out) if self.filtered else None, ptr(m_dev), C.c_int64(m_cap),
                                      C.c_int64(shard.e_lo), C.c_int32(self.world), seg, ptr(cnt), ptr(reply),
                                      C.c_int32(self.reply_format), ptr(self.reply_counts), stream))
-        self._weighted_status = status
         return cnt, hoff, reply
 
     def sample(self, seeds, seed, first_call_id, first_call_ids=None, seeds_state=None):
         """seeds: [n_batches, n_seeds] int64 on the shard's device; batch j draws with call id first_call_id + j.
         first_call_ids: every rank's first call id (list), if the caller knows them; else they are all-gathered.
-        seeds_state: [n_batches, n_seeds] filter states of the seeds (with a temporal filter)."""
+        seeds_state: [n_batches, n_seeds] filter states of the seeds (with a temporal filter).
+
+        Unweighted, unfiltered sampling reads nothing back (world == 1) -- it has no way to fail.  Under a filter / with
+        weights the owner-side hops report through a status word that is OR-ed on the device over ALL hops of the call and
+        read back once when the call ends (all ranks agree on it first: every rank raises or repeats together):
+        bit 2 = a non-positive running weight sum in ANY hop -> RuntimeError (the reference panics, sampling.rs:49);
+        bit 1 = a hop's column-group workspace was too small -> the guess grows 8x and the call runs again."""
+        if not self.general:
+            return self._sample_once(seeds, seed, first_call_id, first_call_ids, seeds_state)
+        while True:
+            self._status_acc.zero_()
+            out = self._sample_once(seeds, seed, first_call_id, first_call_ids, seeds_state)
+            word = self._agreed_status()
+            if word & 2:
+                raise RuntimeError("weighted sampling met a non-positive running weight sum (the reference panics here)")
+            if not word & 1:
+                return out
+            if self._group_mult >= 4096:
+                raise RuntimeError("tg_ns_hop_scan: column-group workspace overflow that enlarging does not cure")
+            self._group_mult *= 8
+
+    def _agreed_status(self):
+        """the call's status word, OR-ed over the ranks (as a MAX per bit: RCCL has no bitwise reductions); one read-back"""
+        bits = torch.stack([self._status_acc[0] & 1, (self._status_acc[0] >> 1) & 1]).to(torch.int64)
+        if self.exchange and self.world > 1:
+            if self.gloo:
+                host = bits.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+                bits = host
+            else:
+                dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+        b = bits.tolist()
+        return int(b[0]) | (int(b[1]) << 1)
+
+    def _sample_once(self, seeds, seed, first_call_id, first_call_ids=None, seeds_state=None):
         C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
         world, nb, B, H = self.world, self.nb, self.B, len(self.fanout)
         assert tuple(seeds.shape) == (nb, B) and seeds.device == self.dev
@@ -340,8 +374,6 @@ class PartitionedSampler:
                                          C.c_int64(cap), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
                                          ptr(self.ws), ptr(cnt_back), None if self.exchange else ptr(off), ptr(reply_back),
                                          C.c_int32(self.reply_format), stream))
-        if self.sampler == _cabi.SAMPLER_WEIGHTED and int(self._weighted_status[0]) & 2:   # sampling.rs:49
-            raise RuntimeError("weighted sampling met a non-positive running weight sum (the reference panics here)")
         return self.out
 
     def _owner_uniform(self, graph, got, m_dev, m_cap, seg, call0, k, seed, stream):

@@ -91,14 +91,15 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
     cabi.ns_homo_batched(g, seeds, fan, 0, 4096, c, ws=ws, form=WINDOWED_WIDE)
     torch.cuda.synchronize()
     assert_equal_on_device(c, b)
-    before = cabi.ns_win_tuning_set(fuse_first_hops=0)
-    try:
-        d = _poisoned(cabi, nb, B, fan)
-        cabi.ns_homo_batched(g, seeds, fan, 0, 4096, d, ws=ws, form=AUTO)
-        torch.cuda.synchronize()
-        assert_equal_on_device(d, b)
-    finally:
-        cabi.ns_win_tuning_set(**before)
+    for knobs in (dict(fold_hist=0), dict(fuse_first_hops=0)):      # the round-2 pipeline: separate histogram pass / kernels
+        before = cabi.ns_win_tuning_set(**knobs)
+        try:
+            d = _poisoned(cabi, nb, B, fan)
+            cabi.ns_homo_batched(g, seeds, fan, 0, 4096, d, ws=ws, form=AUTO)
+            torch.cuda.synchronize()
+            assert_equal_on_device(d, b)
+        finally:
+            cabi.ns_win_tuning_set(**before)
 
 
 @pytest.mark.parametrize("sampler", [0, 1])
@@ -121,7 +122,8 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
         torch.cuda.synchronize()
         assert_equal_on_device(a, b)
         assert_oracle(cabi, a, ptrs, idx, seeds, fan, 9, 77, (0, 150, 299), sampler=sampler)
-        for knobs in (dict(direct_hop0=0), dict(fuse_first_hops=0), dict(gather_blocks=64, gather_threads=128)):
+        for knobs in (dict(direct_hop0=0), dict(fuse_first_hops=0), dict(fold_hist=0), dict(emit_blocks=7),
+                      dict(emit_blocks=1000, emit_threads=128), dict(gather_blocks=64, gather_threads=128)):
             prev = cabi.ns_win_tuning_set(**knobs)
             try:
                 c = _poisoned(cabi, nb, B, fan)
