@@ -151,7 +151,7 @@ TG_API int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, int64
                             int32_t mode, int32_t *form, int32_t *n_windows);
 
 /* Tuning of the window-ordered form (process-wide; defaults come from TG_WIN_* environment variables read once).
- * Outputs never depend on it.  _set: a zero field (negative for the three flags) keeps the current value. */
+ * Outputs never depend on it.  _set: a zero field (negative for the four flags) keeps the current value. */
 typedef struct {
     int64_t window_bytes;    /* bytes of the gathered array per window (default 512 KiB) */
     int32_t gather_blocks;   /* workgroups of the persistent gather kernel (default 256) */
@@ -162,6 +162,12 @@ typedef struct {
     int32_t fold_hist;       /* emit kernels persistent, window histogram of the items kept in LDS instead of a pass of its
                                 own over the items (default 1; needs the two flags above and >= 2 hops) */
     int32_t emit_blocks;     /* workgroups of the persistent emit kernels (default 768, at most 1024) */
+    int32_t staged;          /* gather first, emit afterwards through 64-byte stage slots (default 1; launches it does not
+                                fit -- ordered fan-outs > 30, ids beyond 32 bits -- take the push form) */
+    int32_t stage_round_chunks;   /* staged emit kernel: 64-slot chunks per round (default 8, at most 16) */
+    int32_t stage_gather_threads; /* staged gather kernel: workgroup size (default 512) */
+    int32_t stage_gather_blocks;  /* ... and workgroups (default 512) */
+    int32_t stage_emit_threads;   /* staged emit kernel: workgroup size (default 256) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

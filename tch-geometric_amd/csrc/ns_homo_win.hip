@@ -77,6 +77,11 @@ struct WinParams {
     // ... and keeps the window histogram of their items in LDS (row r of `hist`); batch b's items lie at b * item_pitch
     int32_t n_rows;
     int64_t item_pitch;
+    // staged form (ns_homo_stage.inl)
+    uint32_t *vtab;  // [n_windows] first vertex whose column starts in window i or later
+    uint32_t *stage; // [max_items][stage_words] {column start, degree, neighbours}
+    int32_t n_windows, idx_bits, next_idx_bits;
+    int64_t next_pitch;
 };
 
 // One frontier vertex with something to sample.  Narrow form: launches whose edge pointers and per-batch offsets fit 32
@@ -151,7 +156,10 @@ __host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
 // buys nothing; deeper frontiers are drawn by degree, repeat the hubs and touch every line ~13 times.
 // One hop of one batch by one workgroup; returns the batch's state after the hop.  `hop` / `k` are arguments (not
 // p.hop / p.k) so that one kernel can run consecutive hops of its batch back to back.
-template <typename Item, int KMAX, bool REPLACE, bool DIRECT, bool FOLD = false>
+__device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v); // staged form
+
+// NEXT (DIRECT only; staged form): every new sample is also handed to the next hop as an 8-byte item.
+template <typename Item, int KMAX, bool REPLACE, bool DIRECT, bool FOLD = false, bool NEXT = false>
 __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned char *smem, const int64_t b, const int hop,
                                                  const int k, const WinState st, const CallKey ck,
                                                  uint32_t *lhist = nullptr) {
@@ -276,6 +284,7 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
                             __builtin_nontemporal_store(n_seeds + e, &rows[e]);
                             __builtin_nontemporal_store(i0 + (int64_t)l4[u], &cols[e]);
                             __builtin_nontemporal_store(ep[u], &eidx[e]);
+                            if (NEXT) win_next_item(p, b, (uint32_t)(n_seeds + e - end), (uint32_t)v[u]);
                         }
                     }
                 }
@@ -678,6 +687,12 @@ __global__ void win_gather_kernel(const WinParams p) {
     }
 }
 
+#include "ns_homo_stage.inl"
+
+__device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v) {
+    static_cast<WinItem8 *>(p.items_in)[b * p.next_pitch + rel] = WinItem8{v, ((uint32_t)b << p.next_idx_bits) | rel};
+}
+
 static int win_env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -688,6 +703,7 @@ static int win_env_int(const char *name, int dflt) {
 struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
+    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -699,6 +715,11 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_FUSE_FIRST_HOPS", 1),
         win_env_int("TG_WIN_FOLD_HIST", 1),
         win_env_int("TG_WIN_EMIT_BLOCKS", 768),
+        win_env_int("TG_WIN_STAGED", 1),
+        win_env_int("TG_WIN_STAGE_ROUND_CHUNKS", 8),
+        win_env_int("TG_WIN_STAGE_GATHER_THREADS", 512),
+        win_env_int("TG_WIN_STAGE_GATHER_BLOCKS", 512),
+        win_env_int("TG_WIN_STAGE_EMIT_THREADS", 256),
     };
     return t;
 }
@@ -731,9 +752,17 @@ static WinStageClock &win_clock() {
 }
 
 struct WinLayout {
-    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, total;
+    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, stage, total;
     int64_t max_items;
+    int stage_words; // 16 / 32: words per stage slot of the staged form; 0: fan-outs beyond it (push form only)
 };
+
+// words per stage slot: {column start, degree} + the largest fan-out of an ORDERED hop (hop 0 is direct)
+static int win_stage_words(const int64_t *fanout, int32_t n_hops) {
+    int64_t k = 0;
+    for (int h = 1; h < n_hops; ++h) k = std::max(k, fanout[h]);
+    return n_hops < 2 ? 0 : (k <= 14 ? 16 : (k <= 30 ? 32 : 0));
+}
 
 static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops) {
     WinLayout L;
@@ -757,6 +786,9 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
     L.base = take((size_t)(WIN_MAX_BUCKETS + 1) * sizeof(uint32_t));
     L.items_in = take((size_t)L.max_items * sizeof(WinItemW)); // sized for the wide form
     L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
+    L.vtab = take((size_t)WIN_MAX_BUCKETS * sizeof(uint32_t));
+    L.stage_words = win_stage_words(fanout, n_hops);
+    L.stage = take((size_t)L.max_items * L.stage_words * sizeof(uint32_t));
     L.total = at;
     return L;
 }
@@ -853,6 +885,117 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
         clk.mark("gather", h, stream);
     }
     return TG_OK;
+}
+
+// ---------------------------------------------------------------- staged form: host side
+static bool win_staged_applicable(const WinParams &p, const WinTuning &t, const tg_graph *csc, int64_t n_batches,
+                                  const int64_t *fanout, int32_t n_hops, int stage_words) {
+    if (!t.staged || !t.direct_hop0 || n_hops < 2 || stage_words == 0) return false;
+    if (csc->n_major >= ((int64_t)1 << 32) || csc->n_edges >= ((int64_t)1 << 32)) return false; // 32-bit items / slots
+    int64_t pitch = p.n_seeds;
+    for (int h = 1; h < n_hops; ++h) {
+        pitch *= fanout[h - 1];
+        int bits = 1;
+        while (((int64_t)1 << bits) < pitch) ++bits;
+        if (bits >= 32 || n_batches > ((int64_t)1 << (32 - bits))) return false; // batch | index in one word
+    }
+    return true;
+}
+
+template <int W, int KMAX, bool REPLACE>
+static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, const int64_t *fanout, int32_t n_hops,
+                          hipStream_t stream) {
+    const WinTuning t = win_tuning();
+    WinStageClock &clk = win_clock();
+    p.n_batches = n_batches;
+    p.n_rows = (int32_t)std::min<int64_t>(WIN_PART_BLOCKS, n_batches); // rows of the histogram = sort workgroups
+    p.n_windows = (int32_t)((csc->n_edges >> p.shift) + 1);
+    auto pitch_of = [&](int h) {
+        int64_t f = p.n_seeds;
+        for (int j = 0; j < h; ++j) f *= fanout[j];
+        return f;
+    };
+    auto bits_of = [&](int64_t pitch) {
+        int bits = 1;
+        while (((int64_t)1 << bits) < pitch) ++bits;
+        return bits;
+    };
+    const size_t tables = ((size_t)p.n_buckets + p.n_windows) * sizeof(uint32_t); // counters + vertex table in LDS
+    clk.begin(stream);
+    hipLaunchKernelGGL(win_vtab_kernel, dim3((p.n_windows + 255) / 256), dim3(256), 0, stream, p, csc->n_major);
+    TG_LAUNCH_CHECK();
+    { // E0: seeds, hop 0 direct, the items of hop 1
+        int threads = t.emit_threads;
+        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
+        p.next_pitch = pitch_of(1);
+        p.next_idx_bits = bits_of(p.next_pitch);
+        hipLaunchKernelGGL((win_stage_first_kernel<KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
+                           win_emit_lds_bytes(p.kmax, threads / 64), stream, p, (int)fanout[0]);
+        TG_LAUNCH_CHECK();
+        clk.mark("first", 0, stream);
+    }
+    for (int h = 1; h < n_hops; ++h) {
+        p.hop = h;
+        p.k = (int32_t)fanout[h];
+        p.item_pitch = pitch_of(h);
+        p.idx_bits = bits_of(p.item_pitch);
+        const bool next = h + 1 < n_hops;
+        p.next_pitch = next ? pitch_of(h + 1) : 0;
+        p.next_idx_bits = next ? bits_of(p.next_pitch) : 0;
+        hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+        TG_LAUNCH_CHECK();
+        clk.mark("hist", h, stream);
+        hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
+                           p.n_rows);
+        TG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
+        TG_LAUNCH_CHECK();
+        clk.mark("scans", h, stream);
+        hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+        TG_LAUNCH_CHECK();
+        clk.mark("scatter", h, stream);
+        {
+            int gthreads = t.stage_gather_threads;
+            const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
+            while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
+            const int gblocks = (std::max(t.stage_gather_blocks, 8) + 7) & ~7;
+            hipLaunchKernelGGL((win_stage_gather_kernel<W, REPLACE>), dim3(gblocks), dim3(gthreads),
+                               (size_t)(gthreads / 64) * per_wave, stream, p);
+            TG_LAUNCH_CHECK();
+            clk.mark("gather", h, stream);
+        }
+        {
+            int threads = t.stage_emit_threads;
+            int rc = std::min(std::max(t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
+            while (win_stage_emit_lds_bytes(W, p.k, threads / 64, rc) > 64 * 1024) {
+                if (rc > 1)
+                    rc >>= 1;
+                else if (threads > 64)
+                    threads = ((threads >> 1) + 63) & ~63;
+                else
+                    return tg::fail(TG_ERR_INVALID, "tg_ns_homo_batched_ws: the staged emit kernel does not fit the LDS");
+            }
+            const size_t lds = win_stage_emit_lds_bytes(W, p.k, threads / 64, rc);
+            if (next)
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, true>), dim3((unsigned)n_batches), dim3(threads),
+                                   lds, stream, p, rc);
+            else
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, false>), dim3((unsigned)n_batches),
+                                   dim3(threads), lds, stream, p, rc);
+            TG_LAUNCH_CHECK();
+            clk.mark("emit", h, stream);
+        }
+    }
+    return TG_OK;
+}
+
+template <bool REPLACE>
+static int win_dispatch_staged(const WinParams &p, const tg_graph *csc, int stage_words, int64_t n_batches,
+                               const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
+    if (stage_words == 16)
+        return p.kmax <= 16 ? win_run_staged<16, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
+                            : win_run_staged<16, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
+    return win_run_staged<32, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
 }
 
 // window size: a few hundred KB of the gathered array, at most WIN_MAX_BUCKETS windows
@@ -961,6 +1104,11 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     const bool force_wide = mode == TG_NS_FORM_WINDOWED_WIDE;
     p.slot_bits = slot_bits;
     const bool repl = (cfg ? cfg->sampler : TG_SAMPLER_UNIFORM) == TG_SAMPLER_UNIFORM_REPL;
+    p.vtab = reinterpret_cast<uint32_t *>(w + L.vtab);
+    p.stage = reinterpret_cast<uint32_t *>(w + L.stage);
+    if (narrow && !force_wide && win_staged_applicable(p, win_tuning(), csc, n_batches, fanout, n_hops, L.stage_words))
+        return repl ? win_dispatch_staged<true>(p, csc, L.stage_words, n_batches, fanout, n_hops, stream)
+                    : win_dispatch_staged<false>(p, csc, L.stage_words, n_batches, fanout, n_hops, stream);
     if (narrow && !force_wide) return win_dispatch<WinItemN>(p, repl, n_batches, fanout, n_hops, stream);
     return win_dispatch<WinItemW>(p, repl, n_batches, fanout, n_hops, stream);
 }
@@ -976,6 +1124,11 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->fuse_first_hops = w.fuse_first_hops;
     t->fold_hist = w.fold_hist;
     t->emit_blocks = w.emit_blocks;
+    t->staged = w.staged;
+    t->stage_round_chunks = w.stage_round_chunks;
+    t->stage_gather_threads = w.stage_gather_threads;
+    t->stage_gather_blocks = w.stage_gather_blocks;
+    t->stage_emit_threads = w.stage_emit_threads;
     return TG_OK;
 }
 
@@ -997,6 +1150,11 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->fuse_first_hops >= 0) w.fuse_first_hops = t->fuse_first_hops != 0;
     if (t->fold_hist >= 0) w.fold_hist = t->fold_hist != 0;
     if (t->emit_blocks > 0) w.emit_blocks = t->emit_blocks;
+    if (t->staged >= 0) w.staged = t->staged != 0;
+    if (t->stage_round_chunks > 0) w.stage_round_chunks = t->stage_round_chunks;
+    if (t->stage_gather_threads >= 64 && t->stage_gather_threads <= 1024) w.stage_gather_threads = t->stage_gather_threads & ~63;
+    if (t->stage_gather_blocks > 0) w.stage_gather_blocks = t->stage_gather_blocks;
+    if (t->stage_emit_threads >= 64 && t->stage_emit_threads <= 1024) w.stage_emit_threads = t->stage_emit_threads & ~63;
     return TG_OK;
 }
 

@@ -230,6 +230,60 @@ def test_rccl_backend_gets_device_tensors_only(monkeypatch):
 
 
 # ---------------------------------------------------------------- temporal filters and weights on a partitioned graph
+def test_status_of_every_hop_reaches_the_caller():
+    """the owner-side status word used to be zeroed per hop and read after the last one only.  A column of
+    zero weights that only a SEED reaches (hop 0 of a 2-hop call; the later hop is healthy) must raise, as the reference
+    panics (sampling.rs:49) and as the replicated operator does."""
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n, ts, w = _attr_graph(dev)
+    deg = ptrs[1:] - ptrs[:-1]
+    outdeg = torch.bincount(idx, minlength=n)
+    cand = ((deg > 6) & (outdeg == 0)).nonzero().reshape(-1)           # never sampled as a neighbour: only a seed reaches it
+    assert cand.numel() > 0
+    hub = int(cand[0])
+    seeds = _cabi.seed_batches(21, 0, 2, B, n, dev)
+    seeds[1, 3] = hub
+    fan = [6, 4]
+    shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1, weights=w, timestamps=ts)
+    ps = partitioned.PartitionedSampler(shard, 2, B, fan, sampler=2)
+    ps.sample(seeds, SEED, 0)                                          # healthy weights: fine
+    w0 = w.clone()
+    w0[int(ptrs[hub]):int(ptrs[hub + 1])] = 0.0                        # the hub's whole column weighs nothing
+    # vertices sampled FROM the hub's column get expanded in the later hop with healthy weights: only hop 0 can report it
+    shard0 = partitioned.CscShard.from_full(ptrs, idx, 0, 1, weights=w0, timestamps=ts)
+    ps0 = partitioned.PartitionedSampler(shard0, 2, B, fan, sampler=2)
+    with pytest.raises(RuntimeError, match="non-positive running weight sum"):
+        ps0.sample(seeds, SEED, 0)
+    seeds[1, 3] = seeds[1, 4]
+    ps0.sample(seeds, SEED, 0)                                         # the same sampler, hub not reached: fine again
+
+
+def test_column_group_overflow_repeats_the_call():
+    """a too-small column-group workspace is reported in the call's one read-back; the call is repeated with a larger guess
+    and the guess is kept -- results equal the replicated launch"""
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    ptrs, idx, n, ts, w = _attr_graph(dev)
+    case = FILTER_CASES[2]
+    fan, nb, first = [6, 4], 4, 70
+    seeds = _cabi.seed_batches(21, first, nb, B, n, dev)
+    states = torch.randint(0, 60, (nb, B), device=dev)
+    ref = _replicated_general(ptrs, idx, ts, w, seeds, states, fan, first, case)
+    shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1, weights=w, timestamps=ts)
+    ps = partitioned.PartitionedSampler(shard, nb, B, fan, sampler=case["sampler"], filter_mode=case["filter_mode"],
+                                        forward=case["forward"], window=case["window"])
+    ps._group_mult = 1e-6                                              # a guess of ONE group: every hop overflows at first
+    out = ps.sample(seeds, SEED, first, seeds_state=states)
+    torch.cuda.synchronize()
+    assert ps._group_mult > 1e-6
+    c = ref.counts.cpu()
+    assert torch.equal(out.counts.cpu(), c) and int(c[:, 1].sum()) > 0
+    for b in range(nb):
+        for u, v in zip(out.batch(b, c)[:4], ref.batch(b, c)[:4]):
+            assert torch.equal(u, v)
+
+
 def _attr_graph(dev):
     ptrs, idx, n = _graph(dev)
     g = torch.Generator(device=dev)

@@ -91,7 +91,8 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
     cabi.ns_homo_batched(g, seeds, fan, 0, 4096, c, ws=ws, form=WINDOWED_WIDE)
     torch.cuda.synchronize()
     assert_equal_on_device(c, b)
-    for knobs in (dict(fold_hist=0), dict(fuse_first_hops=0)):      # the round-2 pipeline: separate histogram pass / kernels
+    # the push form (emit -> sort -> gather, round 2's pipeline) and its variants: folded histogram, fused first hops
+    for knobs in (dict(staged=0), dict(staged=0, fold_hist=0), dict(staged=0, fuse_first_hops=0)):
         before = cabi.ns_win_tuning_set(**knobs)
         try:
             d = _poisoned(cabi, nb, B, fan)
@@ -122,8 +123,11 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
         torch.cuda.synchronize()
         assert_equal_on_device(a, b)
         assert_oracle(cabi, a, ptrs, idx, seeds, fan, 9, 77, (0, 150, 299), sampler=sampler)
-        for knobs in (dict(direct_hop0=0), dict(fuse_first_hops=0), dict(fold_hist=0), dict(emit_blocks=7),
-                      dict(emit_blocks=1000, emit_threads=128), dict(gather_blocks=64, gather_threads=128)):
+        for knobs in (dict(direct_hop0=0), dict(staged=0), dict(staged=0, fuse_first_hops=0), dict(staged=0, fold_hist=0),
+                      dict(staged=0, emit_blocks=7), dict(staged=0, emit_blocks=1000, emit_threads=128),
+                      dict(staged=0, gather_blocks=64, gather_threads=128), dict(emit_blocks=7),
+                      dict(stage_round_chunks=1), dict(stage_round_chunks=16, stage_emit_threads=128),
+                      dict(stage_gather_threads=128, stage_gather_blocks=8), dict(emit_blocks=1000, emit_threads=128)):
             prev = cabi.ns_win_tuning_set(**knobs)
             try:
                 c = _poisoned(cabi, nb, B, fan)
@@ -188,4 +192,14 @@ def test_stage_times(cabi):
     finally:
         cabi.ns_win_stage_timing(False)
     names = [s for s, _ in st]
-    assert names[0].startswith("first_hops") and names[-1] == "gather.h1" and all(ms >= 0 for _, ms in st)
+    assert names[0] == "first.h0" and names[-1] == "emit.h1" and all(ms >= 0 for _, ms in st)       # the staged form
+    before = cabi.ns_win_tuning_set(staged=0)
+    cabi.ns_win_stage_timing(True)
+    try:
+        cabi.ns_homo_batched(g, seeds, fan, 0, 0, out, ws=ws, form=WINDOWED)
+        st = cabi.ns_win_stage_times()
+    finally:
+        cabi.ns_win_stage_timing(False)
+        cabi.ns_win_tuning_set(**before)
+    names = [s for s, _ in st]
+    assert names[0].startswith("first_hops") and names[-1] == "gather.h1"                           # the push form
