@@ -168,6 +168,8 @@ typedef struct {
     int32_t stage_gather_threads; /* staged gather kernel: workgroup size (default 512) */
     int32_t stage_gather_blocks;  /* ... and workgroups (default 512) */
     int32_t stage_emit_threads;   /* staged emit kernel: workgroup size (default 256) */
+    int32_t stage_parts;          /* staged form: the last hop runs in this many parts (batch ranges), part p's emit pass on
+                                     a side stream beside part p + 1's sort and gather (default 4; 1 = one stream) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

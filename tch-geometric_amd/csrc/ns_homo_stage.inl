@@ -59,7 +59,7 @@ __global__ void win_vtab_kernel(const WinParams p, int64_t n_major) {
 template <int KMAX, bool REPLACE>
 __global__ void win_stage_first_kernel(const WinParams p, const int k0) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int64_t b = blockIdx.x;
+    const int64_t b = p.b0 + blockIdx.x;
     int64_t *samples = p.samples + b * p.cap_nodes;
     for (int64_t i = threadIdx.x; i < p.n_seeds; i += blockDim.x) samples[i] = p.seeds[b * p.n_seeds + i]; // :184
     const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinPa
     for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
     __syncthreads();
     constexpr int U = 4;
-    for (int64_t b = blockIdx.x; b < p.n_batches; b += gridDim.x) {
+    for (int64_t b = p.b0 + blockIdx.x; b < p.b0 + p.n_batches; b += gridDim.x) {
         const WinState st = p.state[b];
         const int64_t n = st.end - st.begin;
         const WinItem8 *src = items + b * p.item_pitch;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_kernel(const Wi
     for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
     __syncthreads();
     constexpr int U = 4;
-    for (int64_t b = blockIdx.x; b < p.n_batches; b += gridDim.x) {
+    for (int64_t b = p.b0 + blockIdx.x; b < p.b0 + p.n_batches; b += gridDim.x) {
         const WinState st = p.state[b];
         const int64_t n = st.end - st.begin; // the frontier of the hop about to be gathered
         const WinItem8 *src = items + b * p.item_pitch;
@@ -447,5 +447,5 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
 template <int W, int KMAX, bool REPLACE, bool NEXT>
 __global__ void win_stage_emit_kernel(const WinParams p, const int round_chunks) {
     extern __shared__ __align__(16) unsigned char smem[];
-    win_stage_emit_batch<W, KMAX, REPLACE, NEXT>(p, smem, blockIdx.x, round_chunks);
+    win_stage_emit_batch<W, KMAX, REPLACE, NEXT>(p, smem, p.b0 + blockIdx.x, round_chunks);
 }

@@ -39,6 +39,7 @@ constexpr int WIN_PART_THREADS = 512;
 constexpr int WIN_TILE = 4096;        // items per partition tile
 constexpr int WIN_MAX_BUCKETS = 8192; // windows per hop (LDS: 32 KB of counters)
 constexpr int WIN_MAX_ROWS = 1024;    // rows of the histogram matrix in the folded form (= persistent emit workgroups)
+constexpr int WIN_MAX_PARTS = 16;     // staged form: parts of a launch in flight on two streams
 
 struct WinState { // per batch, lives in the workspace
     int64_t begin, end, ne, fbase;
@@ -82,6 +83,7 @@ struct WinParams {
     uint32_t *stage; // [max_items][stage_words] {column start, degree, neighbours}
     int32_t n_windows, idx_bits, next_idx_bits;
     int64_t next_pitch;
+    int64_t b0; // staged form in parts: the kernels of a part walk batches [b0, b0 + n_batches)
 };
 
 // One frontier vertex with something to sample.  Narrow form: launches whose edge pointers and per-batch offsets fit 32
@@ -703,7 +705,7 @@ static int win_env_int(const char *name, int dflt) {
 struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
-    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads;
+    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -720,6 +722,7 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_GATHER_THREADS", 512),
         win_env_int("TG_WIN_STAGE_GATHER_BLOCKS", 512),
         win_env_int("TG_WIN_STAGE_EMIT_THREADS", 256),
+        win_env_int("TG_WIN_STAGE_PARTS", 4),
     };
     return t;
 }
@@ -781,9 +784,9 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
     L.state = take((size_t)n_batches * sizeof(WinState));
     L.call_keys = take((size_t)n_batches * sizeof(CallKey));
     L.n_items = take(TG_MAX_HOPS * sizeof(unsigned long long));
-    L.queues = take(sizeof(WinQueues));
-    L.hist = take((size_t)WIN_MAX_ROWS * WIN_MAX_BUCKETS * sizeof(uint32_t));
-    L.base = take((size_t)(WIN_MAX_BUCKETS + 1) * sizeof(uint32_t));
+    L.queues = take(WIN_MAX_PARTS * sizeof(WinQueues));
+    L.hist = take((size_t)std::max(WIN_MAX_ROWS, WIN_MAX_PARTS * WIN_PART_BLOCKS) * WIN_MAX_BUCKETS * sizeof(uint32_t));
+    L.base = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS + 8) * sizeof(uint32_t));
     L.items_in = take((size_t)L.max_items * sizeof(WinItemW)); // sized for the wide form
     L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
     L.vtab = take((size_t)WIN_MAX_BUCKETS * sizeof(uint32_t));
@@ -902,13 +905,30 @@ static bool win_staged_applicable(const WinParams &p, const WinTuning &t, const 
     return true;
 }
 
+// The side stream and events of the staged form (one set per process; launches that share them serialise on the events,
+// which keeps them correct).  Part p's emit pass runs on the side stream while part p + 1 is sorted and gathered on the
+// caller's: the gather is bound by vector-ALU work (ticket draws), the emit pass by its streams, so they overlap.
+struct WinSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t gathered[WIN_MAX_PARTS] = {}, done = nullptr;
+    int ensure() {
+        if (stream) return TG_OK;
+        TG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto &e : gathered) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        TG_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        return TG_OK;
+    }
+};
+static WinSide &win_side() {
+    static WinSide s;
+    return s;
+}
+
 template <int W, int KMAX, bool REPLACE>
 static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, const int64_t *fanout, int32_t n_hops,
                           hipStream_t stream) {
     const WinTuning t = win_tuning();
     WinStageClock &clk = win_clock();
-    p.n_batches = n_batches;
-    p.n_rows = (int32_t)std::min<int64_t>(WIN_PART_BLOCKS, n_batches); // rows of the histogram = sort workgroups
     p.n_windows = (int32_t)((csc->n_edges >> p.shift) + 1);
     auto pitch_of = [&](int h) {
         int64_t f = p.n_seeds;
@@ -921,12 +941,27 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         return bits;
     };
     const size_t tables = ((size_t)p.n_buckets + p.n_windows) * sizeof(uint32_t); // counters + vertex table in LDS
+    // parts: only worth it when every part still revisits the lines of a window often (>= 1 024 batches each)
+    int parts = std::min(std::max(t.stage_parts, 1), WIN_MAX_PARTS);
+    while (parts > 1 && n_batches / parts < 1024) --parts;
+    if (clk.enabled) parts = 1; // stage timing: one stream, one part, so that the events bracket single kernels
+    WinSide &side = win_side();
+    if (parts > 1) {
+        const int rc = side.ensure();
+        if (rc != TG_OK) return rc;
+    }
+    uint32_t *const hist0 = p.hist, *const base0 = p.base;
+    WinQueues *const queues0 = p.queues;
+    void *const sorted0 = p.items_sorted;
+
     clk.begin(stream);
     hipLaunchKernelGGL(win_vtab_kernel, dim3((p.n_windows + 255) / 256), dim3(256), 0, stream, p, csc->n_major);
     TG_LAUNCH_CHECK();
-    { // E0: seeds, hop 0 direct, the items of hop 1
+    { // E0: seeds, hop 0 direct, the items of hop 1 -- all batches
         int threads = t.emit_threads;
         while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
+        p.b0 = 0;
+        p.n_batches = n_batches;
         p.next_pitch = pitch_of(1);
         p.next_idx_bits = bits_of(p.next_pitch);
         hipLaunchKernelGGL((win_stage_first_kernel<KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
@@ -942,48 +977,66 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         const bool next = h + 1 < n_hops;
         p.next_pitch = next ? pitch_of(h + 1) : 0;
         p.next_idx_bits = next ? bits_of(p.next_pitch) : 0;
-        hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
-        TG_LAUNCH_CHECK();
-        clk.mark("hist", h, stream);
-        hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
-                           p.n_rows);
-        TG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
-        TG_LAUNCH_CHECK();
-        clk.mark("scans", h, stream);
-        hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
-        TG_LAUNCH_CHECK();
-        clk.mark("scatter", h, stream);
-        {
-            int gthreads = t.stage_gather_threads;
-            const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
-            while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
-            const int gblocks = (std::max(t.stage_gather_blocks, 8) + 7) & ~7;
+        int ethreads = t.stage_emit_threads;
+        int rc = std::min(std::max(t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
+        while (win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc) > 64 * 1024) {
+            if (rc > 1)
+                rc >>= 1;
+            else if (ethreads > 64)
+                ethreads = ((ethreads >> 1) + 63) & ~63;
+            else
+                return tg::fail(TG_ERR_INVALID, "tg_ns_homo_batched_ws: the staged emit kernel does not fit the LDS");
+        }
+        const size_t elds = win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc);
+        int gthreads = t.stage_gather_threads;
+        const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
+        while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
+        const int gblocks = (std::max(t.stage_gather_blocks, 8) + 7) & ~7;
+        for (int part = 0; part < parts; ++part) {
+            p.b0 = n_batches * part / parts;
+            p.n_batches = n_batches * (part + 1) / parts - p.b0;
+            p.n_rows = (int32_t)std::min<int64_t>(WIN_PART_BLOCKS, p.n_batches); // rows of the histogram = sort workgroups
+            p.hist = hist0 + (size_t)part * WIN_PART_BLOCKS * WIN_MAX_BUCKETS;
+            p.base = base0 + (size_t)part * (WIN_MAX_BUCKETS + 8);
+            p.queues = queues0 + part;
+            p.items_sorted = static_cast<WinItem8 *>(sorted0) + p.b0 * p.item_pitch; // the part's own range of the sorted array
+            hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+            TG_LAUNCH_CHECK();
+            clk.mark("hist", h, stream);
+            hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
+                               p.n_rows);
+            TG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
+            TG_LAUNCH_CHECK();
+            clk.mark("scans", h, stream);
+            hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+            TG_LAUNCH_CHECK();
+            clk.mark("scatter", h, stream);
             hipLaunchKernelGGL((win_stage_gather_kernel<W, REPLACE>), dim3(gblocks), dim3(gthreads),
                                (size_t)(gthreads / 64) * per_wave, stream, p);
             TG_LAUNCH_CHECK();
             clk.mark("gather", h, stream);
-        }
-        {
-            int threads = t.stage_emit_threads;
-            int rc = std::min(std::max(t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
-            while (win_stage_emit_lds_bytes(W, p.k, threads / 64, rc) > 64 * 1024) {
-                if (rc > 1)
-                    rc >>= 1;
-                else if (threads > 64)
-                    threads = ((threads >> 1) + 63) & ~63;
-                else
-                    return tg::fail(TG_ERR_INVALID, "tg_ns_homo_batched_ws: the staged emit kernel does not fit the LDS");
+            // the emit pass of the last hop has nothing after it to wait for: it goes to the side stream, behind this
+            // part's gather, and the next part's sort + gather start beside it.  (A hop with a successor keeps one
+            // stream: its items feed the next hop's sort.)
+            hipStream_t es = stream;
+            if (parts > 1 && !next) {
+                TG_HIP(hipEventRecord(side.gathered[part], stream));
+                TG_HIP(hipStreamWaitEvent(side.stream, side.gathered[part], 0));
+                es = side.stream;
             }
-            const size_t lds = win_stage_emit_lds_bytes(W, p.k, threads / 64, rc);
             if (next)
-                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, true>), dim3((unsigned)n_batches), dim3(threads),
-                                   lds, stream, p, rc);
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, true>), dim3((unsigned)p.n_batches),
+                                   dim3(ethreads), elds, es, p, rc);
             else
-                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, false>), dim3((unsigned)n_batches),
-                                   dim3(threads), lds, stream, p, rc);
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, false>), dim3((unsigned)p.n_batches),
+                                   dim3(ethreads), elds, es, p, rc);
             TG_LAUNCH_CHECK();
             clk.mark("emit", h, stream);
+        }
+        if (parts > 1 && !next) { // join: the caller's stream continues after the last emit pass
+            TG_HIP(hipEventRecord(side.done, side.stream));
+            TG_HIP(hipStreamWaitEvent(stream, side.done, 0));
         }
     }
     return TG_OK;
@@ -1129,6 +1182,7 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_gather_threads = w.stage_gather_threads;
     t->stage_gather_blocks = w.stage_gather_blocks;
     t->stage_emit_threads = w.stage_emit_threads;
+    t->stage_parts = w.stage_parts;
     return TG_OK;
 }
 
@@ -1155,6 +1209,7 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_gather_threads >= 64 && t->stage_gather_threads <= 1024) w.stage_gather_threads = t->stage_gather_threads & ~63;
     if (t->stage_gather_blocks > 0) w.stage_gather_blocks = t->stage_gather_blocks;
     if (t->stage_emit_threads >= 64 && t->stage_emit_threads <= 1024) w.stage_emit_threads = t->stage_emit_threads & ~63;
+    if (t->stage_parts > 0) w.stage_parts = t->stage_parts;
     return TG_OK;
 }
 
