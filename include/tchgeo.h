@@ -162,14 +162,17 @@ typedef struct {
     int32_t fold_hist;       /* emit kernels persistent, window histogram of the items kept in LDS instead of a pass of its
                                 own over the items (default 1; needs the two flags above and >= 2 hops) */
     int32_t emit_blocks;     /* workgroups of the persistent emit kernels (default 768, at most 1024) */
-    int32_t staged;          /* gather first, emit afterwards through 64-byte stage slots (default 1; launches it does not
-                                fit -- ordered fan-outs > 30, ids beyond 32 bits -- take the push form) */
+    int32_t staged;          /* gather first, emit afterwards through 64-byte stage slots (default 0: measured slower than
+                                the push form; launches it does not fit -- ordered fan-outs > 30, ids beyond
+                                32 bits -- take the push form anyway) */
     int32_t stage_round_chunks;   /* staged emit kernel: 64-slot chunks per round (default 8, at most 16) */
     int32_t stage_gather_threads; /* staged gather kernel: workgroup size (default 512) */
     int32_t stage_gather_blocks;  /* ... and workgroups (default 512) */
     int32_t stage_emit_threads;   /* staged emit kernel: workgroup size (default 256) */
     int32_t stage_parts;          /* staged form: the last hop runs in this many parts (batch ranges), part p's emit pass on
-                                     a side stream beside part p + 1's sort and gather (default 4; 1 = one stream) */
+                                     a side stream beside part p + 1's sort and gather (default 1 = one stream: measured, the overlap
+                                     buys nothing -- both kernels are bound by vector-ALU work -- and every part costs 0.2 ms) */
+    int32_t stage_part_min_batches; /* ... as long as every part keeps at least this many batches (default 1024) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

@@ -140,8 +140,34 @@ constexpr int WIN_ROUND_SLOTS = WIN_ROUND_CHUNKS * 64;
 
 // K1's LDS: chunk offsets | fbase | column starts [slots] i64 | degrees [slots] u32 | per wave: staged positions
 // [64*k] u32, staged lanes [64*k] u8
-__host__ __device__ inline size_t win_emit_wave_lds_bytes(int kmax) {
-    return (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15);
+__host__ __device__ inline size_t win_emit_wave_lds_bytes(int kmax) { // ... + the chunk's drawing lanes [64] u8
+    return (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15) + 64;
+}
+
+// The ticket chain of sample_tickets with the slot's bounded draws r[s] already in registers (they were computed by
+// OTHER lanes, below): same positions, same order.
+template <int KMAX>
+__device__ __forceinline__ void sample_tickets_given(const uint32_t (&r_in)[KMAX], uint32_t n, int k, uint32_t *spos,
+                                                     uint8_t *slane, uint32_t out_base, int lane) {
+    uint32_t keys[KMAX], vals[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (s < k) {
+            const uint32_t m = (n - 1u) - (uint32_t)s;
+            const uint32_t r = r_in[s];
+            const uint32_t last = m - 1u;
+            uint32_t tr = r, tl = last;
+#pragma unroll
+            for (int j = 0; j < s; ++j) {
+                tr = (keys[j] == r) ? vals[j] : tr;
+                tl = (keys[j] == last) ? vals[j] : tl;
+            }
+            keys[s] = r;
+            vals[s] = tl;
+            spos[out_base + s] = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+            slane[out_base + s] = (uint8_t)lane;
+        }
+    }
 }
 __host__ __device__ inline size_t win_emit_head_bytes() {
     return (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
@@ -241,7 +267,59 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
                     Item::make((uint64_t)e0, n, (uint32_t)b, (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
                 if (FOLD && n) atomicAdd(&lhist[win_bucket((uint64_t)e0, p.shift, p.n_buckets)], 1u);
             }
-            if (cnt > 0) {
+            // Which lanes need Philox at all?  A frontier of arbitrary vertices (hop 0) has few of them per chunk (columns
+            // longer than the fan-out), yet a wavefront pays the slot's ceil(k/2) Philox blocks for all 64 lanes.  With at
+            // most half the lanes drawing, the (drawing slot, Philox block) pairs are dealt out over ALL lanes instead --
+            // every lane computes one block and its two bounded draws per pass, the results meet in LDS (the staging
+            // area, not yet in use), and the drawing lanes run only the cheap ticket chain.  Same draws (they are named
+            // by (call, slot, block)), same positions.
+            const bool draws = REPLACE ? (cnt > 0) : (n > (uint32_t)k);
+            const uint64_t dmask = __ballot(draws);
+            const int n_draw = __popcll(dmask);
+            const bool spread = n_draw > 0 && n_draw <= 32;
+            if (spread) {
+                uint8_t *dl = slane + (((size_t)64 * p.kmax + 15) & ~(size_t)15); // drawing lanes, in lane order
+                const int my_rank = __popcll(dmask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                if (draws) dl[my_rank] = (uint8_t)lane;
+                wave_lds_handoff();
+                const int nb = (k + 1) >> 1;
+                for (int t = lane; t < n_draw * nb; t += 64) {
+                    const int rank = t / nb, blk = t - rank * nb;
+                    const int src = dl[rank];
+                    const uint32_t ns = cdeg[c * 64 + src];
+                    const Draw d = draw(ck, (uint64_t)(p.id_base + i0 + src), (uint32_t)blk, REPLACE ? D1_REPLACE : 0u);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int sl = 2 * blk + h;
+                        if (sl < k) spos[rank * k + sl] = bounded32(d.half(h), REPLACE ? ns : (ns - 1u) - (uint32_t)sl);
+                    }
+                }
+                wave_lds_handoff();
+                uint32_t r[KMAX];
+                if (draws) {
+#pragma unroll
+                    for (int sl = 0; sl < KMAX; ++sl)
+                        if (sl < k) r[sl] = spos[my_rank * k + sl];
+                }
+                wave_lds_handoff(); // every lane holds its draws: the staging area may now be overwritten
+                if (cnt > 0) {
+                    if (REPLACE) {
+#pragma unroll
+                        for (int sl = 0; sl < KMAX; ++sl)
+                            if (sl < k) {
+                                spos[excl + sl] = r[sl];
+                                slane[excl + sl] = (uint8_t)lane;
+                            }
+                    } else if (!draws) { // sampling.rs:12-15
+                        for (uint32_t sl = 0; sl < cnt; ++sl) {
+                            spos[excl + sl] = sl;
+                            slane[excl + sl] = (uint8_t)lane;
+                        }
+                    } else {
+                        sample_tickets_given<KMAX>(r, n, k, spos, slane, excl, lane);
+                    }
+                }
+            } else if (cnt > 0) {
                 if (REPLACE) { // sampling.rs:57-69
                     Draw d;
                     for (int s = 0; s < k; ++s) {
@@ -705,7 +783,7 @@ static int win_env_int(const char *name, int dflt) {
 struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
-    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts;
+    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -717,12 +795,13 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_FUSE_FIRST_HOPS", 1),
         win_env_int("TG_WIN_FOLD_HIST", 1),
         win_env_int("TG_WIN_EMIT_BLOCKS", 768),
-        win_env_int("TG_WIN_STAGED", 1),
+        win_env_int("TG_WIN_STAGED", 0),
         win_env_int("TG_WIN_STAGE_ROUND_CHUNKS", 8),
         win_env_int("TG_WIN_STAGE_GATHER_THREADS", 512),
         win_env_int("TG_WIN_STAGE_GATHER_BLOCKS", 512),
         win_env_int("TG_WIN_STAGE_EMIT_THREADS", 256),
-        win_env_int("TG_WIN_STAGE_PARTS", 4),
+        win_env_int("TG_WIN_STAGE_PARTS", 1),
+        win_env_int("TG_WIN_STAGE_PART_MIN_BATCHES", 1024),
     };
     return t;
 }
@@ -943,7 +1022,7 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
     const size_t tables = ((size_t)p.n_buckets + p.n_windows) * sizeof(uint32_t); // counters + vertex table in LDS
     // parts: only worth it when every part still revisits the lines of a window often (>= 1 024 batches each)
     int parts = std::min(std::max(t.stage_parts, 1), WIN_MAX_PARTS);
-    while (parts > 1 && n_batches / parts < 1024) --parts;
+    while (parts > 1 && n_batches / parts < std::max(t.stage_part_min_batches, 1)) --parts;
     if (clk.enabled) parts = 1; // stage timing: one stream, one part, so that the events bracket single kernels
     WinSide &side = win_side();
     if (parts > 1) {
@@ -1183,6 +1262,7 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_gather_blocks = w.stage_gather_blocks;
     t->stage_emit_threads = w.stage_emit_threads;
     t->stage_parts = w.stage_parts;
+    t->stage_part_min_batches = w.stage_part_min_batches;
     return TG_OK;
 }
 
@@ -1210,6 +1290,7 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_gather_blocks > 0) w.stage_gather_blocks = t->stage_gather_blocks;
     if (t->stage_emit_threads >= 64 && t->stage_emit_threads <= 1024) w.stage_emit_threads = t->stage_emit_threads & ~63;
     if (t->stage_parts > 0) w.stage_parts = t->stage_parts;
+    if (t->stage_part_min_batches > 0) w.stage_part_min_batches = t->stage_part_min_batches;
     return TG_OK;
 }
 

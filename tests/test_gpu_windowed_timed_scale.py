@@ -91,8 +91,9 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
     cabi.ns_homo_batched(g, seeds, fan, 0, 4096, c, ws=ws, form=WINDOWED_WIDE)
     torch.cuda.synchronize()
     assert_equal_on_device(c, b)
-    # the push form (emit -> sort -> gather, round 2's pipeline) and its variants: folded histogram, fused first hops
-    for knobs in (dict(staged=0), dict(staged=0, fold_hist=0), dict(staged=0, fuse_first_hops=0)):
+    # variants of the push form (separate histogram pass, un-fused first hops: round 2's pipeline) and the staged form
+    # (gather first into 64-byte stage slots, emit afterwards), in one stream and in parts on two
+    for knobs in (dict(fold_hist=0), dict(fuse_first_hops=0), dict(staged=1, stage_parts=1), dict(staged=1, stage_parts=2)):
         before = cabi.ns_win_tuning_set(**knobs)
         try:
             d = _poisoned(cabi, nb, B, fan)
@@ -123,11 +124,13 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
         torch.cuda.synchronize()
         assert_equal_on_device(a, b)
         assert_oracle(cabi, a, ptrs, idx, seeds, fan, 9, 77, (0, 150, 299), sampler=sampler)
-        for knobs in (dict(direct_hop0=0), dict(staged=0), dict(staged=0, fuse_first_hops=0), dict(staged=0, fold_hist=0),
-                      dict(staged=0, emit_blocks=7), dict(staged=0, emit_blocks=1000, emit_threads=128),
-                      dict(staged=0, gather_blocks=64, gather_threads=128), dict(emit_blocks=7),
-                      dict(stage_round_chunks=1), dict(stage_round_chunks=16, stage_emit_threads=128),
-                      dict(stage_gather_threads=128, stage_gather_blocks=8), dict(emit_blocks=1000, emit_threads=128)):
+        for knobs in (dict(direct_hop0=0), dict(fuse_first_hops=0), dict(fold_hist=0), dict(emit_blocks=7),
+                      dict(emit_blocks=1000, emit_threads=128), dict(gather_blocks=64, gather_threads=128),
+                      dict(staged=1), dict(staged=1, stage_round_chunks=1),
+                      dict(staged=1, stage_round_chunks=16, stage_emit_threads=128),
+                      dict(staged=1, stage_gather_threads=128, stage_gather_blocks=8), dict(staged=1, emit_threads=128),
+                      dict(staged=1, stage_parts=3, stage_part_min_batches=8),
+                      dict(staged=1, stage_parts=16, stage_part_min_batches=1), dict(staged=1, stage_parts=1)):
             prev = cabi.ns_win_tuning_set(**knobs)
             try:
                 c = _poisoned(cabi, nb, B, fan)
@@ -142,7 +145,7 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
 
 
 @pytest.mark.parametrize("fan,B", [([3], 3), ([3, 3, 3], 3), ([5], 7), ([1, 1, 1], 5), ([15, 9, 3], 1)])
-@pytest.mark.parametrize("direct", [1, 0])
+@pytest.mark.parametrize("direct", [1, 0, 2])
 def test_odd_slab_pitch(cabi, fan, B, direct):
     """odd cap_edges: the slabs of odd batches start on an odd element, i.e. 8-byte-aligned; the emit kernel's 16-byte pair
     stores take their alignment from the address (ns_homo_win.hip)"""
@@ -152,7 +155,7 @@ def test_odd_slab_pitch(cabi, fan, B, direct):
     assert cabi.ns_homo_capacity(B, fan)[1] % 2 == 1
     seeds = cabi.seed_batches(0xBA7C4, 5, nb, B, n, dev)
     seeds[:, 0] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))            # a hub in every batch: columns longer than the fan-out
-    before = cabi.ns_win_tuning_set(direct_hop0=direct)
+    before = cabi.ns_win_tuning_set(direct_hop0=min(direct, 1), staged=int(direct == 2))   # 2: the staged form
     try:
         a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
         ws = cabi.ns_homo_workspace(nb, B, fan, dev)
@@ -192,8 +195,8 @@ def test_stage_times(cabi):
     finally:
         cabi.ns_win_stage_timing(False)
     names = [s for s, _ in st]
-    assert names[0] == "first.h0" and names[-1] == "emit.h1" and all(ms >= 0 for _, ms in st)       # the staged form
-    before = cabi.ns_win_tuning_set(staged=0)
+    assert names[0].startswith("first_hops") and names[-1] == "gather.h1" and all(ms >= 0 for _, ms in st)  # the push form
+    before = cabi.ns_win_tuning_set(staged=1)
     cabi.ns_win_stage_timing(True)
     try:
         cabi.ns_homo_batched(g, seeds, fan, 0, 0, out, ws=ws, form=WINDOWED)
@@ -202,4 +205,4 @@ def test_stage_times(cabi):
         cabi.ns_win_stage_timing(False)
         cabi.ns_win_tuning_set(**before)
     names = [s for s, _ in st]
-    assert names[0].startswith("first_hops") and names[-1] == "gather.h1"                           # the push form
+    assert names[0] == "first.h0" and names[-1] == "emit.h1"                                         # the staged form
