@@ -52,7 +52,10 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=1,
                     help="--mode partitioned: super-batches in flight at once, each lane a PartitionedSampler of its own on "
                          "its own HIP stream, host thread and process group (communicator), so that the exchange of one "
-                         "super-batch overlaps the sampling of the next (SURVEY.md 8(e))")
+                         "super-batch overlaps the sampling of the next (SURVEY.md 8(e)).  Verified with ONE rank exchanging "
+                         "with itself only; refused with more ranks")
+    ap.add_argument("--pipelines", choices=["auto", "push", "staged"], default="auto",
+                    help="pipeline of the window-ordered launch: auto = time both in the untimed set-up and keep the faster")
     ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
                     help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
     return ap.parse_args(argv)
@@ -194,6 +197,7 @@ def main(argv=None):
     graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32)
     if not slabs_first:
         out, ws, G = alloc_slabs(G)
+        candidates = [(out, ws)]
 
     # ---- this rank's mini-batches: global batch ids [rank*(W+K)*G, (rank+1)*(W+K)*G); step i samples G of them with
     # call ids first + i*G ...  Seeds of up to 32 steps are kept resident (268 MB each); longer runs cycle through them
@@ -203,7 +207,15 @@ def main(argv=None):
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
     placement_ms = None
     in_flight = None
-    if len(candidates) > 1:
+    pipelines = ["push"]
+    if form != 2 and args.pipelines != "push":
+        # the window-ordered launch has two pipelines with identical outputs (push: emit -> sort -> gather scattering its
+        # samples; staged: gather into 64-byte stage slots -> emit all four streams); which is faster depends on where
+        # the slabs landed, so the set-up times both, like a planner would
+        pipelines = ["push", "staged"] if args.pipelines == "auto" else [args.pipelines]
+    pipeline = pipelines[0]
+    _cabi.ns_win_tuning_set(staged=int(pipeline == "staged"))
+    if len(candidates) > 1 or len(pipelines) > 1:
         # untimed set-up: the launch is timed on every combination of {samples slab} x {rows / cols / edge_index slabs} x
         # {workspace} of the placements (the gather kernel's time follows the first, the emit kernel's the second), one
         # warm + two timed launches each; the fastest combination is kept, the rest freed
@@ -212,7 +224,9 @@ def main(argv=None):
         placement_ms = {}
         best, best_ms = None, None
         n_c = len(candidates)
-        for a, b_, c in itertools.product(range(n_c), range(n_c), range(n_c) if form != 2 else [0]):
+        for (a, b_, c), pl in itertools.product(itertools.product(range(n_c), range(n_c), range(n_c) if form != 2 else [0]),
+                                                pipelines):
+            _cabi.ns_win_tuning_set(staged=int(pl == "staged"))
             mix = copy.copy(candidates[a][0])
             mix.samples = candidates[a][0].samples
             mix.rows, mix.cols, mix.edge_index = (candidates[b_][0].rows, candidates[b_][0].cols,
@@ -226,9 +240,10 @@ def main(argv=None):
             ev1.record()
             torch.cuda.synchronize(dev)
             ms = ev0.elapsed_time(ev1) / 2
-            placement_ms["samples%d_streams%d_ws%d" % (a, b_, c)] = round(ms, 3)
+            placement_ms["samples%d_streams%d_ws%d_%s" % (a, b_, c, pl)] = round(ms, 3)
             if best_ms is None or ms < best_ms:
-                best, best_ms = (a, b_, c), ms
+                best, best_ms, pipeline = (a, b_, c), ms, pl
+        _cabi.ns_win_tuning_set(staged=int(pipeline == "staged"))
         # beside the line (never part of `value`): the same launches with TWO in flight, one per placement on its own
         # stream -- what a caller that prefetches the next super-batch gets
         in_flight = None
@@ -333,9 +348,10 @@ def main(argv=None):
                         "batch %d, default sampler (uniform w/o replacement), no filter" %
                         (args.scale, n_nodes, n_edges, fanout, B),
             "step": "one launch over %d independent %d-seed mini-batches" % (G, B),
-            "placement_policy": ("the launch is timed on the FASTEST of the slab / workspace placements tried in untimed "
-                                 "set-up (all listed in placements_tried_ms_per_launch; --placements 1 = take the first)"
-                                 if placement_ms else "first allocation"),
+            "placement_policy": ("the launch is timed on the FASTEST of the slab / workspace placements x pipelines tried in "
+                                 "untimed set-up (all listed in placements_tried_ms_per_launch; --placements 1 "
+                                 "--pipelines push = take the first)" if placement_ms else "first allocation"),
+            "pipeline": pipeline if form != 2 else "fused",
             "first_placement_ms_per_launch": (next(iter(placement_ms.values())) if placement_ms else None),
             "batches_per_launch": G,
             "placements_tried_ms_per_launch": placement_ms,
@@ -450,6 +466,11 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     lanes = max(1, args.lanes)
+    if lanes > 1 and world > 1:
+        # several communicators driven from several host threads with blocking size read-backs in between: collectives of
+        # different communicators may be enqueued in different orders on different ranks -- a known way to deadlock.  Only
+        # ever run (and verified) with ONE rank exchanging with itself; refused beyond that until a multi-GPU run exists.
+        raise SystemExit("bench.py: --lanes > 1 is verified for one rank only (world %d); use --lanes 1" % world)
     exchanging = world > 1 or args.force_exchange
     # a lane's collectives must meet the same lane's on every rank in the same order: one communicator per lane
     groups = [dist.new_group(ranks=list(range(world))) if (exchanging and lanes > 1) else None for _ in range(lanes)]
@@ -485,8 +506,13 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
             try:
                 torch.cuda.set_device(dev)
                 run_lane(j, lo, hi, timed)
-            except Exception as ex:  # noqa: BLE001
-                errs.append(ex)
+            except BaseException as ex:  # noqa: BLE001
+                # the other lanes may sit in collectives that this lane will never join: do not wait for them
+                import traceback
+                traceback.print_exc()
+                sys.stderr.write("bench.py: lane %d failed (%r); leaving at once\n" % (j, ex))
+                sys.stderr.flush()
+                os._exit(3)
         ts = [threading.Thread(target=guarded, args=(j,)) for j in range(lanes)]
         for t in ts:
             t.start()

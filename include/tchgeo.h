@@ -620,6 +620,12 @@ TG_API int tg_compact_rows(const int64_t *src, int64_t pitch, const int64_t *len
 TG_API int tg_probe_random_gather(const int64_t *table, int64_t n_table, int64_t n_threads, int64_t per_thread,
                                   uint64_t seed, int64_t *sink, void *stream);
 
+/* Debug build only (`make dbg`, -DTG_DEBUG_BOUNDS -> lib/libtchgeo_hip_dbg.so): registers a device word; the multi-hop
+ * neighbor-sampling kernels then compare every frontier id with n_major before it indexes `ptrs`, raise bit 0 of the word
+ * for an offender and sample vertex 0 instead of reading out of bounds.  For experiments that drop or alter a hop's work.
+ * The regular build trusts the ids (contract: ids in `indices` are < n_major) and returns TG_ERR_UNSUPPORTED here. */
+TG_API int tg_debug_bounds_set_flag(uint32_t *device_word);
+
 /* Harness calibration: the speed of light of neighbor_sampling_homogenous's output contract.  Moves the ALGORITHMIC bytes
  * of a finished launch `src` (per seed 8 B read + 8 B written, per expanded frontier slot 24 B read, per sampled edge 8 B
  * read + 32 B written) as pure streams into the slabs `dst` (same pitch, other memory) -- precomputed contents,

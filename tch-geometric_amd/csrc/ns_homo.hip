@@ -48,6 +48,7 @@ struct NsHomoParams {
     uint32_t tag;
     int64_t id_base;
     const int64_t *seed_ids, *seed_call_ids; // remote-frontier mode (n_hops == 1)
+    TG_BOUNDS_FIELDS
 };
 
 // per wave: edge base [64] i64 | staged positions [64*k] u32 | staged lanes [64*k] u8 | (big fan-outs only) the
@@ -164,7 +165,8 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 const int64_t i = round_begin + (int64_t)c * 64 + lane;
                 uint32_t cnt = 0;
                 if (i < round_end) {
-                    const int64_t w = samples[i];
+                    int64_t w = samples[i];
+                    TG_CHECK_VERTEX(p, w);
                     const int64_t deg = p.ptrs32 ? (int64_t)(p.ptrs32[w + 1] - p.ptrs32[w]) : p.ptrs[w + 1] - p.ptrs[w];
                     cnt = (deg <= 0) ? 0u : (REPLACE ? (uint32_t)k : (uint32_t)min(deg, (int64_t)k));
                 }
@@ -190,7 +192,8 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 const int64_t i = i0 + lane;
                 int64_t e0 = 0, deg = 0;
                 if (i < round_end) {
-                    const int64_t w = samples[i];
+                    int64_t w = samples[i];
+                    TG_CHECK_VERTEX(p, w);
                     if (p.ptrs32) {
                         e0 = (int64_t)p.ptrs32[w];
                         deg = (int64_t)p.ptrs32[w + 1] - e0;
@@ -376,6 +379,7 @@ static int ns_homo_batched_impl(const tg_graph *csc, const int64_t *seeds, int64
     p.call_id = rng->call_id;
     p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
     p.id_base = cfg ? cfg->id_base : 0;
+    TG_BOUNDS_INIT(p, csc);
     p.seed_ids = cfg ? cfg->seed_ids : nullptr;
     p.seed_call_ids = cfg ? cfg->seed_call_ids : nullptr;
     TG_REQUIRE((p.seed_ids == nullptr) == (p.seed_call_ids == nullptr),

@@ -195,7 +195,8 @@ __global__ void win_stage_gather_kernel(const WinParams p) {
         for (int w = 0; w < W; ++w) row[w] = 0u;
         uint32_t slot_index = 0xffffffffu;
         if (live) {
-            const WinItem8 it = items[j];
+            WinItem8 it = items[j];
+            TG_CHECK_VERTEX(p, it.v);
             const uint32_t b = it.bs >> p.idx_bits, idx = it.bs & idx_mask;
             uint64_t e0, e1;
             if (p.ptrs32) {

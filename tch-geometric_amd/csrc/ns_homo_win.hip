@@ -84,6 +84,7 @@ struct WinParams {
     int32_t n_windows, idx_bits, next_idx_bits;
     int64_t next_pitch;
     int64_t b0; // staged form in parts: the kernels of a part walk batches [b0, b0 + n_batches)
+    TG_BOUNDS_FIELDS
 };
 
 // One frontier vertex with something to sample.  Narrow form: launches whose edge pointers and per-batch offsets fit 32
@@ -228,7 +229,8 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
             const int64_t i = round_begin + (int64_t)c * 64 + lane;
             int64_t e0 = 0, deg = 0;
             if (i < round_end) {
-                const int64_t w = samples[i];
+                int64_t w = samples[i];
+                TG_CHECK_VERTEX(p, w);
                 if (p.ptrs32) {
                     e0 = (int64_t)p.ptrs32[w];
                     deg = (int64_t)p.ptrs32[w + 1] - e0;
@@ -1218,6 +1220,7 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     p.call_id = rng->call_id;
     p.tag = (cfg && cfg->rng_tag) ? cfg->rng_tag : TG_TAG_NS_HOMO;
     p.id_base = cfg ? cfg->id_base : 0;
+    TG_BOUNDS_INIT(p, csc);
     unsigned char *w = static_cast<unsigned char *>(ws);
     p.state = reinterpret_cast<WinState *>(w + L.state);
     p.call_keys = reinterpret_cast<CallKey *>(w + L.call_keys);

@@ -26,9 +26,11 @@ struct HopParams {
     uint32_t tag;
     uint64_t seed, call_id;
     int64_t *cnt, *offsets, *neighbors, *edge_ptrs, *parents;
+    TG_BOUNDS_FIELDS
 };
 
 __device__ __forceinline__ void hop_range(const HopParams &p, int64_t w, int64_t &e0, int64_t &deg) {
+    TG_CHECK_VERTEX(p, w);
     if (p.ptrs32) {
         e0 = (int64_t)p.ptrs32[w];
         deg = (int64_t)p.ptrs32[w + 1] - e0;
@@ -238,6 +240,7 @@ extern "C" int tg_ns_hop(const tg_graph *csc, const tg_hop_in *in, const tg_rng 
     p.k = in->fanout;
     p.replace = in->sampler == TG_SAMPLER_UNIFORM_REPL;
     p.tag = in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO;
+    TG_BOUNDS_INIT(p, csc);
     p.seed = rng->seed;
     p.call_id = rng->call_id;
     p.cnt = out->cnt;

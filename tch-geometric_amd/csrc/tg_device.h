@@ -82,6 +82,41 @@ __device__ __forceinline__ double u64_to_f64_01(uint64_t x) {
     return __longlong_as_double((long long)(0x3FF0000000000000ull | (x >> 12))) - 1.0;
 }
 
+// ---- -DTG_DEBUG_BOUNDS: range-checked frontier ids ------------------------------------------------------------------
+// The multi-hop kernels index `ptrs[w]` with ids that came out of `indices` one hop earlier and trust them (the C ABI's
+// contract: ids of the adjacency are < n_major; the host module validates a graph once).  An EXPERIMENT that drops or
+// alters a hop's gathers breaks that contract -- round 2 lost a box to exactly that -- so experiments
+// run on the debug build (`make dbg` -> lib/libtchgeo_hip_dbg.so): every such id is compared with n_major first; an
+// offender raises bit 0 of the word registered with tg_debug_bounds_set_flag and is replaced by vertex 0.
+#ifdef TG_DEBUG_BOUNDS
+struct DebugBounds {
+    unsigned int *flag;
+    long long n_major;
+};
+#define TG_BOUNDS_FIELDS tg::DebugBounds dbg;
+#define TG_BOUNDS_INIT(p, graph)                                                                                       \
+    do {                                                                                                               \
+        (p).dbg.flag = tg::debug_bounds_flag();                                                                        \
+        (p).dbg.n_major = (graph)->n_major;                                                                            \
+    } while (0)
+#define TG_CHECK_VERTEX(p, w)                                                                                          \
+    do {                                                                                                               \
+        if ((unsigned long long)(w) >= (unsigned long long)(p).dbg.n_major) {                                          \
+            if ((p).dbg.flag) atomicOr((p).dbg.flag, 1u);                                                              \
+            (w) = 0;                                                                                                   \
+        }                                                                                                              \
+    } while (0)
+#else
+#define TG_BOUNDS_FIELDS
+#define TG_BOUNDS_INIT(p, graph)                                                                                       \
+    do {                                                                                                               \
+    } while (0)
+#define TG_CHECK_VERTEX(p, w)                                                                                          \
+    do {                                                                                                               \
+    } while (0)
+#endif
+unsigned int *debug_bounds_flag(); // host side (api.hip): the registered device word, or NULL
+
 // ---- wave64 helpers -------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

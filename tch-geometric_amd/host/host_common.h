@@ -152,28 +152,44 @@ inline void raise_if_flagged(int64_t flag, const char *what) {
 
 // The values of an adjacency's `indices` become `ptrs[w]` look-ups one hop later (neighbor_sampling.rs:197-198,
 // random_walk.rs:41), where the reference panics on an id beyond the table and an unchecked kernel would read out of
-// bounds.  One pass over `indices` per graph, remembered by (address, length, bound) so that calls on a resident
-// graph pay nothing; a graph rebuilt at the same address with the same length is taken as already checked.
+// bounds.  One pass over `indices` per graph, remembered so that calls on a resident graph pay nothing.  The memo is keyed
+// on the tensor's IDENTITY AND CONTENT VERSION -- storage object, address, length, bound, and the version counter that
+// every in-place write bumps -- and holds a weak reference to the storage: a new tensor that the caching allocator puts
+// at the same address has another storage object (the entry of the dead one is dropped), and a graph mutated in place
+// has another version; both are checked again.  (Writes that bypass autograd's version counter -- raw kernels on
+// data_ptr() -- are the caller's to re-validate; the C ABI states the contract.)
 inline void check_graph_ids(const Tensor &indices, int64_t hi, const c10::Device &dev, const char *what) {
     struct Key {
-        const void *p;
+        c10::weak_intrusive_ptr<c10::StorageImpl> storage;
+        const void *impl, *p;
         int64_t n, hi;
+        uint32_t version;
     };
     static std::mutex mu;
     static std::vector<Key> seen;
     if (indices.numel() == 0) return;
-    const Key k{indices.data_ptr(), indices.numel(), hi};
+    c10::StorageImpl *impl = indices.storage().unsafeGetStorageImpl();
+    const void *ptr = indices.data_ptr();
+    const uint32_t version = indices._version();
     {
         std::lock_guard<std::mutex> lock(mu);
-        for (const Key &s : seen)
-            if (s.p == k.p && s.n == k.n && s.hi == k.hi) return;
+        for (size_t i = 0; i < seen.size();) {
+            if (seen[i].storage.expired()) { // the tensor it described is gone: its address may be reused
+                seen.erase(seen.begin() + (long)i);
+                continue;
+            }
+            const Key &s = seen[i];
+            if (s.impl == impl && s.p == ptr && s.n == indices.numel() && s.hi == hi && s.version == version) return;
+            ++i;
+        }
     }
     RangeCheck rc(dev);
     rc.add(indices, hi);
     rc.verify(what);
     std::lock_guard<std::mutex> lock(mu);
     if (seen.size() >= 64) seen.erase(seen.begin());
-    seen.push_back(k);
+    seen.push_back(Key{c10::weak_intrusive_ptr<c10::StorageImpl>(indices.storage().getWeakStorageImpl()), impl, ptr,
+                       indices.numel(), hi, version});
 }
 
 inline std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257

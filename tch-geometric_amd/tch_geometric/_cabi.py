@@ -28,7 +28,8 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_sanitize_range", "tg_ns_hop_segments", "tg_het_hop_begin_all", "tg_het_hop_end_all", "tg_part_requests", "tg_part_count", "tg_part_scan_workspace_bytes", "tg_part_sample", "tg_part_emit", "tg_part_unpack", "tg_part_pack", "tg_compact_rows", "tg_budget_capacity",
            "tg_budget_workspace_bytes", "tg_budget_sample", "tg_ns_homo_workspace_bytes", "tg_ns_homo_batched_ws", "tg_het_meta_words", "tg_het_step_begin",
            "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
-           "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol"]
+           "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol",
+           "tg_debug_bounds_set_flag"]
 
 
 class TgGraph(C.Structure):
