@@ -89,6 +89,83 @@ inline Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
     check_kind(t, want);
     return t.to(dev).contiguous(); // tensor_to_slice assumes contiguity (utils/tensor.rs:57-59)
 }
+// Adjacency tensors (ptrs / indices / per-edge weights and timestamps) that live on the CPU -- the reference's own
+// calling convention: it borrows CPU tensors zero-copy (utils/tensor.rs:50-59) -- are uploaded ONCE and kept resident:
+// a memo keyed on the tensor's storage object, address, length and content version (every in-place write bumps it), with
+// a weak reference to the storage so that the entry of a freed tensor is dropped and its address can be reused safely.
+// RMAT-24's CSC is 2.3 GB = 40 ms per upload; per call that was the whole cost of a "CPU graph" (DESIGN.md 5).
+// Bounded by TG_GRAPH_CACHE_GB (default 64) of device memory, least recently used first; graph_cache_clear() drops all.
+struct ResidentGraphs {
+    struct Entry {
+        c10::weak_intrusive_ptr<c10::StorageImpl> storage;
+        const void *impl, *p;
+        int64_t n;
+        uint32_t version;
+        int dev;
+        Tensor copy;
+        uint64_t used;
+    };
+    std::mutex mu;
+    std::vector<Entry> entries;
+    uint64_t tick = 0, hits = 0, uploads = 0;
+    int64_t limit_bytes() const {
+        static const int64_t gb = [] {
+            const char *v = getenv("TG_GRAPH_CACHE_GB");
+            return v ? atoll(v) : 64ll;
+        }();
+        return gb << 30;
+    }
+    int64_t bytes_locked() const {
+        int64_t b = 0;
+        for (const Entry &e : entries) b += (int64_t)e.copy.nbytes();
+        return b;
+    }
+    Tensor get(const Tensor &t, const c10::Device &dev) {
+        c10::StorageImpl *impl = t.storage().unsafeGetStorageImpl();
+        const void *ptr = t.data_ptr();
+        const uint32_t version = t._version();
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            for (size_t i = 0; i < entries.size();) {
+                if (entries[i].storage.expired()) {
+                    entries.erase(entries.begin() + (long)i);
+                    continue;
+                }
+                Entry &e = entries[i];
+                if (e.impl == impl && e.p == ptr && e.n == t.numel() && e.version == version && e.dev == dev.index() &&
+                    e.copy.scalar_type() == t.scalar_type()) {
+                    e.used = ++tick;
+                    ++hits;
+                    return e.copy;
+                }
+                ++i;
+            }
+        }
+        Tensor copy = t.contiguous().to(dev);
+        std::lock_guard<std::mutex> lock(mu);
+        ++uploads;
+        if ((int64_t)copy.nbytes() > limit_bytes()) return copy; // larger than the whole budget: not kept
+        while (!entries.empty() && bytes_locked() + (int64_t)copy.nbytes() > limit_bytes()) {
+            size_t lru = 0;
+            for (size_t i = 1; i < entries.size(); ++i)
+                if (entries[i].used < entries[lru].used) lru = i;
+            entries.erase(entries.begin() + (long)lru);
+        }
+        entries.push_back(Entry{c10::weak_intrusive_ptr<c10::StorageImpl>(t.storage().getWeakStorageImpl()), impl, ptr,
+                                t.numel(), version, (int)dev.index(), copy, ++tick});
+        return copy;
+    }
+    static ResidentGraphs &instance() {
+        static ResidentGraphs g;
+        return g;
+    }
+};
+// an adjacency argument on `dev`: device tensors pass through, CPU tensors come from the resident memo
+inline Tensor on_graph(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
+    check_kind(t, want);
+    if (t.is_cuda() || t.numel() == 0) return t.to(dev).contiguous();
+    return ResidentGraphs::instance().get(t, dev);
+}
 inline Tensor back(const Tensor &t, const c10::Device &out_dev) { return t.device() == out_dev ? t : t.to(out_dev); }
 inline at::TensorOptions i64(const c10::Device &dev) { return at::TensorOptions().dtype(at::kLong).device(dev); }
 

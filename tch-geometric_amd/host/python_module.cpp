@@ -446,12 +446,12 @@ py::tuple neighbor_sampling_homogenous(const Tensor &col_ptrs, const Tensor &row
     validate_fanout(num_neighbors);
     const c10::Device dev = compute_device({&col_ptrs, &row_indices, &inputs});
     DeviceGuard guard(dev);
-    Tensor ptrs = on(col_ptrs, dev, at::kLong), idx = on(row_indices, dev, at::kLong);
+    Tensor ptrs = on_graph(col_ptrs, dev, at::kLong), idx = on_graph(row_indices, dev, at::kLong);
     Tensor seeds = on(inputs, dev, at::kLong).reshape({-1});
     Tensor w, ts, st;
-    if (s.kind == TG_SAMPLER_WEIGHTED) w = on(as_homogeneous(s.weights), dev, at::kDouble); // python.rs:214
+    if (s.kind == TG_SAMPLER_WEIGHTED) w = on_graph(as_homogeneous(s.weights), dev, at::kDouble); // python.rs:214
     if (f.mode != TG_FILTER_NONE) {
-        ts = on(as_homogeneous(f.timestamps), dev, at::kLong); // python.rs:149
+        ts = on_graph(as_homogeneous(f.timestamps), dev, at::kLong); // python.rs:149
         st = on(as_homogeneous(f.state), dev, at::kLong).reshape({-1});
         if (st.numel() != seeds.numel()) throw py::value_error("filter state must have one entry per input");
     }
@@ -512,16 +512,16 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
         if (!col_ptrs.contains(py::str(r.key))) continue; // graphs are keyed by col_ptrs (python.rs:294)
         r.src = tix.at(std::get<0>(et));
         r.dst = tix.at(std::get<2>(et));
-        r.ptrs = on(col_ptrs[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
-        r.idx = on(row_indices[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
+        r.ptrs = on_graph(col_ptrs[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
+        r.idx = on_graph(row_indices[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
         r.active = num_neighbors.contains(py::str(r.key)); // the hop loop iterates num_neighbors (:294)
         if (r.active) {
             r.fanout = num_neighbors[py::str(r.key)].cast<std::vector<int64_t>>();
             validate_fanout(r.fanout);
             if ((int64_t)r.fanout.size() < num_hops) throw py::index_error("num_neighbors[" + r.key + "] is shorter than num_hops");
         }
-        if (s.kind == TG_SAMPLER_WEIGHTED) r.w = on(from_dict(s.weights, r.key), dev, at::kDouble);
-        if (has_state) r.ts = on(from_dict(f.timestamps, r.key), dev, at::kLong);
+        if (s.kind == TG_SAMPLER_WEIGHTED) r.w = on_graph(from_dict(s.weights, r.key), dev, at::kDouble);
+        if (has_state) r.ts = on_graph(from_dict(f.timestamps, r.key), dev, at::kLong);
         rels.push_back(std::move(r));
     }
 
@@ -1024,7 +1024,7 @@ Tensor random_walk(const Tensor &row_ptrs, const Tensor &col_indices, const Tens
                    float q) {
     const c10::Device dev = compute_device({&row_ptrs, &col_indices, &start});
     DeviceGuard guard(dev);
-    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
+    Tensor ptrs = on_graph(row_ptrs, dev, at::kLong), idx = on_graph(col_indices, dev, at::kLong);
     Tensor st = on(start, dev, at::kLong).reshape({-1});
     if (walk_length < 0) throw py::value_error("walk_length must be >= 0");
     RangeCheck rc(dev);
@@ -1050,8 +1050,8 @@ std::tuple<Tensor, Tensor> tempo_random_walk(const Tensor &row_ptrs, const Tenso
                                              std::pair<int64_t, int64_t> window) {
     const c10::Device dev = compute_device({&row_ptrs, &col_indices, &start});
     DeviceGuard guard(dev);
-    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
-    Tensor nts = on(node_timestamps, dev, at::kLong), ets = on(edge_timestamps, dev, at::kLong);
+    Tensor ptrs = on_graph(row_ptrs, dev, at::kLong), idx = on_graph(col_indices, dev, at::kLong);
+    Tensor nts = on_graph(node_timestamps, dev, at::kLong), ets = on_graph(edge_timestamps, dev, at::kLong);
     Tensor st = on(start, dev, at::kLong).reshape({-1}), sts = on(start_timestamps, dev, at::kLong).reshape({-1});
     if (walk_length < 0) throw py::value_error("walk_length must be >= 0");
     if (sts.numel() != st.numel()) throw py::value_error("start_timestamps must have one entry per start node");
@@ -1090,8 +1090,8 @@ std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, cons
     else throw py::value_error("Unknown bias type: " + bias_type); // python.rs:666-671
     const c10::Device dev = compute_device({&row_ptrs, &col_indices, &start});
     DeviceGuard guard(dev);
-    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
-    Tensor nts = on(node_timestamps, dev, at::kLong), ets = on(edge_timestamps, dev, at::kLong);
+    Tensor ptrs = on_graph(row_ptrs, dev, at::kLong), idx = on_graph(col_indices, dev, at::kLong);
+    Tensor nts = on_graph(node_timestamps, dev, at::kLong), ets = on_graph(edge_timestamps, dev, at::kLong);
     Tensor st = on(start, dev, at::kLong).reshape({-1}), sts = on(start_timestamps, dev, at::kLong).reshape({-1});
     if (walk_length < 1) throw py::value_error("walk_length must be >= 1");
     if (retry_count < 0) throw py::value_error("retry_count must be >= 0");
@@ -1145,6 +1145,23 @@ PYBIND11_MODULE(tch_geometric, m) {
         st.seed = s;
         st.call = 0;
     }, py::arg("seed"), "Seed the global (seed, call counter) state; every operator call consumes one call id.");
+    // additive: CPU-resident adjacency tensors are uploaded once and kept on the device (host_common.h ResidentGraphs)
+    m.def("graph_cache_info", [] {
+        ResidentGraphs &g = ResidentGraphs::instance();
+        std::lock_guard<std::mutex> lk(g.mu);
+        py::dict d;
+        d["entries"] = g.entries.size();
+        d["bytes"] = g.bytes_locked();
+        d["limit_bytes"] = g.limit_bytes();
+        d["hits"] = g.hits;
+        d["uploads"] = g.uploads;
+        return d;
+    }, "Device copies kept of CPU-resident adjacency tensors: {entries, bytes, limit_bytes, hits, uploads}.");
+    m.def("graph_cache_clear", [] {
+        ResidentGraphs &g = ResidentGraphs::instance();
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.entries.clear();
+    }, "Drop every device copy of a CPU-resident adjacency tensor.");
     m.def("rng_state", [] {
         RngState &st = rng_state();
         std::lock_guard<std::mutex> lk(st.mu);

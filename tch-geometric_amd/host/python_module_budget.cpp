@@ -40,8 +40,8 @@ py::tuple budget_sampling(const std::vector<std::string> &node_types,
         if (!col_ptrs.contains(py::str(r.key))) continue; // graphs are keyed by col_ptrs (python.rs:509-523)
         r.src = tix.at(std::get<0>(et));
         r.dst = tix.at(std::get<2>(et));
-        r.ptrs = on(col_ptrs[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
-        r.idx = on(row_indices[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
+        r.ptrs = on_graph(col_ptrs[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
+        r.idx = on_graph(row_indices[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
         if (rts.contains(py::str(r.key))) r.ts = on(rts[py::str(r.key)].cast<Tensor>(), dev, at::kLong);
         rels.push_back(std::move(r));
     }

@@ -37,8 +37,8 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
         keys.push_back(key);
         rel_src.push_back(tix.at(std::get<0>(et)));
         rel_dst.push_back(tix.at(std::get<2>(et)));
-        ptrs.push_back(on(col_ptrs[py::str(key)].cast<Tensor>(), dev, at::kLong));
-        idx.push_back(on(row_indices[py::str(key)].cast<Tensor>(), dev, at::kLong));
+        ptrs.push_back(on_graph(col_ptrs[py::str(key)].cast<Tensor>(), dev, at::kLong));
+        idx.push_back(on_graph(row_indices[py::str(key)].cast<Tensor>(), dev, at::kLong));
         rts.push_back(rts_dict.contains(py::str(key)) ? on(rts_dict[py::str(key)].cast<Tensor>(), dev, at::kLong)
                                                       : Tensor());
     }

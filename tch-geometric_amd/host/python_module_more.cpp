@@ -89,7 +89,7 @@ py::tuple negative_sample_neighbors_homogenous(const Tensor &row_ptrs, const Ten
                                                int64_t num_neg, int64_t try_count) {
     const c10::Device dev = compute_device({&row_ptrs, &col_indices, &inputs});
     DeviceGuard guard(dev);
-    Tensor ptrs = on(row_ptrs, dev, at::kLong), idx = on(col_indices, dev, at::kLong);
+    Tensor ptrs = on_graph(row_ptrs, dev, at::kLong), idx = on_graph(col_indices, dev, at::kLong);
     Tensor in = on(inputs, dev, at::kLong).reshape({-1});
     if (graph_size.second < 1) throw py::value_error("graph_size[1] must be >= 1 (the reference panics on an empty range)");
     NegRun r;
@@ -133,8 +133,8 @@ py::tuple negative_sample_neighbors_heterogenous(const std::vector<std::string> 
         keys.push_back(key);
         rel_src.push_back(tix.at(std::get<0>(et)));
         rel_dst.push_back(tix.at(std::get<2>(et)));
-        ptrs.push_back(on(row_ptrs[py::str(key)].cast<Tensor>(), dev, at::kLong));
-        idx.push_back(on(col_indices[py::str(key)].cast<Tensor>(), dev, at::kLong));
+        ptrs.push_back(on_graph(row_ptrs[py::str(key)].cast<Tensor>(), dev, at::kLong));
+        idx.push_back(on_graph(col_indices[py::str(key)].cast<Tensor>(), dev, at::kLong));
         auto sz = sizes[py::str(key)].cast<std::pair<int64_t, int64_t>>();
         if (sz.second < 1) throw py::value_error("sizes[" + key + "][1] must be >= 1");
         node_count.push_back(sz.second);

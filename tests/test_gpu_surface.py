@@ -315,3 +315,37 @@ def test_concurrent_callers_on_their_own_streams(tg):
             assert match, "a concurrent call returned something no call id of the counter produces"
             used.add(match[0])
     assert len(used) == n_threads * per and tg.rng_state()[1] == n_threads * per
+
+
+def test_cpu_resident_graph_is_uploaded_once(tg):
+    """The reference borrows CPU tensors (utils/tensor.rs:50-59); here a CPU-resident adjacency is uploaded on first use
+    and kept on the device, keyed on the tensor's identity and content version: later calls reuse the copy, an in-place
+    write or another tensor uploads again.  Results equal the call with device tensors."""
+    DEV = "cuda:0"
+    ei = torch.from_numpy(load_karate()[0])
+    ptrs_d, idx_d, _ = tg.to_csc(ei.to(DEV), 34)
+    ptrs, idx = ptrs_d.cpu(), idx_d.cpu()
+    inputs = torch.tensor([0, 1, 4, 5])
+    tg.graph_cache_clear()
+    base = tg.graph_cache_info()
+    outs = []
+    for _ in range(3):
+        tg.seed(11)
+        outs.append(tg.neighbor_sampling_homogenous(ptrs, idx, inputs, [5, 5]))
+    info = tg.graph_cache_info()
+    assert info["uploads"] - base["uploads"] == 2 and info["hits"] - base["hits"] == 4 and info["entries"] == 2
+    tg.seed(11)
+    ref = tg.neighbor_sampling_homogenous(ptrs_d, idx_d, inputs.to(DEV), [5, 5])
+    for o in outs:
+        assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(o[:4], ref[:4])) and o[4] == ref[4]
+        assert not o[0].is_cuda                                        # results come back where the inputs live
+    idx[0] = idx[0]                                                    # an in-place write: the content version moves on
+    tg.seed(11)
+    tg.neighbor_sampling_homogenous(ptrs, idx, inputs, [5, 5])
+    assert tg.graph_cache_info()["uploads"] - base["uploads"] == 3
+    idx2 = idx.clone()                                                 # another tensor with the same content
+    tg.neighbor_sampling_homogenous(ptrs, idx2, inputs, [5, 5])
+    assert tg.graph_cache_info()["uploads"] - base["uploads"] == 4
+    del idx2
+    tg.graph_cache_clear()
+    assert tg.graph_cache_info()["entries"] == 0
