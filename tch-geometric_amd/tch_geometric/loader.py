@@ -5,7 +5,9 @@ The reference's surface is one call per mini-batch (examples/neighbor_sampling.p
 launch: one `tg_ns_homo_batched` launch samples them all (batch j of the epoch draws with call id `call_id0 + j`, so
 every mini-batch equals what `neighbor_sampling_homogenous` returns for that (seed, call id) -- and the oracle), one
 `tg_gather_rows` launch per attribute fetches the feature rows of all their nodes, and the mini-batches are handed
-out as views.  Everything stays in HBM; the host learns only the per-batch sizes (one read-back per launch).
+out as lazily built views of that `SuperBatch` (or the super-batch itself: `NeighborLoader.super_batches()`).
+Everything stays in HBM; the host learns only the per-batch sizes (one read-back per launch, taken from pinned memory
+behind a launch that runs one super-batch ahead on a side stream).
 """
 from typing import Iterator, List, Optional
 
@@ -25,7 +27,88 @@ def _checked_inputs(nodes: Tensor, n_nodes: int) -> Tensor:
     return nodes
 
 
+class SuperBatch:
+    """`prefetch` mini-batches sampled by ONE launch, as flat batch-major device tensors plus per-batch offsets -- the unit
+    the loader really works in.  `n_id` [sum nodes], `edge_index` [2, sum edges] (batch-local numbering), `e_id`
+    [sum edges] (COO edge ids of the source graph), one flat tensor per node / edge attribute, `node_ptr` / `edge_ptr`
+    (python lists, length G + 1), `layer_offsets` [G][hops] triples, `call_id0`.  Iterating (or indexing) yields the
+    mini-batches as `MiniBatch` views; a consumer that can take the whole super-batch (a model over a batch of
+    sub-graphs with `ptr` offsets) pays no per-mini-batch host work at all."""
+    __slots__ = ("n_id", "edge_index", "e_id", "node_attrs", "edge_attrs", "node_ptr", "edge_ptr", "layer_offsets",
+                 "batch_size", "call_id0", "n_hops")
+
+    def __len__(self):
+        return len(self.node_ptr) - 1
+
+    def __getitem__(self, j):
+        if j < 0:
+            j += len(self)
+        if not 0 <= j < len(self):
+            raise IndexError(j)
+        return MiniBatch(self, j)
+
+    def __iter__(self):
+        for j in range(len(self.node_ptr) - 1):
+            yield MiniBatch(self, j)
+
+    @property
+    def num_nodes(self):
+        return self.node_ptr[-1]
+
+    @property
+    def num_edges(self):
+        return self.edge_ptr[-1]
+
+
+class MiniBatch:
+    """Mini-batch j of a SuperBatch.  Nothing is built until it is asked for: sizes are python ints, tensors are views
+    (torch.narrow) made on first access -- handing a mini-batch out costs well under a microsecond of host time instead
+    of the ~20 us an eagerly built container with a dozen attributes took (profiles/r01/loader_end_to_end.json)."""
+    __slots__ = ("_sb", "_j", "_cache")
+
+    def __init__(self, sb, j):
+        self._sb, self._j, self._cache = sb, j, None
+
+    num_nodes = property(lambda self: self._sb.node_ptr[self._j + 1] - self._sb.node_ptr[self._j])
+    num_edges = property(lambda self: self._sb.edge_ptr[self._j + 1] - self._sb.edge_ptr[self._j])
+    batch_size = property(lambda self: self._sb.batch_size)
+    call_id = property(lambda self: self._sb.call_id0 + self._j)
+    layer_offsets = property(lambda self: [tuple(x) for x in self._sb.layer_offsets[self._j][:self._sb.n_hops]])
+
+    def _node(self, t):
+        a = self._sb.node_ptr[self._j]
+        return t.narrow(0, a, self._sb.node_ptr[self._j + 1] - a)
+
+    def _edge(self, t, dim=0):
+        a = self._sb.edge_ptr[self._j]
+        return t.narrow(dim, a, self._sb.edge_ptr[self._j + 1] - a)
+
+    n_id = property(lambda self: self._node(self._sb.n_id))
+    e_id = property(lambda self: self._edge(self._sb.e_id))
+    edge_index = property(lambda self: self._edge(self._sb.edge_index, 1))
+
+    def __getattr__(self, name):  # node / edge attributes of the source graph (x, y, edge_attr, ...)
+        sb = object.__getattribute__(self, "_sb")
+        if name in sb.node_attrs:
+            return self._node(sb.node_attrs[name])
+        if name in sb.edge_attrs:
+            return self._edge(sb.edge_attrs[name])
+        raise AttributeError(name)
+
+    def tensor_items(self):
+        sb = self._sb
+        items = [("n_id", self.n_id), ("e_id", self.e_id), ("edge_index", self.edge_index)]
+        items += [(k, self._node(v)) for k, v in sb.node_attrs.items()]
+        items += [(k, self._edge(v)) for k, v in sb.edge_attrs.items()]
+        return items
+
+
 class NeighborLoader:
+    """One launch samples `prefetch` mini-batches; while the caller consumes super-batch i, super-batch i + 1 is already
+    being sampled on a side stream into the other of two slab sets (its sizes travel to pinned host memory behind the
+    kernel), so neither the launch nor its one read-back sits on the consumer's path.  Launches of >= 2 048 mini-batches
+    take the window-ordered form (workspace kept by the loader)."""
+
     def __init__(self, data, num_neighbors: List[int], input_nodes: Optional[Tensor] = None, batch_size: int = 1024,
                  prefetch: int = 16, replace: bool = False, shuffle: bool = False, drop_last: bool = False,
                  seed: int = 0, call_id0: int = 0, device="cuda"):
@@ -51,42 +134,80 @@ class NeighborLoader:
                 self._node_attrs.append((key, value.to(self.device)))
             elif kind == "edge":
                 self._edge_attrs.append((key, value.to(self.device)))
-        self._out = None
+        self._slabs = [None, None]          # two slab sets: one being consumed, one being sampled
+        self._ws = None
+        self._side = None
         self.epoch = 0
 
     def __len__(self) -> int:
         n = self.input_nodes.numel()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def _emit(self, seeds: Tensor, first_batch: int) -> Iterator[Graph]:
-        """seeds: [G, B] -- sample G mini-batches in one launch, gather their attributes, yield them"""
+    # ---- stage 1 (side stream): sample G mini-batches into slab set `which`, sizes -> pinned host memory
+    def _sample(self, which, seeds: Tensor, first_batch: int):
         G, B = seeds.shape
-        if self._out is None or self._out.n_batches < G or self._out.n_seeds != B:
-            self._out = _cabi.NsBatchedOut(max(G, min(self.prefetch, len(self))), B, self.fanout, self.device)
-        out = self._out
-        _cabi.ns_homo_batched(self._graph, seeds.contiguous(), self.fanout, self.seed, self.call_id0 + first_batch, out,
-                              sampler=self.sampler)
-        counts = out.counts[:G].cpu()                      # the launch's only read-back
-        n_nodes, n_edges = counts[:, 0].tolist(), counts[:, 1].tolist()
-        lo = out.layer_offsets[:G].cpu().tolist()
-        n_id, rows, cols, e_ptr = _cabi.ns_homo_compact(out, G, counts)  # copies: the slabs are reused by the next launch
-        rows_of = lambda table, index: _cabi.gather_rows(table, index)[0]   # ids come from the sampler: no range read-back
-        e_id = rows_of(self.perm, e_ptr)                    # COO edge ids of the source graph
-        node_parts = {k: torch.split(rows_of(v, n_id), n_nodes) for k, v in self._node_attrs}
-        edge_parts = {k: torch.split(rows_of(v, e_id), n_edges) for k, v in self._edge_attrs}
-        n_parts, e_parts = torch.split(n_id, n_nodes), torch.split(e_id, n_edges)
-        ei_parts = torch.split(torch.stack([rows, cols]), n_edges, dim=1)    # [2, E_b] views of one [2, sum E] tensor
-        for b in range(G):
-            g = Graph(num_nodes=n_nodes[b], n_id=n_parts[b], e_id=e_parts[b], batch_size=B,
-                      edge_index=ei_parts[b],
-                      layer_offsets=[tuple(x) for x in lo[b][:len(self.fanout)]], call_id=self.call_id0 + first_batch + b)
-            for k, parts in node_parts.items():
-                setattr(g, k, parts[b])
-            for k, parts in edge_parts.items():
-                setattr(g, k, parts[b])
-            yield g
+        H = len(self.fanout)
+        slab = self._slabs[which]
+        if slab is None or slab["out"].n_batches < G or slab["out"].n_seeds != B:
+            cap = max(G, min(self.prefetch, len(self)))
+            slab = {"out": _cabi.NsBatchedOut(cap, B, self.fanout, self.device),
+                    "counts": torch.empty((cap, 2), dtype=torch.int64).pin_memory(),
+                    "lo": torch.empty((cap, max(H, 1), 3), dtype=torch.int64).pin_memory(),
+                    "free": None}
+            self._slabs[which] = slab
+        if G >= 2048 and self._ws is None:   # many batches per launch: the window-ordered form pays
+            self._ws = _cabi.ns_homo_workspace(max(G, min(self.prefetch, len(self))), B, self.fanout, self.device)
+        cur = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(cur)                # the seeds (and an earlier consumer of this slab set) are ahead of us
+        if slab["free"] is not None:
+            side.wait_event(slab["free"])
+        with torch.cuda.stream(side):
+            seeds = seeds.contiguous()
+            out = slab["out"]
+            _cabi.ns_homo_batched(self._graph, seeds, self.fanout, self.seed, self.call_id0 + first_batch, out,
+                                  sampler=self.sampler, ws=self._ws if G >= 2048 else None)
+            slab["counts"][:G].copy_(out.counts[:G], non_blocking=True)
+            slab["lo"][:G].copy_(out.layer_offsets[:G], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        seeds.record_stream(side)
+        return (which, G, B, first_batch, done)
 
-    def __iter__(self) -> Iterator[Graph]:
+    # ---- stage 2 (caller's stream): flatten, gather the attribute rows
+    def _finish(self, ticket) -> SuperBatch:
+        which, G, B, first_batch, done = ticket
+        slab = self._slabs[which]
+        out = slab["out"]
+        done.synchronize()                   # the host needs the sizes; the device work it waits for is long done
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        counts = slab["counts"][:G]
+        n_nodes, n_edges = counts[:, 0].tolist(), counts[:, 1].tolist()
+        n_id, rows, cols, e_ptr = _cabi.ns_homo_compact(out, G, counts)   # copies: the slabs go back to the sampler
+        free = torch.cuda.Event()
+        free.record(cur)
+        slab["free"] = free
+        rows_of = lambda table, index: _cabi.gather_rows(table, index)[0]   # ids come from the sampler: no range read-back
+        sb = SuperBatch()
+        sb.n_id, sb.edge_index, sb.e_id = n_id, torch.stack([rows, cols]), rows_of(self.perm, e_ptr)
+        sb.node_attrs = {k: rows_of(v, n_id) for k, v in self._node_attrs}
+        sb.edge_attrs = {k: rows_of(v, sb.e_id) for k, v in self._edge_attrs}
+        ptr_n, ptr_e, a, e = [0], [0], 0, 0
+        for x, y in zip(n_nodes, n_edges):
+            a += x
+            e += y
+            ptr_n.append(a)
+            ptr_e.append(e)
+        sb.node_ptr, sb.edge_ptr = ptr_n, ptr_e
+        sb.layer_offsets = slab["lo"][:G].tolist()
+        sb.batch_size, sb.call_id0, sb.n_hops = B, self.call_id0 + first_batch, len(self.fanout)
+        return sb
+
+    def super_batches(self) -> Iterator[SuperBatch]:
+        """The epoch as super-batches of up to `prefetch` mini-batches; the next one is sampled while this one is used."""
         nodes = self.input_nodes
         epoch = self.epoch                                      # captured: a second iterator is the next epoch
         self.epoch += 1
@@ -99,11 +220,23 @@ class NeighborLoader:
         # every epoch draws afresh, as the reference's global stream does (utils/random.rs:19-22): mini-batch j of
         # epoch e uses call id call_id0 + e * len(self) + j -- reproducible for a fixed (seed, epoch)
         batch0 = epoch * len(self)
+        work = []
         for start in range(0, n_full, self.prefetch):
             G = min(self.prefetch, n_full - start)
-            yield from self._emit(nodes[start * B:(start + G) * B].reshape(G, B), batch0 + start)
+            work.append((nodes[start * B:(start + G) * B].reshape(G, B), batch0 + start))
         if not self.drop_last and n_full * B < n:               # ragged last mini-batch: its own launch
-            yield from self._emit(nodes[n_full * B:].reshape(1, -1), batch0 + n_full)
+            work.append((nodes[n_full * B:].reshape(1, -1), batch0 + n_full))
+        pending = None
+        for i, (seeds, first) in enumerate(work):
+            if pending is None:
+                pending = self._sample(i & 1, seeds, first)
+            ticket = pending
+            pending = self._sample((i + 1) & 1, *work[i + 1]) if i + 1 < len(work) else None
+            yield self._finish(ticket)
+
+    def __iter__(self) -> Iterator[MiniBatch]:
+        for sb in self.super_batches():
+            yield from sb
 
 
 class HeteroNeighborLoader:

@@ -1,6 +1,7 @@
-"""End-to-end mini-batch throughput: seeds -> batched sampling -> feature / label gather -> mini-batch views
+"""End-to-end mini-batch throughput: seeds -> batched sampling -> feature / label gather -> mini-batches
 (tch_geometric.loader.NeighborLoader) on RMAT-24 with a [2^24, D] float32 feature matrix, batch 1024, fanout [15,10].
-Prints one JSON object."""
+Three consumers per prefetch depth: mini-batches whose sizes only are read, mini-batches whose x / y / edge_index views
+are built, and whole super-batches.  Prints one JSON object."""
 import json
 import os
 import sys
@@ -15,39 +16,58 @@ from tch_geometric.loader import NeighborLoader  # noqa: E402
 from tch_geometric.transforms import Graph  # noqa: E402
 
 dev = torch.device("cuda:0")
-scale, D = int(os.environ.get("SCALE", "24")), int(os.environ.get("DIM", "128"))
+scale = int(os.environ.get("SCALE", "24"))
+dims = [int(x) for x in os.environ.get("DIMS", "128,32,0").split(",")]
+prefetches = [int(x) for x in os.environ.get("PREFETCH", "16,256,1024").split(",")]
 n = 1 << scale
 row, col = _cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
-data = Graph(edge_index=torch.stack([row, col]), num_nodes=n)
+ei = torch.stack([row, col])
 del row, col
-data.x = torch.empty((n, D), dtype=torch.float32, device=dev)
-data.x.view(torch.int32)[:] = 1
-data.y = torch.zeros(n, dtype=torch.int64, device=dev)
-n_batches = int(os.environ.get("BATCHES", "2048"))
+n_batches = int(os.environ.get("BATCHES", "8192"))
 seeds = _cabi.seed_batches(0xBA7C4, 0, n_batches, 1024, n, dev).reshape(-1)
-res = {"config": "RMAT-%d, x [%d, %d] f32, %d mini-batches of 1024 seeds, fanout [15, 10]" % (scale, n, D, n_batches)}
-for prefetch in (1, 16, 256):
-    t_build = time.perf_counter()
-    loader = NeighborLoader(data, [15, 10], input_nodes=seeds, batch_size=1024, prefetch=prefetch)
-    torch.cuda.synchronize()
-    t_build = time.perf_counter() - t_build
-    it = iter(loader)
-    for _ in range(min(prefetch, 32)):
-        next(it)                                             # warm-up launch
-    torch.cuda.synchronize()
-    edges = nodes = nb = 0
-    budget = max(prefetch, min(n_batches - prefetch, 64 if prefetch == 1 else 1024))
-    t0 = time.perf_counter()
-    for b in it:
-        edges += b.e_id.numel()
-        nodes += b.num_nodes
-        nb += 1
-        if nb >= budget:
-            break
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    res["prefetch_%d" % prefetch] = {"mini_batches_per_s": nb / dt, "sampled_edges_per_s": edges / dt,
-                                     "feature_GBps": nodes * D * 4 / dt / 1e9, "ms_per_mini_batch": dt / nb * 1e3,
-                                     "loader_setup_s": t_build}
-    del loader, it
+res = {"config": "RMAT-%d, %d mini-batches of 1024 seeds per epoch, fanout [15, 10]; x [2^%d, D] f32 + y i64" % (scale, n_batches, scale)}
+for D in dims:
+    data = Graph(edge_index=ei, num_nodes=n)
+    if D:
+        data.x = torch.empty((n, D), dtype=torch.float32, device=dev)
+        data.x.view(torch.int32)[:] = 1
+        data.y = torch.zeros(n, dtype=torch.int64, device=dev)
+    for prefetch in prefetches:
+        loader = NeighborLoader(data, [15, 10], input_nodes=seeds, batch_size=1024, prefetch=prefetch)
+        entry = {}
+        for k, sb in enumerate(loader.super_batches()):   # un-timed: slabs, pinned buffers and the allocator's pools come up
+            if k >= 2:
+                break
+        torch.cuda.synchronize()
+        for mode in ("mini_batches_sizes_only", "mini_batches_views_built", "super_batches"):
+            it = loader.super_batches() if mode == "super_batches" else iter(loader)
+            budget = min(n_batches, max(4 * prefetch, 2048))
+            warm = prefetch if mode != "super_batches" else 1
+            for _ in range(warm):
+                next(it)
+            torch.cuda.synchronize()
+            edges = nodes = nb = 0
+            t0 = time.perf_counter()
+            for b in it:
+                if mode == "super_batches":
+                    edges += b.num_edges
+                    nodes += b.num_nodes
+                    nb += len(b)
+                else:
+                    edges += b.num_edges
+                    nodes += b.num_nodes
+                    nb += 1
+                    if mode == "mini_batches_views_built":
+                        _ = (b.n_id, b.edge_index, b.x, b.y) if D else (b.n_id, b.edge_index)
+                if nb >= budget:
+                    break
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            del it
+            entry[mode] = {"mini_batches_per_s": round(nb / dt), "G_sampled_edges_per_s": round(edges / dt / 1e9, 3),
+                           "feature_TBps_out": round(nodes * D * 4 / dt / 1e12, 3), "us_per_mini_batch": round(dt / nb * 1e6, 2)}
+        res["D%d_prefetch%d" % (D, prefetch)] = entry
+        print(json.dumps({"D%d_prefetch%d" % (D, prefetch): entry}), file=sys.stderr, flush=True)
+        del loader
+    del data
 print(json.dumps(res))
