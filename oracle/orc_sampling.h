@@ -111,22 +111,57 @@ static inline int64_t orc_replacement(orc_ctx *c, uint64_t id, int64_t n, int64_
     return k;
 }
 
+/* philox-mode's running weight sum: BLOCKED, so that a wavefront can form it without a 64-deep dependent chain.
+ * The candidates' RAW positions (position in the column / in the live list; excluded positions count as weight 0.0,
+ * which an IEEE sum passes through unchanged) are cut into chunks of 64 from position 0; inside a chunk the inclusive
+ * prefix is a Kogge-Stone scan -- for d = 1, 2, 4, 8, 16, 32: y[i] += y[i - d] (i >= d), all lanes at once -- in f64; the
+ * sum before a chunk (`carry`) is the left-to-right sum of the previous chunks' totals y[63]; the running sum at raw
+ * position r is carry + y[r mod 64].  ref-mode keeps the reference's literal left-to-right sum (sampling.rs:40,48); the two
+ * differ in the last bits of a double only, and the kernels implement exactly this order (tg_device.h
+ * wave_blocked_prefix_f64). */
+static inline void orc_blocked_prefix(const double *x, int64_t n_raw, double *out) {
+    double carry = 0.0;
+    for (int64_t base = 0; base < n_raw; base += 64) {
+        double y[64], t[64];
+        for (int i = 0; i < 64; i++) y[i] = (base + i < n_raw) ? x[base + i] : 0.0;
+        for (int d = 1; d < 64; d <<= 1) {
+            for (int i = 0; i < 64; i++) t[i] = (i >= d) ? y[i] + y[i - d] : y[i];
+            for (int i = 0; i < 64; i++) y[i] = t[i];
+        }
+        for (int i = 0; i < 64 && base + i < n_raw; i++) out[base + i] = carry + y[i];
+        carry = carry + y[63];
+    }
+}
+
 /* src/utils/sampling.rs:28-55 reservoir_sampling_weighted over positions
  * [0,n) with weights w[pos]; returns min(n,k), or -1 where the reference
  * panics (empty float range: running weight sum <= 0, sampling.rs:49).
- * Philox mode keeps the left-to-right running sum of the reference. */
+ * raw_pos[i] (ascending; NULL = i) is candidate i's raw position among n_raw, which philox-mode's blocked running sum is
+ * defined on (above); ref-mode sums left to right as the reference does. */
 static inline int64_t orc_reservoir_weighted(orc_ctx *c, uint64_t id, int64_t n, int64_t k, const double *w,
-                                             int64_t *dst) {
+                                             int64_t *dst, const int64_t *raw_pos, int64_t n_raw) {
     int64_t filled = 0;
     double w_sum = 0.0;
+    double *blocked = NULL;
+    if (c->rng->mode != ORC_RNG_REF && n > 0) {
+        if (!raw_pos) n_raw = n;
+        double *x = (double *)calloc((size_t)n_raw, sizeof(double));
+        blocked = (double *)malloc(sizeof(double) * (size_t)n_raw);
+        for (int64_t i = 0; i < n; i++) x[raw_pos ? raw_pos[i] : i] = w[i];
+        orc_blocked_prefix(x, n_raw, blocked);
+        free(x);
+    }
     for (int64_t i = 0; i < k && i < n; i++) { /* sampling.rs:37-45 */
         dst[i] = i;
         w_sum = w_sum + w[i];
         filled++;
     }
     for (int64_t i = k; i < n; i++) { /* sampling.rs:47-53 */
-        w_sum = w_sum + w[i];
-        if (!(0.0 < w_sum)) return -1;
+        w_sum = blocked ? blocked[raw_pos ? raw_pos[i] : i] : w_sum + w[i];
+        if (!(0.0 < w_sum)) {
+            free(blocked);
+            return -1;
+        }
         double j;
         uint64_t slot_x = 0;
         if (c->rng->mode == ORC_RNG_REF) {
@@ -142,6 +177,7 @@ static inline int64_t orc_reservoir_weighted(orc_ctx *c, uint64_t id, int64_t n,
             dst[slot] = i;
         }
     }
+    free(blocked);
     return filled;
 }
 

@@ -255,7 +255,14 @@ static int64_t orc_sample_vertex(orc_ctx *c, const orc_ns_cfg *cfg, orc_sampler_
         cnt = (n > 0) ? orc_replacement(c, id, n, k, st->dst) : 0; /* neighbor_sampling.rs:118-122 */
         break;
     case ORC_SAMPLER_WEIGHTED:
-        cnt = orc_reservoir_weighted(c, id, n, k, st->cw, st->dst);
+        /* raw positions = positions in the column (st->cand holds edge pointers, b the column start) */
+        if (cfg->filter_mode != ORC_FILTER_NONE) {
+            int64_t *raw = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+            for (int64_t q = 0; q < n; q++) raw[q] = st->cand[q] - b;
+            cnt = orc_reservoir_weighted(c, id, n, k, st->cw, st->dst, raw, deg);
+            free(raw);
+        } else
+            cnt = orc_reservoir_weighted(c, id, n, k, st->cw, st->dst, NULL, n);
         if (cnt < 0) return -1;
         break;
     default: {
@@ -1187,7 +1194,7 @@ ORC_API orc_het_out *orc_hgt(int32_t T, int32_t R, const int32_t *rel_src, const
                 }
             int64_t *dst = (int64_t *)malloc(sizeof(int64_t) * (size_t)(k ? k : 1));
             int64_t cnt = 0;
-            if (k > 0) cnt = orc_reservoir_weighted(&c, (uint64_t)(layer * T + t), n, k, w, dst);
+            if (k > 0) cnt = orc_reservoir_weighted(&c, (uint64_t)(layer * T + t), n, k, w, dst, NULL, n);
             if (cnt < 0) {
                 *status = -1;
                 cnt = 0;

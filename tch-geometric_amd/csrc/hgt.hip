@@ -350,7 +350,7 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
             wv = sc * sc;
         }
         double tot;
-        const double pref = wave_serial_prefix_f64(wv, w_sum, &tot, pbuf); // left-to-right sum, sampling.rs:40,48
+        const double pref = wave_blocked_prefix_f64(wv, w_sum, &tot); // blocked running sum, sampling.rs:40,48
         w_sum = tot;
         int64_t hit = -1;
         if (ok && m >= k) {

@@ -345,7 +345,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                         if (weighted) { // sampling.rs:28-55
                             const double wv = ok ? wvv[u] : 0.0;
                             double tot;
-                            const double pref = wave_serial_prefix_f64(wv, w_sum, &tot, pbuf);
+                            const double pref = wave_blocked_prefix_f64(wv, w_sum, &tot);
                             w_sum = tot;
                             if (ok && rank >= (uint32_t)k) {
                                 if (!(0.0 < pref)) {

@@ -354,7 +354,7 @@ __global__ void hw_select_kernel(const HopScanParams p) {
     const int kmax = p.k;
     int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem) + (size_t)wave * (2 * kmax + 64);
     uint32_t *slot_rank = reinterpret_cast<uint32_t *>(slot_ptr + kmax);
-    double *pbuf = reinterpret_cast<double *>(slot_ptr + 2 * kmax); // 64 doubles for the serial prefix
+    // (64 doubles behind slot_ptr used to hold the serial prefix; the blocked running sum needs no scratch)
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -390,7 +390,7 @@ __global__ void hw_select_kernel(const HopScanParams p) {
                     const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
                     const double wv = ok ? wvv[u] : 0.0; // x + 0.0 == x: excluded edges leave the running sum alone
                     double tot;
-                    const double pref = wave_serial_prefix_f64(wv, w_sum, &tot, pbuf); // left-to-right, sampling.rs:40,48
+                    const double pref = wave_blocked_prefix_f64(wv, w_sum, &tot); // blocked running sum, sampling.rs:40,48
                     w_sum = tot;
                     uint32_t hit_slot = 0xffffffffu;
                     if (ok && rank >= (uint32_t)k) {

@@ -162,6 +162,22 @@ __device__ __forceinline__ void wave_lds_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// philox-mode's BLOCKED running weight sum (the CPU checker restates it as orc_blocked_prefix): inclusive prefix of one f64 per
+// lane as a Kogge-Stone scan -- for d = 1, 2, 4, 8, 16, 32: v += (lane >= d ? v of lane - d : nothing), every lane at
+// once -- then `carry` (the left-to-right sum of the earlier chunks' totals) is added.  Six dependent adds per chunk of 64
+// candidates instead of 64: the reference's literal left-to-right sum made the weighted sampler's time the length of the
+// longest column's chain.  *total = the value after lane 63.  All 64 lanes must be active.
+__device__ __forceinline__ double wave_blocked_prefix_f64(double v, double carry, double *total) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double u = __shfl_up(v, d, 64);
+        if (lane >= d) v = v + u;
+    }
+    *total = carry + __shfl(v, 63, 64);
+    return carry + v;
+}
+
 // Left-to-right inclusive prefix of one f64 per lane starting from `carry`: lane l receives
 // (((carry + v0) + v1) + ... + vl) with exactly the reference's rounding (sampling.rs:40,48 sums weights in
 // candidate order).  The chain is inherently serial, so it is kept as short as the hardware allows: the 64 values
