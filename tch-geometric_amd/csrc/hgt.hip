@@ -306,43 +306,68 @@ __global__ void hgt_live_list_kernel(HgtType ty, const uint64_t *__restrict__ cm
         if ((cmask[i >> 6] >> (i & 63)) & 1ull) live[hgt_chunk_rank(rank, cmask, i)] = i;
 }
 constexpr int64_t HGT_LDS_SLOTS = 8192; // samples per layer whose slot tables fit 64 KB of LDS
-// one wavefront: the reference's weighted reservoir over the live entries, weights score^2 (:110)
+// The reference's weighted reservoir over the live entries, weights score^2 (:104-135), by ONE WORKGROUP.  With
+// philox-mode's blocked running sum (tg_device.h wave_blocked_prefix_f64) the chunks of 64 entries only meet in the
+// left-to-right sum of their totals, so: (A) every wavefront forms the totals of its chunks; (B) one lane adds them up left
+// to right (the defined order; ~12 ns per chunk); (C) every wavefront draws for its chunks -- a candidate m >= k that is
+// accepted raises slot_rank[its slot] to m with an atomic max: the LAST accepted candidate of a slot wins, as in the
+// reference's sequential loop, whatever the order the chunks are visited in; (D) slot s holds entry slot_rank[s], or s
+// itself if nothing hit it.  One wavefront used to walk the whole list: 276 us per layer for 50-80 K entries.
 __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int64_t *n_live_ptr,
                                                    const int64_t *__restrict__ live, int64_t k, uint64_t seed,
                                                    uint64_t call_id, uint64_t draw_id, int64_t *chosen, int64_t *n_chosen,
-                                                   int *panic, unsigned char *smem, double *pbuf, uint32_t *slots_global) {
-    // slot tables: LDS up to 8192 samples per layer, the caller's global scratch beyond
-    uint32_t *slot_pos = (k > HGT_LDS_SLOTS) ? slots_global : reinterpret_cast<uint32_t *>(smem);
-    uint32_t *slot_rank = slot_pos + (k > 0 ? k : 0);
-    const int lane = threadIdx.x & 63;
+                                                   int *panic, unsigned char *smem, double *carries, uint32_t *slots_global) {
+    // slot table: LDS up to 8192 samples per layer, the caller's global scratch beyond
+    uint32_t *slot_rank = (k > HGT_LDS_SLOTS) ? slots_global : reinterpret_cast<uint32_t *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int64_t n = *n_live_ptr;
     if (k < 0) { // num_samples has no entry for this type: the reference panics once the budget exists (:202)
-        if (lane == 0) {
+        if (tid == 0) {
             if (ty.ctr->present) *panic = 1;
             *n_chosen = 0;
         }
         return;
     }
     if (k == 0) {
-        if (lane == 0) *n_chosen = 0;
+        if (tid == 0) *n_chosen = 0;
         return;
     }
     const CallKey ck = call_key(seed, call_id, TAG_HGT);
     const bool gslots = k > HGT_LDS_SLOTS;
-    auto slots_handoff = [&]() { // lanes of this wavefront hand slot-table entries to each other
-        if (gslots) {          // global scratch: make the stores / atomics visible before the reads
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        } else {
-            wave_lds_handoff();
-        }
+    auto block_handoff = [&]() { // slot-table entries / chunk totals pass between the wavefronts of this workgroup
+        if (gslots) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (gslots) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
-    for (int64_t s = lane; s < k; s += 64) slot_rank[s] = 0;
-    slots_handoff();
-    double w_sum = 0.0;
-    for (int64_t base = 0; base < n; base += 64) {
-        const int64_t m = base + lane;
+    const int64_t nc = (n + 63) >> 6;
+    for (int64_t s = tid; s < k; s += blockDim.x) slot_rank[s] = 0;
+    for (int64_t c = wave; c < nc; c += n_waves) { // (A) chunk totals
+        const int64_t m = c * 64 + lane;
+        double wv = 0.0;
+        if (m < n) {
+            const double sc = ty.bscore[live[m]];
+            wv = sc * sc;
+        }
+        double tot;
+        (void)wave_blocked_prefix_f64(wv, 0.0, &tot);
+        if (lane == 0) carries[c] = tot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) { // (B) carries[c] = sum of the totals before chunk c, added left to right
+        double run = 0.0;
+        for (int64_t c = 0; c < nc; ++c) {
+            const double t = carries[c];
+            carries[c] = run;
+            run = run + t;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int64_t c = wave; c < nc; c += n_waves) { // (C) draws
+        const int64_t m = c * 64 + lane;
         const bool ok = m < n;
         double wv = 0.0;
         if (ok) {
@@ -350,37 +375,33 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
             wv = sc * sc;
         }
         double tot;
-        const double pref = wave_blocked_prefix_f64(wv, w_sum, &tot); // blocked running sum, sampling.rs:40,48
-        w_sum = tot;
-        int64_t hit = -1;
+        const double pref = wave_blocked_prefix_f64(wv, carries[c], &tot); // blocked running sum, sampling.rs:40,48
         if (ok && m >= k) {
             if (!(0.0 < pref)) {
                 *panic = 1;
             } else {
                 const Draw d = draw(ck, draw_id, (uint32_t)m, D1_WEIGHTED);
                 const double j = u64_to_f64_01(d.a()) * pref + 0.0;
-                if (j < wv) hit = (int64_t)bounded64(d.b(), (uint64_t)k);
+                if (j < wv) atomicMax(&slot_rank[bounded64(d.b(), (uint64_t)k)], (uint32_t)m);
             }
         }
-        if (ok && m < k) slot_pos[m] = (uint32_t)m;
-        if (hit >= 0) atomicMax(&slot_rank[hit], (uint32_t)m);
-        slots_handoff();
-        if (hit >= 0 && __atomic_load_n(&slot_rank[hit], __ATOMIC_RELAXED) == (uint32_t)m) slot_pos[hit] = (uint32_t)m;
-        slots_handoff();
     }
-    const int64_t cnt = min(n, k);
-    for (int64_t s = lane; s < cnt; s += 64) chosen[s] = (int64_t)slot_pos[s];
-    if (lane == 0) *n_chosen = cnt;
+    block_handoff();
+    const int64_t cnt = min(n, k); // (D)  (m >= k >= 1, so a rank of 0 means "never hit": the slot keeps entry s, :37-45)
+    for (int64_t s = tid; s < cnt; s += blockDim.x) {
+        const uint32_t r = gslots ? __atomic_load_n(&slot_rank[s], __ATOMIC_RELAXED) : slot_rank[s];
+        chosen[s] = r ? (int64_t)r : s;
+    }
+    if (tid == 0) *n_chosen = cnt;
 }
 __global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_ptr, const int64_t *__restrict__ live,
                                               int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
-                                              int64_t *chosen, int64_t *n_chosen, int *panic, uint32_t *slots_global) {
+                                              int64_t *chosen, int64_t *n_chosen, int *panic, uint32_t *slots_global,
+                                              double *carries) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double pbuf[64]; // serial prefix scratch (one wavefront per launch)
-    hgt_reservoir_body(ty, n_live_ptr, live, k, seed, call_id, draw_id, chosen, n_chosen, panic, smem, pbuf, slots_global);
+    hgt_reservoir_body(ty, n_live_ptr, live, k, seed, call_id, draw_id, chosen, n_chosen, panic, smem, carries, slots_global);
 }
-// The node types of a layer sample from their own budgets independently (:201-221), and each reservoir is one
-// wavefront bound by its running-sum chain: one workgroup per type runs them side by side.
+// The node types of a layer sample from their own budgets independently (:201-221): one workgroup per type, side by side.
 constexpr int HGT_MULTI_TYPES = 8;
 struct HgtMultiArgs {
     HgtType ty[HGT_MULTI_TYPES];
@@ -390,14 +411,14 @@ struct HgtMultiArgs {
     int64_t *n_chosen[HGT_MULTI_TYPES];
     int64_t k[HGT_MULTI_TYPES];
     uint32_t *slots[HGT_MULTI_TYPES];
+    double *carries[HGT_MULTI_TYPES];
 };
 __global__ void hgt_weighted_reservoir_multi_kernel(const HgtMultiArgs a, uint64_t seed, uint64_t call_id, int64_t layer,
                                                     int n_types, int *panic) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double pbuf[64];
     const int t = blockIdx.x;
     hgt_reservoir_body(a.ty[t], a.n_live[t], a.live[t], a.k[t], seed, call_id, (uint64_t)(layer * n_types + t), a.chosen[t],
-                       a.n_chosen[t], panic, smem, pbuf, a.slots[t]);
+                       a.n_chosen[t], panic, smem, a.carries[t], a.slots[t]);
 }
 // :213-221 move the samples to the node list, give them local ids, erase them from the budget
 __global__ void hgt_append_kernel(HgtType ty, const int64_t *__restrict__ live, const int64_t *__restrict__ chosen,
@@ -579,6 +600,7 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     b += align16(8 * (size_t)(pl.scan_cap / 64 + 2)); // chunk masks
     for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
     b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T * 2;                     // chosen + slot tables, per type
+    for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)(pl.cap_budget[t] / 64 + 2)); // chunk carries, per type
     b += align16(16 * (size_t)pl.T);                                           // n_live, n_chosen per type
     b += align16(8 * (size_t)pl.edge_cap) * 2;   // cand_j, cand_ep
     b += align16(pl.sort_temp_bytes);
@@ -668,6 +690,9 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     for (int t = 0; t < T; ++t) chosen_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
     std::vector<uint32_t *> slots_t((size_t)T);
     for (int t = 0; t < T; ++t) slots_t[(size_t)t] = reinterpret_cast<uint32_t *>(take(8 * (size_t)pl.max_k));
+    std::vector<double *> carries_t((size_t)T);
+    for (int t = 0; t < T; ++t)
+        carries_t[(size_t)t] = reinterpret_cast<double *>(take(8 * (size_t)(pl.cap_budget[t] / 64 + 2)));
     int64_t *n_live_t = reinterpret_cast<int64_t *>(take(16 * (size_t)T)), *n_chosen_t = n_live_t + T;
     int64_t *cand_j = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
     int64_t *cand_ep = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
@@ -748,7 +773,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             if (int rcs = device_scan((pl.cap_budget[t] + 63) / 64, n_live_t + t)) return rcs; // over the chunks' counts
             hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], cmask,
                                rank, live_t[(size_t)t]);
-            const size_t lds = (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 8 : 8;
+            const size_t lds = (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 4 : 8;
             if (lds > lds_max) lds_max = lds;
         }
         if (T <= HGT_MULTI_TYPES) { // the types' reservoirs side by side, one workgroup each
@@ -761,16 +786,17 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                 ma.n_chosen[t] = n_chosen_t + t;
                 ma.k[t] = pb->num_samples[(size_t)t * H + layer];
                 ma.slots[t] = slots_t[(size_t)t];
+                ma.carries[t] = carries_t[(size_t)t];
             }
-            hipLaunchKernelGGL(hgt_weighted_reservoir_multi_kernel, dim3((unsigned)T), dim3(64), lds_max, stream, ma,
+            hipLaunchKernelGGL(hgt_weighted_reservoir_multi_kernel, dim3((unsigned)T), dim3(1024), lds_max, stream, ma,
                                rng->seed, rng->call_id, (int64_t)layer, T, panic);
         } else {
             for (int t = 0; t < T; ++t) {
                 const int64_t k = pb->num_samples[(size_t)t * H + layer];
-                hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(64),
-                                   (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 8 : 8, stream, ty[t], n_live_t + t,
+                hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(1024),
+                                   (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 4 : 8, stream, ty[t], n_live_t + t,
                                    live_t[(size_t)t], k, rng->seed, rng->call_id, (uint64_t)((int64_t)layer * T + t),
-                                   chosen_t[(size_t)t], n_chosen_t + t, panic, slots_t[(size_t)t]);
+                                   chosen_t[(size_t)t], n_chosen_t + t, panic, slots_t[(size_t)t], carries_t[(size_t)t]);
             }
         }
         for (int t = 0; t < T; ++t)
