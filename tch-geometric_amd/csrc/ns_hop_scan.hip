@@ -57,6 +57,8 @@ struct HopScanParams {
     uint64_t *gchunk; // [group_cap] admissible edges of each of the group's 8 chunks, one byte each (<= 64)
     int64_t *gpref;   // [group_cap + 1] exclusive prefix of gcount
     int64_t *park;    // [m * k]
+    double *long_tot; // weighted sampler, long columns: per workgroup HW_LONG_CHUNKS chunk totals -> carries ...
+    uint32_t *long_cnt; // ... and admissible edges per chunk -> candidates before the chunk
     int32_t *status;  // [0] overflow flag
     // outputs
     int64_t *cnt, *offsets, *neighbors, *edge_ptrs, *parents, *states_out;
@@ -343,9 +345,15 @@ __global__ void hs_select_kernel(const HopScanParams p) {
 }
 
 // ---------------------------------------------------------------- weighted sampler (sampling.rs:28-55)
-// The reference's weighted reservoir IS a per-candidate algorithm with a left-to-right f64 running sum: the chain
-// of one column cannot be split without changing its rounding, but columns are independent -- one wavefront per
-// frontier vertex, all over the device.  status[0] |= 2 where the reference panics (running sum <= 0).
+// The reference's weighted reservoir is a per-candidate algorithm over a running weight sum.  Columns are independent:
+// one wavefront per frontier vertex, all over the device -- except LONG columns (> HW_LONG_EDGES), whose single wavefront
+// used to set the time of the whole hop (245 us for the longest column of cfg4): with philox-mode's blocked running sum
+// (tg_device.h) the 64-edge chunks of a column only meet in the left-to-right sum of their totals, so a whole workgroup
+// takes such a column (hw_select_long_kernel).  status[0] |= 2 where the reference panics (running sum <= 0).
+constexpr int64_t HW_LONG_EDGES = 16384;  // columns longer than this go to hw_select_long_kernel
+constexpr int HW_LONG_BLOCKS = 256;       // its workgroups (each with its own scratch)
+constexpr int64_t HW_LONG_CHUNKS = 8192;  // chunks of 64 edges its scratch holds per workgroup (512 K edges); beyond: one
+                                          // wavefront walks the column as before
 __global__ void hw_select_kernel(const HopScanParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -368,6 +376,10 @@ __global__ void hw_select_kernel(const HopScanParams p) {
         if (w >= 0) {
             const int64_t st = p.states ? p.states[v] : 0;
             const int64_t e0 = sg.ptrs[w], e1 = sg.ptrs[w + 1];
+            if (e1 - e0 > HW_LONG_EDGES) { // a whole workgroup takes it (hw_select_long_kernel): list it and move on
+                if (lane == 0) p.vgroups[1 + atomicAdd(reinterpret_cast<unsigned long long *>(p.vgroups), 1ull)] = v;
+                continue;
+            }
             const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
             const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
             double w_sum = 0.0;
@@ -422,6 +434,141 @@ __global__ void hw_select_kernel(const HopScanParams p) {
     }
 }
 
+// One workgroup per long column: (A) every wavefront forms the weight totals and admissible counts of its chunks, (B) one
+// lane turns them into carries (left to right: the defined order of the blocked sum) and candidate ranks, (C) every
+// wavefront draws for its chunks -- candidates of rank < k fill slot rank, an accepted later candidate raises its slot to
+// (rank, position) with a 64-bit atomic max, so that the LAST accepted candidate of a slot wins as in the reference's loop
+// whatever order the chunks run in -- (D) the slots are read out.  Same draws (named by (call, vertex, rank)), same result.
+__global__ void __launch_bounds__(1024) hw_select_long_kernel(const HopScanParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ HsSeg S[HS_MAX_SEG];
+    __shared__ uint32_t n_total_s;
+    hs_load_segs(p, S);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int kmax = p.k;
+    int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem);
+    unsigned long long *slot_best = reinterpret_cast<unsigned long long *>(slot_ptr + kmax);
+    double *tot = p.long_tot + (size_t)blockIdx.x * HW_LONG_CHUNKS;
+    uint32_t *cnt = p.long_cnt + (size_t)blockIdx.x * HW_LONG_CHUNKS;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int64_t n_long = p.vgroups[0];
+    for (int64_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const int64_t v = p.vgroups[1 + li];
+        const int64_t w = p.vertices[v];
+        const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+        const int k = sg.k;
+        const int64_t st = p.states ? p.states[v] : 0;
+        const int64_t e0 = sg.ptrs[w], e1 = sg.ptrs[w + 1];
+        const int64_t nc = (e1 - e0 + 63) >> 6;
+        const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
+        const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
+        const bool filtered = p.filter_mode != TG_FILTER_NONE;
+        for (int sl = tid; sl < k; sl += blockDim.x) slot_best[sl] = 0ull;
+        __syncthreads();
+        auto chunk = [&](int64_t c, bool &ok, uint64_t &mask, double &wv, int64_t &e) {
+            e = e0 + c * 64 + lane;
+            const int64_t t = (filtered && e < e1) ? __builtin_nontemporal_load(&sg.timestamps[e]) : 0;
+            const double x = (e < e1) ? __builtin_nontemporal_load(&sg.weights[e]) : 0.0;
+            ok = e < e1 && hs_pass(p, st, t);
+            mask = __ballot(ok);
+            wv = ok ? x : 0.0; // x + 0.0 == x: excluded edges leave the running sum alone
+        };
+        if (nc > HW_LONG_CHUNKS) { // beyond the scratch: wavefront 0 walks the column chunk by chunk (the old form)
+            if (wave == 0) {
+                double w_sum = 0.0;
+                uint32_t n = 0;
+                for (int64_t c = 0; c < nc; ++c) {
+                    bool ok;
+                    uint64_t mask;
+                    double wv, t2;
+                    int64_t e;
+                    chunk(c, ok, mask, wv, e);
+                    const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
+                    const double pref = wave_blocked_prefix_f64(wv, w_sum, &t2);
+                    w_sum = t2;
+                    if (ok && rank < (uint32_t)k) slot_ptr[rank] = e;
+                    if (ok && rank >= (uint32_t)k) {
+                        if (!(0.0 < pref)) {
+                            atomicOr(p.status, 2);
+                        } else {
+                            const Draw d = draw(ck, did, rank, D1_WEIGHTED);
+                            const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                            if (j < wv)
+                                atomicMax(&slot_best[bounded64(d.b(), (uint64_t)k)],
+                                          ((unsigned long long)rank << 32) | (unsigned long long)(e - e0));
+                        }
+                    }
+                    n += (uint32_t)__popcll(mask);
+                }
+                if (lane == 0) n_total_s = n;
+            }
+            __syncthreads();
+        } else {
+            for (int64_t c = wave; c < nc; c += n_waves) { // (A)
+                bool ok;
+                uint64_t mask;
+                double wv, t2;
+                int64_t e;
+                chunk(c, ok, mask, wv, e);
+                (void)wave_blocked_prefix_f64(wv, 0.0, &t2);
+                if (lane == 0) {
+                    tot[c] = t2;
+                    cnt[c] = (uint32_t)__popcll(mask);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid == 0) { // (B)
+                double run = 0.0;
+                uint32_t n = 0;
+                for (int64_t c = 0; c < nc; ++c) {
+                    const double t2 = tot[c];
+                    const uint32_t q = cnt[c];
+                    tot[c] = run;
+                    cnt[c] = n;
+                    run = run + t2;
+                    n += q;
+                }
+                n_total_s = n;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int64_t c = wave; c < nc; c += n_waves) { // (C)
+                bool ok;
+                uint64_t mask;
+                double wv, t2;
+                int64_t e;
+                chunk(c, ok, mask, wv, e);
+                const uint32_t rank = cnt[c] + (uint32_t)__popcll(mask & lt_mask);
+                const double pref = wave_blocked_prefix_f64(wv, tot[c], &t2); // blocked running sum, sampling.rs:40,48
+                if (ok && rank < (uint32_t)k) slot_ptr[rank] = e; // sampling.rs:37-45
+                if (ok && rank >= (uint32_t)k) {
+                    if (!(0.0 < pref)) {
+                        atomicOr(p.status, 2);
+                    } else {
+                        const Draw d = draw(ck, did, rank, D1_WEIGHTED);
+                        const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                        if (j < wv)
+                            atomicMax(&slot_best[bounded64(d.b(), (uint64_t)k)],
+                                      ((unsigned long long)rank << 32) | (unsigned long long)(e - e0));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t cnt_sel = min(n_total_s, (uint32_t)k); // (D)  (rank >= k >= 1: a slot_best of 0 = never hit)
+        if (tid == 0) p.cnt[v] = cnt_sel;
+        for (int sl = tid; sl < kmax; sl += blockDim.x) {
+            int64_t ep = -1;
+            if ((uint32_t)sl < cnt_sel) ep = slot_best[sl] ? e0 + (int64_t)(slot_best[sl] & 0xffffffffull) : slot_ptr[sl];
+            p.park[v * kmax + sl] = ep;
+        }
+        __syncthreads();
+    }
+}
+
 // thread per (frontier vertex, slot): the slot's output position is offsets[v] + s -- no search, two rounds of loads
 __global__ void hs_emit_kernel(const HopScanParams p) {
     __shared__ HsSeg S[HS_MAX_SEG];
@@ -459,7 +606,8 @@ extern "C" int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t
     const int64_t big = group_cap + 1 > m + 1 ? group_cap + 1 : m + 1;
     *bytes = (int64_t)(hs_align(8 * (size_t)(m + 1)) + hs_align(4 * (size_t)group_cap) + hs_align(8 * (size_t)group_cap) +
                        hs_align(8 * (size_t)(group_cap + 1)) +
-                       hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(hs_scan_temp(big)) + 512);
+                       hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(hs_scan_temp(big)) + 512 +
+                       hs_align(12 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS)); // long columns of the weighted sampler
     return TG_OK;
 }
 
@@ -520,6 +668,11 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
     p.gchunk = reinterpret_cast<uint64_t *>(take(8 * (size_t)group_cap));
     p.gpref = reinterpret_cast<int64_t *>(take(8 * (size_t)(group_cap + 1)));
     p.park = reinterpret_cast<int64_t *>(take(8 * (size_t)p.m * p.k));
+    {
+        unsigned char *ls = take(12 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS);
+        p.long_tot = reinterpret_cast<double *>(ls);
+        p.long_cnt = reinterpret_cast<uint32_t *>(ls + 8 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS);
+    }
     void *temp = base + off;
     size_t temp_bytes = (size_t)workspace_bytes - off;
     p.status = status;
@@ -548,7 +701,9 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
         const size_t lds = (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t);
         int64_t blocks = (p.m + n_waves - 1) / n_waves;
         if (blocks > 256 * 32) blocks = 256 * 32;
+        TG_HIP(hipMemsetAsync(p.vgroups, 0, sizeof(int64_t), stream)); // the list of long columns: [0] = how many
         hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
+        hipLaunchKernelGGL(hw_select_long_kernel, dim3(HW_LONG_BLOCKS), dim3(1024), (size_t)p.k * 16, stream, p);
     } else {
         if (short_m) {
             hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
