@@ -400,6 +400,19 @@ TG_API int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo, con
  * tg_ns_hop_scan / tg_ns_hop_weighted over them (m = m_cap, shard.timestamps / shard.weights = the shard's slices) and
  * packs the hop's compact outputs into the reply (tg_part_pack: cnt u32, entries in reply_format, reply_counts).
  * tg_part_emit with a reply_format that carries the filter state also fills the `states` slab.  Same draws as the replicated sampler, so the same results. */
+/* tg_part_sample with a workspace (tg_part_sample_workspace_bytes(m_cap); 256-byte aligned): hops with many requests
+ * (>= 2^21) against a large shard are first counting-sorted by the WINDOW of their column (found from the vertex id through
+ * a vertex -> window table) and sampled in that order, XCD by XCD, so that the `indices[edge_ptr]` gathers hit L2 instead
+ * of costing a line request each; the replies are the same words in the same places.  workspace == NULL or a small hop:
+ * tg_part_sample. */
+TG_API int tg_part_sample_workspace_bytes(int64_t m_cap, int64_t *bytes);
+/* when tg_part_sample_ws orders a hop (process-wide; defaults 2^21 requests, 2^24 shard edges; negative = keep).  Results
+ * never depend on it; tests lower the thresholds to run the ordered path on small graphs. */
+TG_API int tg_part_sample_order_thresholds(int64_t min_requests, int64_t min_edges);
+TG_API int tg_part_sample_ws(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests, const int64_t *m_dev,
+                      int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout,
+                      int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off, int64_t *reply,
+                      int32_t reply_format, void *workspace, int64_t workspace_bytes, void *stream);
 TG_API int tg_part_unpack(int64_t v_lo, int64_t n_major, const void *requests, const int64_t *m_dev, int64_t m_cap,
                           int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int64_t *vertices, int64_t *ids,
                           int64_t *call_ids, void *stream);

@@ -326,6 +326,219 @@ template <int KMAX> __global__ void part_sample_kernel(const PartOwnerParams p) 
     }
 }
 
+// ---------------------------------------------------------------- owner side, window-ordered (many requests per hop)
+// part_sample_kernel walks the requests in arrival order: its `indices[edge_ptr]` gathers go all over the shard, one
+// 128-byte line request each (the 55 G/s ceiling of DESIGN.md 4.1b: 2.6 of the 4.8 ms of a 4 096-batch call).  With a
+// workspace (tg_part_sample_ws) the requests are first counting-sorted BY THE WINDOW OF THEIR COLUMN -- found from the
+// vertex id through a vertex -> window table, no look-up needed -- into a permutation; the XCDs then sweep contiguous
+// eighths of the sorted order, so that at any time an XCD works inside a few windows that its L2 holds.  A request's
+// replies still go to ITS place (off[j], request order), so the replies the origin receives are the same words.
+constexpr int PSORT_BLOCKS = 512, PSORT_THREADS = 512, PSORT_MAX_WINDOWS = 4096, PSORT_SCAN_GROUPS = 16;
+struct PartSortParams {
+    const PartRequest *req;
+    const int64_t *m_dev;
+    const int64_t *ptrs;
+    int64_t v_lo, n_major;
+    int32_t shift, n_windows;
+    uint32_t *vtab, *hist, *base, *perm;
+};
+__global__ void psort_vtab_kernel(const PartSortParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_windows) return;
+    const int64_t target = (int64_t)i << p.shift;
+    int64_t lo = 0, hi = p.n_major; // first local vertex whose column starts at or beyond window i
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (p.ptrs[mid] >= target)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    p.vtab[i] = (uint32_t)lo;
+}
+__device__ __forceinline__ int psort_window(const uint32_t *vtab, int n_windows, int64_t w, int64_t n_major) {
+    if (w < 0 || w >= n_major) return 0; // not this shard's: sampled as empty wherever it lands
+    int lo = 0, hi = n_windows;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)vtab[mid] <= w)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(PSORT_THREADS) psort_hist_kernel(const PartSortParams p) {
+    __shared__ uint32_t h[PSORT_MAX_WINDOWS], lvtab[PSORT_MAX_WINDOWS];
+    for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) {
+        h[i] = 0;
+        lvtab[i] = p.vtab[i];
+    }
+    __syncthreads();
+    const int64_t m = *p.m_dev;
+    for (int64_t t0 = (int64_t)blockIdx.x * 4096; t0 < m; t0 += (int64_t)gridDim.x * 4096)
+        for (int64_t j = t0 + threadIdx.x; j < min(m, t0 + 4096); j += blockDim.x)
+            atomicAdd(&h[psort_window(lvtab, p.n_windows, p.req[j].vertex - p.v_lo, p.n_major)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) p.hist[(size_t)blockIdx.x * p.n_windows + i] = h[i];
+}
+// per window: exclusive running sum over the rows (64 windows x 16 row groups per workgroup), totals -> base
+__global__ void __launch_bounds__(64 * PSORT_SCAN_GROUPS) psort_colscan_kernel(const PartSortParams p, int n_rows) {
+    __shared__ uint32_t part[PSORT_SCAN_GROUPS][64];
+    const int bl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + bl;
+    const int rows_per = (n_rows + PSORT_SCAN_GROUPS - 1) / PSORT_SCAN_GROUPS;
+    const int r0 = g * rows_per, r1 = min(n_rows, r0 + rows_per);
+    uint32_t sum = 0;
+    if (w < p.n_windows)
+        for (int r = r0; r < r1; ++r) sum += p.hist[(size_t)r * p.n_windows + w];
+    part[g][bl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int gg = 0; gg < g; ++gg) run += part[gg][bl];
+    if (w < p.n_windows) {
+        for (int r = r0; r < r1; ++r) {
+            uint32_t *cell = p.hist + (size_t)r * p.n_windows + w;
+            const uint32_t v = *cell;
+            *cell = run;
+            run += v;
+        }
+        if (g == PSORT_SCAN_GROUPS - 1) p.base[w] = run;
+    }
+}
+__global__ void psort_basescan_kernel(const PartSortParams p) { // one workgroup: exclusive scan of the window totals
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < p.n_windows; c0 += blockDim.x) {
+        const int i = c0 + tid;
+        const uint32_t v = i < p.n_windows ? p.base[i] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (i < p.n_windows) p.base[i] = off + incl - v;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = carry_s;
+            for (int w = 0; w < nw; ++w) t += wave_tot[w];
+            carry_s = t;
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(PSORT_THREADS) psort_scatter_kernel(const PartSortParams p) {
+    __shared__ uint32_t cur[PSORT_MAX_WINDOWS], lvtab[PSORT_MAX_WINDOWS];
+    for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) {
+        cur[i] = p.base[i] + p.hist[(size_t)blockIdx.x * p.n_windows + i];
+        lvtab[i] = p.vtab[i];
+    }
+    __syncthreads();
+    const int64_t m = *p.m_dev;
+    for (int64_t t0 = (int64_t)blockIdx.x * 4096; t0 < m; t0 += (int64_t)gridDim.x * 4096)
+        for (int64_t j = t0 + threadIdx.x; j < min(m, t0 + 4096); j += blockDim.x)
+            p.perm[atomicAdd(&cur[psort_window(lvtab, p.n_windows, p.req[j].vertex - p.v_lo, p.n_major)], 1u)] = (uint32_t)j;
+}
+
+// part_sample_kernel over the SORTED order: lane <- request perm[i]; the replies of a request go to off[request]
+template <int KMAX> __global__ void part_sample_sorted_kernel(const PartOwnerParams p, const uint32_t *__restrict__ perm) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int k = p.k;
+    const size_t wave_bytes = 128 * sizeof(int64_t) + (size_t)64 * k * sizeof(uint32_t) + (((size_t)64 * k + 15) & ~(size_t)15);
+    unsigned char *wbase = smem + (size_t)wave * wave_bytes;
+    int64_t *ebase = reinterpret_cast<int64_t *>(wbase);
+    int64_t *obase = ebase + 64;
+    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase + 128 * sizeof(int64_t));
+    uint8_t *slane = reinterpret_cast<uint8_t *>(wbase + 128 * sizeof(int64_t) + (size_t)64 * k * sizeof(uint32_t));
+    const int64_t m = *p.m_dev;
+    const int64_t n_chunks = (m + 63) >> 6;
+    // blocks with equal blockIdx % 8 share an XCD (observed; a speed matter only): group x sweeps the x-th eighth of the
+    // sorted order, in order
+    const int x = blockIdx.x & 7, local = blockIdx.x >> 3, per_x = gridDim.x >> 3;
+    const int64_t c_lo = n_chunks * x / 8, c_hi = n_chunks * (x + 1) / 8;
+    for (int64_t c = c_lo + (int64_t)local * n_waves + wave; c < c_hi; c += (int64_t)per_x * n_waves) {
+        const int64_t i = (c << 6) + lane;
+        int64_t e0 = 0, out0 = 0;
+        uint32_t cnt = 0, n = 0;
+        uint64_t call = 0, did = 0;
+        if (i < m) {
+            const int64_t j = perm[i];
+            const PartRequest r = p.req[j];
+            const int64_t w = r.vertex - p.v_lo;
+            cnt = p.cnt[j];
+            if (cnt) {
+                e0 = p.ptrs[w];
+                n = (uint32_t)(p.ptrs[w + 1] - e0);
+                out0 = p.off[j];
+            }
+            int src = 0;
+            while (src + 1 < p.world && p.seg_off[src + 1] <= j) ++src;
+            call = p.seg_call0[src] + (uint64_t)r.batch;
+            did = (uint64_t)r.slot;
+        }
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        const uint32_t excl = incl - cnt;
+        const uint32_t total = __shfl(incl, 63, 64);
+        ebase[lane] = e0;
+        obase[lane] = out0 - (int64_t)excl; // + the running index of the staged entry = the reply position
+        if (cnt > 0) {
+            const CallKey ck = call_key(p.seed, call, TAG_NS_HOMO);
+            if (p.replace) { // sampling.rs:57-69
+                Draw d;
+                for (int s = 0; s < k; ++s) {
+                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
+                    spos[excl + s] = bounded32(d.half(s & 1), n);
+                    slane[excl + s] = (uint8_t)lane;
+                }
+            } else if (n <= (uint32_t)k) { // sampling.rs:12-15
+                for (uint32_t s = 0; s < cnt; ++s) {
+                    spos[excl + s] = s;
+                    slane[excl + s] = (uint8_t)lane;
+                }
+            } else {
+                sample_tickets<KMAX>(ck, did, n, k, spos, slane, excl, lane);
+            }
+        }
+        wave_lds_handoff();
+        for (uint32_t q0 = 0; q0 < total; q0 += 256) {
+            int64_t ep[4], v[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+                const uint32_t qq = q < total ? q : 0u;
+                const int l = slane[qq];
+                ep[u] = ebase[l] + (int64_t)spos[qq];
+                o[u] = obase[l] + (int64_t)qq;
+            }
+            if (p.indices32) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (int64_t)p.indices32[ep[u]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = p.indices[ep[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = q0 + (uint32_t)(u * 64 + lane);
+                if (q < total) {
+                    if (p.packed) {
+                        p.reply[o[u]] = (int64_t)((uint64_t)v[u] | ((uint64_t)(ep[u] + p.e_lo) << 32));
+                    } else {
+                        int64_t *dst = p.reply + o[u] * 2;
+                        dst[0] = v[u];
+                        dst[1] = ep[u] + p.e_lo;
+                    }
+                }
+            }
+        }
+        wave_lds_handoff();
+    }
+}
+
 // ---------------------------------------------------------------- owner side, general form (temporal filters, weights)
 // The flat hops of ns_hop_scan.hip sample a frontier given as arrays (vertex, draw id, call id, state); here the
 // received requests are unpacked into that shape (vertices rebased to the shard, -1 = not mine / padding) and the hop's
@@ -707,6 +920,99 @@ extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo,
         hipLaunchKernelGGL(tg::part_sample_kernel<16>, dim3(grid), dim3(64 * n_waves), lds, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(tg::part_sample_kernel<32>, dim3(grid), dim3(64 * n_waves), lds, (hipStream_t)stream, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+struct PartSortLayout {
+    size_t vtab, hist, base, perm, total;
+};
+static PartSortLayout part_sort_layout(int64_t m_cap) {
+    PartSortLayout L;
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        const size_t here = at;
+        at += (bytes + 255) & ~(size_t)255;
+        return here;
+    };
+    L.vtab = take((size_t)tg::PSORT_MAX_WINDOWS * 4);
+    L.hist = take((size_t)tg::PSORT_BLOCKS * tg::PSORT_MAX_WINDOWS * 4);
+    L.base = take((size_t)(tg::PSORT_MAX_WINDOWS + 8) * 4);
+    L.perm = take((size_t)(m_cap > 0 ? m_cap : 1) * 4);
+    L.total = at;
+    return L;
+}
+
+static int64_t g_part_order_min_requests = (int64_t)1 << 21, g_part_order_min_edges = (int64_t)1 << 24;
+extern "C" int tg_part_sample_order_thresholds(int64_t min_requests, int64_t min_edges) {
+    if (min_requests >= 0) g_part_order_min_requests = min_requests;
+    if (min_edges >= 0) g_part_order_min_edges = min_edges;
+    return TG_OK;
+}
+
+extern "C" int tg_part_sample_workspace_bytes(int64_t m_cap, int64_t *bytes) {
+    TG_REQUIRE(bytes && m_cap >= 0, "tg_part_sample_workspace_bytes: bad arguments");
+    *bytes = (int64_t)part_sort_layout(m_cap).total;
+    return TG_OK;
+}
+
+extern "C" int tg_part_sample_ws(const tg_graph *shard, int64_t v_lo, int64_t e_lo, const void *requests, const int64_t *m_dev,
+                                 int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
+                                 int32_t fanout, int32_t sampler, uint64_t seed, const uint32_t *cnt, const int64_t *off,
+                                 int64_t *reply, int32_t reply_format, void *workspace, int64_t workspace_bytes,
+                                 void *stream) {
+    // worth it when the hop's gathers revisit lines: many requests against a shard far larger than the L2s
+    const bool ordered = workspace && m_cap >= g_part_order_min_requests && m_cap > 0 && m_cap < ((int64_t)1 << 32) && shard &&
+                         shard->n_edges >= g_part_order_min_edges && shard->n_major < ((int64_t)1 << 32);
+    if (!ordered)
+        return tg_part_sample(shard, v_lo, e_lo, requests, m_dev, m_cap, world, seg_off, seg_call0, fanout, sampler, seed, cnt,
+                              off, reply, reply_format, stream);
+    tg::PartOwnerParams p;
+    int rc = part_owner_params(p, shard, v_lo, e_lo, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed, m_cap);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(reply_format == TG_PART_REPLY_PAIRS || reply_format == TG_PART_REPLY_PACKED,
+               "tg_part_sample_ws: reply_format is TG_PART_REPLY_PAIRS or TG_PART_REPLY_PACKED");
+    TG_REQUIRE(cnt && off && reply, "tg_part_sample_ws: null buffers");
+    const PartSortLayout L = part_sort_layout(m_cap);
+    TG_REQUIRE(workspace_bytes >= (int64_t)L.total && ((uintptr_t)workspace & 255) == 0,
+               "tg_part_sample_ws: workspace too small or not 256-byte aligned");
+    p.packed = reply_format == TG_PART_REPLY_PACKED;
+    p.cnt = const_cast<uint32_t *>(cnt);
+    p.off = off;
+    p.reply = reply;
+    p.reply_counts = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *w = static_cast<unsigned char *>(workspace);
+    tg::PartSortParams sp;
+    sp.req = p.req;
+    sp.m_dev = m_dev;
+    sp.ptrs = shard->ptrs;
+    sp.v_lo = v_lo;
+    sp.n_major = shard->n_major;
+    const int elem = shard->indices32 ? 4 : 8;
+    int shift = 0;
+    while (((int64_t)elem << shift) < (512 << 10)) ++shift; // 512 KB of the gathered array per window ...
+    while (((shard->n_edges >> shift) + 1) > tg::PSORT_MAX_WINDOWS) ++shift; // ... as far as the counters go
+    sp.shift = shift;
+    sp.n_windows = (int32_t)((shard->n_edges >> shift) + 1);
+    sp.vtab = reinterpret_cast<uint32_t *>(w + L.vtab);
+    sp.hist = reinterpret_cast<uint32_t *>(w + L.hist);
+    sp.base = reinterpret_cast<uint32_t *>(w + L.base);
+    sp.perm = reinterpret_cast<uint32_t *>(w + L.perm);
+    hipLaunchKernelGGL(tg::psort_vtab_kernel, dim3((sp.n_windows + 255) / 256), dim3(256), 0, s, sp);
+    hipLaunchKernelGGL(tg::psort_hist_kernel, dim3(tg::PSORT_BLOCKS), dim3(tg::PSORT_THREADS), 0, s, sp);
+    hipLaunchKernelGGL(tg::psort_colscan_kernel, dim3((sp.n_windows + 63) / 64), dim3(64 * tg::PSORT_SCAN_GROUPS), 0, s, sp,
+                       tg::PSORT_BLOCKS);
+    hipLaunchKernelGGL(tg::psort_basescan_kernel, dim3(1), dim3(1024), 0, s, sp);
+    hipLaunchKernelGGL(tg::psort_scatter_kernel, dim3(tg::PSORT_BLOCKS), dim3(tg::PSORT_THREADS), 0, s, sp);
+    TG_LAUNCH_CHECK();
+    const int n_waves = 4;
+    const size_t lds = (size_t)n_waves * (128 * sizeof(int64_t) + (size_t)64 * fanout * 4 + (((size_t)64 * fanout + 15) & ~(size_t)15));
+    const unsigned grid = 1024; // a multiple of 8: eight groups of equal size
+    if (fanout <= 16)
+        hipLaunchKernelGGL(tg::part_sample_sorted_kernel<16>, dim3(grid), dim3(64 * n_waves), lds, s, p, sp.perm);
+    else
+        hipLaunchKernelGGL(tg::part_sample_sorted_kernel<32>, dim3(grid), dim3(64 * n_waves), lds, s, p, sp.perm);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -29,7 +29,8 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_budget_workspace_bytes", "tg_budget_sample", "tg_ns_homo_workspace_bytes", "tg_ns_homo_batched_ws", "tg_het_meta_words", "tg_het_step_begin",
            "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
            "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol",
-           "tg_debug_bounds_set_flag"]
+           "tg_debug_bounds_set_flag", "tg_part_sample_workspace_bytes", "tg_part_sample_ws",
+           "tg_part_sample_order_thresholds"]
 
 
 class TgGraph(C.Structure):

@@ -389,10 +389,13 @@ class PartitionedSampler:
         _cabi.check(lib.tg_part_count(C.byref(graph), C.c_int64(shard.v_lo), ptr(got), ptr(m_dev), C.c_int64(m_cap),
                                       C.c_int32(world), seg, call0, C.c_int32(k), C.c_int32(self.sampler), ptr(cnt),
                                       ptr(off), ptr(self.reply_counts), ptr(tmp), C.c_int64(tmp.numel() * 8), stream))
-        _cabi.check(lib.tg_part_sample(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
-                                       ptr(m_dev), C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
-                                       C.c_int32(self.sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(reply),
-                                       C.c_int32(self.reply_format), stream))
+        ws_bytes = C.c_int64(0)   # many requests against a large shard: sampled in window order (tg_part_sample_ws)
+        _cabi.check(lib.tg_part_sample_workspace_bytes(C.c_int64(m_cap), C.byref(ws_bytes)))
+        sws = self._buf("sample_ws", ws_bytes.value // 8 + 64, torch.int64)
+        _cabi.check(lib.tg_part_sample_ws(C.byref(graph), C.c_int64(shard.v_lo), C.c_int64(shard.e_lo), ptr(got),
+                                          ptr(m_dev), C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
+                                          C.c_int32(self.sampler), C.c_uint64(seed), ptr(cnt), ptr(off), ptr(reply),
+                                          C.c_int32(self.reply_format), ptr(sws), C.c_int64(sws.numel() * 8), stream))
         return cnt, off, reply
 
 

@@ -61,6 +61,50 @@ def test_single_rank_partitioned_equals_batched(sampler):
             assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_), b
 
 
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("packed", [None, False])
+def test_owner_side_in_window_order(sampler, packed):
+    """tg_part_sample_ws: the owner sorts a hop's requests by the window of their column and samples in that order; the
+    replies are the same words in the same places.  Thresholds lowered so that the small graph takes the ordered path;
+    then a launch that takes it by itself (RMAT-22, 512 batches: 7.8 M requests in the second hop)."""
+    import ctypes as C
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    _cabi.lib.tg_part_sample_order_thresholds(C.c_int64(1), C.c_int64(1))
+    try:
+        ptrs, idx, n = _graph(dev)
+        seeds = _cabi.seed_batches(9, 40, 7, B, n, dev)
+        seeds[3, :5] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))
+        shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
+        ref = _replicated(ptrs, idx, seeds, 40, sampler)
+        dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler, packed_replies=packed)
+        torch.cuda.synchronize()
+        for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
+            s, r, c, e, lo = dout.batch(b)
+            assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_), b
+    finally:
+        _cabi.lib.tg_part_sample_order_thresholds(C.c_int64(1 << 21), C.c_int64(1 << 24))
+    if sampler == 0 and packed is None:
+        n = 1 << 22
+        row, col = _cabi.rmat_edges(22, n * 16, 0x5EED0016, dev)
+        ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, True)
+        del row, col
+        nb = 512
+        seeds = _cabi.seed_batches(0xBA7C4, 0, nb, 1024, n, dev)
+        shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
+        ps = partitioned.PartitionedSampler(shard, nb, 1024, FANOUT)
+        out = ps.sample(seeds, SEED, 0)
+        ref = _cabi.NsBatchedOut(nb, 1024, FANOUT, dev)
+        _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, FANOUT, SEED, 0, ref)
+        torch.cuda.synchronize()
+        assert torch.equal(out.counts, ref.counts) and torch.equal(out.layer_offsets, ref.layer_offsets)
+        ar_n = torch.arange(out.samples.shape[1], device=dev)[None, :]
+        ar_e = torch.arange(out.rows.shape[1], device=dev)[None, :]
+        assert bool(((out.samples == ref.samples) | (ar_n >= ref.counts[:, 0:1])).all())
+        for a_, b_ in ((out.rows, ref.rows), (out.cols, ref.cols), (out.edge_index, ref.edge_index)):
+            assert bool(((a_ == b_) | (ar_e >= ref.counts[:, 1:2])).all())
+
+
 @pytest.mark.parametrize("fan", [[1], [32, 2], [3, 3, 3], []])
 def test_device_form_other_fanouts_and_empty_columns(fan):
     from tch_geometric import _cabi, partitioned
