@@ -318,15 +318,17 @@ def main(argv=None):
     bytes_per_launch = alg_bytes / my_launches
     achieved = bytes_per_launch / avg_kernel_s / 1e9
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % (pipeline if form != 2 else "fused"))
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))  # PMC passes of an identical launch, collected by tools/pmc_win.sh
             form_ran = "fused" if args.form == "fused" else "windowed"
             if (tj.get("batches_per_launch") == G and args.scale == 24 and B == 1024 and fanout == [15, 10]
-                    and tj.get("idx32") == args.idx32 and tj.get("ptr32") == args.ptr32 and tj.get("form") == form_ran):
+                    and tj.get("idx32") == args.idx32 and tj.get("ptr32") == args.ptr32 and tj.get("form") == form_ran
+                    and (form_ran == "fused" or tj.get("pipeline", "push") == pipeline)):
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of the same launch; NOT this run)"
+                traffic_source = ("profiles/%s (separate rocprofv3 --pmc passes of the same launch and pipeline; NOT this "
+                                  "run)" % os.path.basename(tpath))
         except Exception:
             traffic = None
 

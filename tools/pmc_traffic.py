@@ -10,8 +10,10 @@ import sys
 from collections import defaultdict
 
 rd_dir, wr_dir, form, bpl = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+pipeline = sys.argv[5] if len(sys.argv) > 5 else "push"
 needles = ("tg::win_",) if form == "windowed" else ("ns_homo_uniform_kernel",)
-launch_marker = "win_init_kernel" if form == "windowed" else "ns_homo_uniform_kernel"
+# the first kernel of a launch: win_init (round 2's pipeline), win_first_hops* (fused first hops), win_vtab (staged form)
+launch_markers = ("win_init_kernel", "win_first_hops", "win_vtab_kernel") if form == "windowed" else ("ns_homo_uniform_kernel",)
 
 
 def collect(root):
@@ -23,7 +25,7 @@ def collect(root):
                 tot[row["Counter_Name"]] += float(row["Counter_Value"])
                 short = name.split("(")[0].split("<")[0].replace("void ", "")
                 per_kernel[short][row["Counter_Name"]] += float(row["Counter_Value"])
-                if launch_marker in name:
+                if any(mk in name for mk in launch_markers):
                     launches.add(row["Dispatch_Id"])
     return tot, per_kernel, max(len(launches), 1)
 
@@ -33,7 +35,7 @@ wr, wr_k, n_wr = collect(wr_dir)
 rd_bytes = (128 * rd["TCC_EA0_RDREQ_128B_sum"] + 64 * rd["TCC_EA0_RDREQ_64B_sum"] + 32 * rd["TCC_EA0_RDREQ_32B_sum"]) / n_rd
 wr_bytes = (64 * wr["TCC_EA0_WRREQ_64B_sum"] + 32 * (wr["TCC_EA0_WRREQ_sum"] - wr["TCC_EA0_WRREQ_64B_sum"])) / n_wr
 out = {
-    "form": form, "batches_per_launch": bpl, "idx32": 1, "ptr32": 1, "launches_profiled": [n_rd, n_wr],
+    "form": form, "pipeline": pipeline, "batches_per_launch": bpl, "idx32": 1, "ptr32": 1, "launches_profiled": [n_rd, n_wr],
     "read_requests_per_launch": rd["TCC_EA0_RDREQ_sum"] / n_rd,
     "read_requests_128B_per_launch": rd["TCC_EA0_RDREQ_128B_sum"] / n_rd,
     "write_requests_per_launch": wr["TCC_EA0_WRREQ_sum"] / n_wr,
