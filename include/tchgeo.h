@@ -173,6 +173,7 @@ typedef struct {
                                      a side stream beside part p + 1's sort and gather (default 1 = one stream: measured, the overlap
                                      buys nothing -- both kernels are bound by vector-ALU work -- and every part costs 0.2 ms) */
     int32_t stage_part_min_batches; /* ... as long as every part keeps at least this many batches (default 1024) */
+    int32_t stage_sort_blocks;      /* staged form: workgroups of the item sort = rows of its histogram (default 512, the most) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

@@ -35,8 +35,10 @@ for D in dims:
     for prefetch in prefetches:
         loader = NeighborLoader(data, [15, 10], input_nodes=seeds, batch_size=1024, prefetch=prefetch)
         entry = {}
-        for k, sb in enumerate(loader.super_batches()):   # un-timed: slabs, pinned buffers and the allocator's pools come up
-            if k >= 2:
+        warm = 0
+        for sb in loader.super_batches():   # un-timed, as long as a timed pass: slabs, pinned buffers, the allocator's pools
+            warm += len(sb)
+            if warm >= min(n_batches, max(4 * prefetch, 2048)):
                 break
         torch.cuda.synchronize()
         for mode in ("mini_batches_sizes_only", "mini_batches_views_built", "super_batches"):

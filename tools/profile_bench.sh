@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$tag
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-secondary --no-verify --form $form --pipelines $pl --batches-per-step $bpl --steps 4 --warmup 2"
+ARGS="--no-cpu-baseline --no-secondary --no-verify --placements 1 --form $form --pipelines $pl --batches-per-step $bpl --steps 6 --warmup 2"
 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $OUT/pmc_rd --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_rd.log 2>&1
 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $OUT/pmc_wr --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_wr.log 2>&1
