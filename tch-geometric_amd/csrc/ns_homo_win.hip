@@ -785,7 +785,7 @@ static int win_env_int(const char *name, int dflt) {
 struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
-    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches;
+    int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches, stage_sort_blocks;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -804,6 +804,7 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_EMIT_THREADS", 256),
         win_env_int("TG_WIN_STAGE_PARTS", 1),
         win_env_int("TG_WIN_STAGE_PART_MIN_BATCHES", 1024),
+        win_env_int("TG_WIN_STAGE_SORT_BLOCKS", 512),
     };
     return t;
 }
@@ -1076,7 +1077,7 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         for (int part = 0; part < parts; ++part) {
             p.b0 = n_batches * part / parts;
             p.n_batches = n_batches * (part + 1) / parts - p.b0;
-            p.n_rows = (int32_t)std::min<int64_t>(WIN_PART_BLOCKS, p.n_batches); // rows of the histogram = sort workgroups
+            p.n_rows = (int32_t)std::min<int64_t>(std::min(std::max(t.stage_sort_blocks, 1), WIN_PART_BLOCKS), p.n_batches); // rows of the histogram = sort workgroups
             p.hist = hist0 + (size_t)part * WIN_PART_BLOCKS * WIN_MAX_BUCKETS;
             p.base = base0 + (size_t)part * (WIN_MAX_BUCKETS + 8);
             p.queues = queues0 + part;
@@ -1266,6 +1267,7 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_emit_threads = w.stage_emit_threads;
     t->stage_parts = w.stage_parts;
     t->stage_part_min_batches = w.stage_part_min_batches;
+    t->stage_sort_blocks = w.stage_sort_blocks;
     return TG_OK;
 }
 
@@ -1294,6 +1296,7 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_emit_threads >= 64 && t->stage_emit_threads <= 1024) w.stage_emit_threads = t->stage_emit_threads & ~63;
     if (t->stage_parts > 0) w.stage_parts = t->stage_parts;
     if (t->stage_part_min_batches > 0) w.stage_part_min_batches = t->stage_part_min_batches;
+    if (t->stage_sort_blocks > 0) w.stage_sort_blocks = t->stage_sort_blocks;
     return TG_OK;
 }
 
