@@ -151,11 +151,13 @@ def main(argv=None):
 
     form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
 
+    ws_staged = form != 2 and args.pipelines != "push"   # the workspaces then hold the staged pipeline's stage slots too
+
     def alloc_slabs(G):  # 16 384 batches per launch need ~100 GB of slabs + workspace: on a GPU with less free HBM, halve
         while True:
             try:
                 out = _cabi.NsBatchedOut(G, B, fanout, dev)
-                ws = _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None
+                ws = _cabi.ns_homo_workspace(G, B, fanout, dev, staged=ws_staged) if form != 2 else None
                 return out, ws, G
             except torch.OutOfMemoryError:
                 out = ws = None
@@ -178,7 +180,7 @@ def main(argv=None):
                 if free_b < need + (24 << 30):           # keep room for the graph, its build and the seeds
                     break
                 candidates.append((_cabi.NsBatchedOut(G, B, fanout, dev),
-                                   _cabi.ns_homo_workspace(G, B, fanout, dev) if form != 2 else None))
+                                   _cabi.ns_homo_workspace(G, B, fanout, dev, staged=ws_staged) if form != 2 else None))
             except torch.OutOfMemoryError:
                 torch.cuda.empty_cache()
                 break

@@ -137,6 +137,8 @@ TG_API int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t
 #define TG_NS_FORM_WINDOWED 1
 #define TG_NS_FORM_FUSED 2
 #define TG_NS_FORM_WINDOWED_WIDE 3 /* _WINDOWED with the 24-byte work items that launches beyond 32-bit offsets use */
+/* (the size includes the staged pipeline's stage slots only while tg_ns_win_tuning.staged is on at the time of the query;
+ * a launch whose workspace lacks them takes the push form) */
 TG_API int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
                                int64_t *n_bytes);
 TG_API int tg_ns_homo_batched_ws(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
@@ -149,6 +151,12 @@ TG_API int tg_ns_homo_batched_ws(const tg_graph *csc, const int64_t *seeds, int6
 TG_API int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
                             int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out, int64_t workspace_bytes,
                             int32_t mode, int32_t *form, int32_t *n_windows);
+
+/* Which PIPELINE of the window-ordered form the call takes under the current tuning: *staged = 1 the staged one (gather
+ * into stage slots, then emit; needs the larger workspace), 0 the push one or no window-ordered form at all.  A pure query. */
+TG_API int tg_ns_homo_batched_pipeline(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out, int64_t workspace_bytes,
+                                int32_t mode, int32_t *staged);
 
 /* Tuning of the window-ordered form (process-wide; defaults come from TG_WIN_* environment variables read once).
  * Outputs never depend on it.  _set: a zero field (negative for the four flags) keeps the current value. */

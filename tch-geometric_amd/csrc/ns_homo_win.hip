@@ -837,7 +837,7 @@ static WinStageClock &win_clock() {
 }
 
 struct WinLayout {
-    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, stage, total;
+    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, stage, total, total_push;
     int64_t max_items;
     int stage_words; // 16 / 32: words per stage slot of the staged form; 0: fan-outs beyond it (push form only)
 };
@@ -872,6 +872,7 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
     L.items_in = take((size_t)L.max_items * sizeof(WinItemW)); // sized for the wide form
     L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
     L.vtab = take((size_t)WIN_MAX_BUCKETS * sizeof(uint32_t));
+    L.total_push = at; // what the push form needs; the staged form's slots come after it
     L.stage_words = win_stage_words(fanout, n_hops);
     L.stage = take((size_t)L.max_items * L.stage_words * sizeof(uint32_t));
     L.total = at;
@@ -1164,7 +1165,10 @@ extern "C" int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, co
                "tg_ns_homo_workspace_bytes: bad arguments");
     for (int h = 0; h < n_hops; ++h)
         TG_REQUIRE(fanout[h] >= 1 && fanout[h] <= 255, "tg_ns_homo_workspace_bytes: fanout[%d] outside [1, 255]", h);
-    *n_bytes = (int64_t)tg::win_layout(n_batches, n_seeds, fanout, n_hops).total;
+    // the staged pipeline's stage slots (16 GB for the 16 384-batch bench launch) only when that pipeline is switched on
+    // (tg_ns_win_tuning.staged) at the time of the query; a launch whose workspace lacks them takes the push form
+    const tg::WinLayout L = tg::win_layout(n_batches, n_seeds, fanout, n_hops);
+    *n_bytes = (int64_t)(tg::win_tuning().staged ? L.total : L.total_push);
     return TG_OK;
 }
 
@@ -1194,8 +1198,8 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
                                const tg_ns_out *out, void *ws, int64_t ws_bytes, int32_t mode, hipStream_t stream) {
     using namespace tg;
     const WinLayout L = win_layout(n_batches, n_seeds, fanout, n_hops);
-    TG_REQUIRE(ws && ws_bytes >= (int64_t)L.total, "tg_ns_homo_batched_ws: workspace too small (%lld < %lld bytes)",
-               (long long)ws_bytes, (long long)L.total);
+    TG_REQUIRE(ws && ws_bytes >= (int64_t)L.total_push, "tg_ns_homo_batched_ws: workspace too small (%lld < %lld bytes)",
+               (long long)ws_bytes, (long long)L.total_push);
     TG_REQUIRE(((uintptr_t)ws & 255) == 0, "tg_ns_homo_batched_ws: workspace must be 256-byte aligned");
     WinParams p;
     p.ptrs = csc->ptrs;
@@ -1242,7 +1246,8 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     const bool repl = (cfg ? cfg->sampler : TG_SAMPLER_UNIFORM) == TG_SAMPLER_UNIFORM_REPL;
     p.vtab = reinterpret_cast<uint32_t *>(w + L.vtab);
     p.stage = reinterpret_cast<uint32_t *>(w + L.stage);
-    if (narrow && !force_wide && win_staged_applicable(p, win_tuning(), csc, n_batches, fanout, n_hops, L.stage_words))
+    if (narrow && !force_wide && ws_bytes >= (int64_t)L.total &&
+        win_staged_applicable(p, win_tuning(), csc, n_batches, fanout, n_hops, L.stage_words))
         return repl ? win_dispatch_staged<true>(p, csc, L.stage_words, n_batches, fanout, n_hops, stream)
                     : win_dispatch_staged<false>(p, csc, L.stage_words, n_batches, fanout, n_hops, stream);
     if (narrow && !force_wide) return win_dispatch<WinItemN>(p, repl, n_batches, fanout, n_hops, stream);
@@ -1330,7 +1335,7 @@ extern "C" int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, i
     if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE) return TG_OK; // the scanning kernels: neither form
     if (workspace_bytes <= 0 || !tg_ns_homo_windowed_applicable(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, mode))
         return TG_OK;
-    if ((int64_t)tg::win_layout(n_batches, n_seeds, fanout, n_hops).total > workspace_bytes) return TG_OK; // the launch would refuse
+    if ((int64_t)tg::win_layout(n_batches, n_seeds, fanout, n_hops).total_push > workspace_bytes) return TG_OK; // the launch would refuse
     int32_t shift = 0, nb = 0;
     tg::win_window_geometry(csc, &shift, &nb);
     int slot_bits = 1;
@@ -1339,5 +1344,21 @@ extern "C" int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, i
                         n_batches <= ((int64_t)1 << (32 - slot_bits));
     *form = (narrow && mode != TG_NS_FORM_WINDOWED_WIDE) ? TG_NS_FORM_WINDOWED : TG_NS_FORM_WINDOWED_WIDE;
     if (n_windows) *n_windows = nb;
+    return TG_OK;
+}
+
+extern "C" int tg_ns_homo_batched_pipeline(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                           int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out,
+                                           int64_t workspace_bytes, int32_t mode, int32_t *staged) {
+    TG_REQUIRE(staged, "tg_ns_homo_batched_pipeline: null");
+    *staged = 0;
+    int32_t form = 0, n_win = 0;
+    const int rc = tg_ns_homo_batched_form(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, workspace_bytes, mode, &form, &n_win);
+    if (rc != TG_OK || form != TG_NS_FORM_WINDOWED) return rc;
+    const tg::WinLayout L = tg::win_layout(n_batches, n_seeds, fanout, n_hops);
+    tg::WinParams p{};
+    p.n_seeds = n_seeds;
+    *staged = workspace_bytes >= (int64_t)L.total &&
+              tg::win_staged_applicable(p, tg::win_tuning(), csc, n_batches, fanout, n_hops, L.stage_words);
     return TG_OK;
 }

@@ -30,7 +30,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
            "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol",
            "tg_debug_bounds_set_flag", "tg_part_sample_workspace_bytes", "tg_part_sample_ws",
-           "tg_part_sample_order_thresholds"]
+           "tg_part_sample_order_thresholds", "tg_ns_homo_batched_pipeline"]
 
 
 class TgGraph(C.Structure):
@@ -150,12 +150,19 @@ class NsBatchedOut:
         return self.samples[b, :ns], self.rows[b, :ne], self.cols[b, :ne], self.edge_index[b, :ne], lo
 
 
-def ns_homo_workspace(n_batches, n_seeds, fanout, device):
-    """Workspace of tg_ns_homo_batched_ws (the window-ordered gather of many-batch launches), as an int64 tensor."""
+def ns_homo_workspace(n_batches, n_seeds, fanout, device, staged=None):
+    """Workspace of tg_ns_homo_batched_ws (the window-ordered gather of many-batch launches), as an int64 tensor.
+    staged: True = sized for the staged pipeline too (its stage slots), False = push pipeline only, None = as the current
+    tuning says."""
     nbytes = C.c_int64(0)
     fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
-    check(lib.tg_ns_homo_workspace_bytes(C.c_int64(n_batches), C.c_int64(n_seeds), fan, C.c_int32(len(fanout)),
-                                         C.byref(nbytes)))
+    prev = ns_win_tuning_set(staged=int(staged)) if staged is not None else None
+    try:
+        check(lib.tg_ns_homo_workspace_bytes(C.c_int64(n_batches), C.c_int64(n_seeds), fan, C.c_int32(len(fanout)),
+                                             C.byref(nbytes)))
+    finally:
+        if prev is not None:
+            ns_win_tuning_set(staged=prev["staged"])
     return torch.empty(nbytes.value // 8 + 1, dtype=torch.int64, device=device)
 
 
@@ -201,6 +208,20 @@ def ns_homo_batched_form(graph, out, n_batches, n_seeds, fanout, ws=None, form=0
                                       C.c_int64(ws.numel() * 8 if ws is not None else 0), C.c_int32(form),
                                       C.byref(taken), C.byref(n_win)))
     return taken.value, n_win.value
+
+
+def ns_homo_batched_staged(graph, out, n_batches, n_seeds, fanout, ws=None, form=0, sampler=SAMPLER_UNIFORM):
+    """True if ns_homo_batched(..., ws=ws, form=form) would take the STAGED pipeline of the window-ordered form under the
+    current tuning (it needs the workspace sized while `staged` was on: ns_homo_workspace(..., staged=True))."""
+    cfg = TgNsConfig()
+    cfg.sampler, cfg.filter_mode = sampler, FILTER_NONE
+    fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
+    so = out.struct()
+    st = C.c_int32(0)
+    check(lib.tg_ns_homo_batched_pipeline(C.byref(graph), C.c_int64(n_batches), C.c_int64(n_seeds), fan,
+                                          C.c_int32(len(fanout)), C.byref(cfg), C.byref(so),
+                                          C.c_int64(ws.numel() * 8 if ws is not None else 0), C.c_int32(form), C.byref(st)))
+    return bool(st.value)
 
 
 class TgNsWinTuning(C.Structure):

@@ -54,7 +54,7 @@ def test_out_of_range_frontier_id_is_flagged_not_followed(dbg_cabi, form, knobs)
                 idx_c[int(ptrs[hub]):int(ptrs[hub + 1])] = n                           # every neighbour of the hub: id n_major
             g = cabi.graph_view(ptrs, idx_c, indices32=idx_c.to(torch.int32), ptrs32=ptrs.to(torch.int32))
             out = cabi.NsBatchedOut(6, 64, fan, dev)
-            ws = cabi.ns_homo_workspace(6, 64, fan, dev)
+            ws = cabi.ns_homo_workspace(6, 64, fan, dev, staged=True)
             flag.zero_()
             cabi.ns_homo_batched(g, seeds, fan, 0, 0, out, ws=ws if form != 2 else None, form=form)
             torch.cuda.synchronize()

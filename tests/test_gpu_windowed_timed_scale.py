@@ -76,7 +76,7 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
     dev = torch.device(DEV)
     seeds = cabi.seed_batches(0xBA7C4, 4096, nb, B, n, dev)
     a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
-    ws = cabi.ns_homo_workspace(nb, B, fan, dev)
+    ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True)
     taken, n_win = cabi.ns_homo_batched_form(g, a, nb, B, fan, ws=ws, form=AUTO)
     assert taken == WINDOWED and n_win >= 2048, (taken, n_win)       # the 16-byte-item windowed form, ~2 056 windows
     assert cabi.ns_win_tuning()["window_bytes"] == 512 * 1024
@@ -97,6 +97,7 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
         before = cabi.ns_win_tuning_set(**knobs)
         try:
             d = _poisoned(cabi, nb, B, fan)
+            assert cabi.ns_homo_batched_staged(g, d, nb, B, fan, ws=ws, form=AUTO) == bool(knobs.get("staged"))
             cabi.ns_homo_batched(g, seeds, fan, 0, 4096, d, ws=ws, form=AUTO)
             torch.cuda.synchronize()
             assert_equal_on_device(d, b)
@@ -116,7 +117,7 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
     before = cabi.ns_win_tuning_set(window_bytes=2048 if shadows else 4096)
     try:
         a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
-        ws = cabi.ns_homo_workspace(nb, B, fan, dev)
+        ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True)
         taken, n_win = cabi.ns_homo_batched_form(g, a, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler)
         assert taken == WINDOWED and n_win > 2048, (taken, n_win)
         cabi.ns_homo_batched(g, seeds, fan, 9, 77, a, sampler=sampler, ws=ws, form=WINDOWED)
@@ -134,6 +135,8 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
             prev = cabi.ns_win_tuning_set(**knobs)
             try:
                 c = _poisoned(cabi, nb, B, fan)
+                assert cabi.ns_homo_batched_staged(g, c, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler) == \
+                    bool(knobs.get("staged")), knobs
                 cabi.ns_homo_batched(g, seeds, fan, 9, 77, c, sampler=sampler, ws=ws, form=WINDOWED)
                 torch.cuda.synchronize()
                 assert_equal_on_device(c, b)
@@ -158,8 +161,10 @@ def test_odd_slab_pitch(cabi, fan, B, direct):
     before = cabi.ns_win_tuning_set(direct_hop0=min(direct, 1), staged=int(direct == 2))   # 2: the staged form
     try:
         a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
-        ws = cabi.ns_homo_workspace(nb, B, fan, dev)
+        ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True)
         assert cabi.ns_homo_batched_form(g, a, nb, B, fan, ws=ws, form=WINDOWED)[0] == WINDOWED
+        # the staged pipeline needs a second hop and ordered fan-outs <= 30: the others take the push form
+        assert cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=ws, form=WINDOWED) == (direct == 2 and len(fan) > 1)
         cabi.ns_homo_batched(g, seeds, fan, 2, 5, a, ws=ws, form=WINDOWED)
         cabi.ns_homo_batched(g, seeds, fan, 2, 5, b, form=FUSED)
         torch.cuda.synchronize()
@@ -182,12 +187,32 @@ def test_form_query(cabi):
     assert cabi.ns_homo_batched_form(g, out, 4, 64, [15, 10], ws=ws[:8], form=WINDOWED)[0] == FUSED
 
 
+def test_push_sized_workspace_takes_the_push_pipeline(cabi):
+    n, ptrs, idx, g = _rmat(cabi, 12)
+    dev = torch.device(DEV)
+    nb, B, fan = 8, 64, [15, 10]
+    seeds = cabi.seed_batches(0xBA7C4, 0, nb, B, n, dev)
+    small, big = cabi.ns_homo_workspace(nb, B, fan, dev, staged=False), cabi.ns_homo_workspace(nb, B, fan, dev, staged=True)
+    assert big.numel() > small.numel()
+    before = cabi.ns_win_tuning_set(staged=1)
+    try:
+        a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+        assert not cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=small, form=WINDOWED)
+        assert cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=big, form=WINDOWED)
+        cabi.ns_homo_batched(g, seeds, fan, 0, 0, a, ws=small, form=WINDOWED)
+        cabi.ns_homo_batched(g, seeds, fan, 0, 0, b, ws=big, form=WINDOWED)
+        torch.cuda.synchronize()
+        assert_equal_on_device(a, b)
+    finally:
+        cabi.ns_win_tuning_set(**before)
+
+
 def test_stage_times(cabi):
     n, ptrs, idx, g = _rmat(cabi, 14)
     dev = torch.device(DEV)
     nb, B, fan = 64, 128, [15, 10]
     seeds = cabi.seed_batches(0xBA7C4, 0, nb, B, n, dev)
-    out, ws = cabi.NsBatchedOut(nb, B, fan, dev), cabi.ns_homo_workspace(nb, B, fan, dev)
+    out, ws = cabi.NsBatchedOut(nb, B, fan, dev), cabi.ns_homo_workspace(nb, B, fan, dev, staged=True)
     cabi.ns_win_stage_timing(True)
     try:
         cabi.ns_homo_batched(g, seeds, fan, 0, 0, out, ws=ws, form=WINDOWED)

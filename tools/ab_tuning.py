@@ -18,7 +18,7 @@ G, B, fan, scale = int(os.environ.get("G", 16384)), 1024, [15, 10], 24
 ROUNDS = int(os.environ.get("ROUNDS", 3))
 n = 1 << scale
 out = _cabi.NsBatchedOut(G, B, fan, dev)
-ws = _cabi.ns_homo_workspace(G, B, fan, dev)
+ws = _cabi.ns_homo_workspace(G, B, fan, dev, staged=True)   # sized for both pipelines
 out2 = _cabi.NsBatchedOut(G, B, fan, dev) if os.environ.get("SOL", "1") == "1" else None
 row, col = _cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
 ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, True)
