@@ -61,6 +61,12 @@ inline void check_kind(const Tensor &t, at::ScalarType want) {
         throw py::value_error(os.str());
     }
 }
+// Where the reference PANICS (Rust `panic!` / index out of bounds / empty float range -> pyo3_runtime.PanicException) this
+// module raises `tch_geometric.PanicException`: a subclass of RuntimeError (pyo3's derives from BaseException; a
+// RuntimeError is what callers that guard a sampler call can reasonably catch), registered in python_module.cpp.
+struct PanicError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
 inline void check_rc(int rc) {
     if (rc == TG_OK) return;
     std::string msg = std::string("tchgeo: ") + tg_last_error();

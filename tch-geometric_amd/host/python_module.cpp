@@ -203,7 +203,7 @@ bool run_ns_filtered_device(NsResult &r, const c10::Device &dev, const tg_graph 
     }
     if (status_h & 1) throw std::runtime_error("neighbor sampling: column-group workspace overflow");
     if (status_h & 2) // sampling.rs:49: gen_range over an empty float range panics in the reference
-        throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+        throw PanicError("weighted sampling met a non-positive running weight sum (the reference panics here)");
     if (status_h & 4) throw std::runtime_error("neighbor sampling: internal capacity error");
     const int64_t *m = mh.data_ptr<int64_t>();
     r.n_samples = m[0];
@@ -285,7 +285,7 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
                                         ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
             total = read_scalar<int64_t>(offsets[m]);
             if (read_scalar<int32_t>(status) & 2) // sampling.rs:49: gen_range over an empty float range panics
-                throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+                throw PanicError("weighted sampling met a non-positive running weight sum (the reference panics here)");
         } else
         for (;;) { // the frontier's columns need sum(ceil(deg/512)) groups; grow the workspace if the guess was low
             Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
@@ -390,7 +390,7 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
     r.n_samples = l[lo_words];
     r.n_edges = l[lo_words + 1];
     if (r.n_samples < 0) // sampling.rs:49: gen_range over an empty float range panics in the reference
-        throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+        throw PanicError("weighted sampling met a non-positive running weight sum (the reference panics here)");
     for (int h = 0; h < H; ++h) r.layer_offsets.emplace_back(l[3 * h], l[3 * h + 1], l[3 * h + 2]);
     return r;
 }
@@ -947,7 +947,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
             nogil.reset();
             if (status_h & 1) throw std::runtime_error("neighbor_sampling_heterogenous: column-group workspace overflow");
             if (status_h & 2) // sampling.rs:49: gen_range over an empty float range panics in the reference
-                throw std::runtime_error("weighted sampling met a non-positive running weight sum (the reference panics here)");
+                throw PanicError("weighted sampling met a non-positive running weight sum (the reference panics here)");
             if (status_h & 4) throw std::runtime_error("neighbor_sampling_heterogenous: internal capacity error");
             const int64_t *m = mh.data_ptr<int64_t>();
             py::dict samples, rows, cols, eidx, los;
@@ -1126,7 +1126,7 @@ std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, cons
                                          ws_bytes, stream_of(dev)));
     const int32_t flags = read_scalar<int32_t>(status);
     if (flags & 2)
-        throw std::runtime_error("cannot sample empty range: every bias weight so far underflowed to zero (the "
+        throw PanicError("cannot sample empty range: every bias weight so far underflowed to zero (the "
                                  "reference panics here, utils/sampling.rs:49)");
     if (flags & 1) throw std::runtime_error("biased_tempo_random_walk: sort slab too small for a CSR row");
     return {back(walks, start.device()), back(wts, start.device())};
@@ -1139,6 +1139,7 @@ void register_more(py::module_ &m); // negative sampling + hgt (python_module_mo
 PYBIND11_MODULE(tch_geometric, m) {
     m.doc() = "MI355X-native backend behind tch-geometric's operator surface (reference: src/python.rs)";
     // additive: the reference's RNG cannot be seeded from Python (utils/random.rs:14-17 is not exported)
+    static py::exception<PanicError> panic_exception(m, "PanicException", PyExc_RuntimeError);
     m.def("seed", [](uint64_t s) {
         RngState &st = rng_state();
         std::lock_guard<std::mutex> lk(st.mu);

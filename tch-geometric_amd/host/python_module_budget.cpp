@@ -99,7 +99,7 @@ py::tuple budget_sampling(const std::vector<std::string> &node_types,
     for (int t = 0; t < T && H > 0; ++t) {
         const std::string &name = node_types[(size_t)t];
         if (!num_neighbors.contains(py::str(name)))
-            throw std::runtime_error("budget_sampling: num_neighbors has no entry for node type " + name +
+            throw PanicError("budget_sampling: num_neighbors has no entry for node type " + name +
                                      " (the reference panics here, budget_sampling.rs:226)");
         auto q = num_neighbors[py::str(name)].cast<std::vector<int64_t>>();
         if ((int64_t)q.size() < H) throw py::index_error("num_neighbors[" + name + "] is shorter than num_hops");
@@ -205,7 +205,7 @@ py::tuple budget_sampling(const std::vector<std::string> &node_types,
         for (int t = 0; t < T; ++t) { // :225 node_types order
             const std::string &name = node_types[(size_t)t];
             if (!num_neighbors.contains(py::str(name)))
-                throw std::runtime_error("budget_sampling: num_neighbors has no entry for node type " + name +
+                throw PanicError("budget_sampling: num_neighbors has no entry for node type " + name +
                                          " (the reference panics here, budget_sampling.rs:226)");
             auto quota = num_neighbors[py::str(name)].cast<std::vector<int64_t>>();
             if ((int64_t)quota.size() <= layer) throw py::index_error("num_neighbors[" + name + "] is shorter than num_hops");

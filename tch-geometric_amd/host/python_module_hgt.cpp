@@ -156,7 +156,7 @@ py::tuple hgt_sampling(const std::vector<std::string> &node_types,
     Tensor c = to_host(counts); // the call's only synchronisation
     nogil.reset();
     if ((c[T + R].item<int64_t>() & 0xffffffff) != 0)
-        throw std::runtime_error("hgt_sampling: num_samples has no entry for a node type that owns a budget, or a "
+        throw PanicError("hgt_sampling: num_samples has no entry for a node type that owns a budget, or a "
                                  "weight sum was not positive (the reference panics here)");
     py::dict d_samples, d_ts, d_rows, d_cols, d_eidx;
     for (int t = 0; t < T; ++t) {

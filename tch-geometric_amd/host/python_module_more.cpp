@@ -76,7 +76,7 @@ NegRun run_neg(const c10::Device &dev, int T, const std::vector<int32_t> &rel_sr
     check_rc(tg_neg_sample(&pb, &rng, &out, ws.data_ptr<int64_t>(), stream_of(dev)));
     Tensor c = to_host(counts); // the call's only synchronisation
     if ((c[T + R].item<int64_t>() & 0xffffffff) != 0)
-        throw std::runtime_error("inbound negative sampling indexed a CSR row out of range (the reference panics here, "
+        throw PanicError("inbound negative sampling indexed a CSR row out of range (the reference panics here, "
                                  "negative_sampling.rs:113)");
     for (int t = 0; t < T; ++t) run.n_samples.push_back(c[t].item<int64_t>());
     for (int r = 0; r < R; ++r) run.n_edges.push_back(c[T + r].item<int64_t>());

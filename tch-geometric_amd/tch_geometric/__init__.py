@@ -7,7 +7,7 @@ import torch  # noqa: F401
 
 from . import _cabi  # noqa: F401  (raises if lib/libtchgeo_hip.so is missing)
 from .tch_geometric import *  # noqa: F401,F403
-from .tch_geometric import (backend_version, graph_cache_clear, graph_cache_info, rng_state, seed,  # noqa: F401
-                            set_rng_state)
+from .tch_geometric import (PanicException, backend_version, graph_cache_clear, graph_cache_info,  # noqa: F401
+                            rng_state, seed, set_rng_state)
 from .utils import (TEMPORAL_SAMPLE_DYNAMIC, TEMPORAL_SAMPLE_RELATIVE, TEMPORAL_SAMPLE_STATIC,  # noqa: F401
                     TemporalEdgeFilter, UniformEdgeSampler, WeightedEdgeSampler)

@@ -26,6 +26,7 @@ def seed(seed: int) -> None: ...                      # additive: the reference 
 def rng_state() -> Tuple[int, int]: ...
 def set_rng_state(seed: int, call_counter: int) -> None: ...
 def backend_version() -> str: ...
+class PanicException(RuntimeError): ...               # raised where the reference panics (pyo3_runtime.PanicException there)
 def graph_cache_info() -> Dict[str, int]: ...         # additive: CPU-resident adjacency tensors are uploaded once and
 def graph_cache_clear() -> None: ...                  # kept on the device (keyed on storage identity + content version)
 

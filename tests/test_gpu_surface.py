@@ -101,7 +101,8 @@ def test_error_behaviour(tg):
     with pytest.raises(ValueError, match="Unknown bias type: cubic"):           # python.rs:670
         tg.biased_tempo_random_walk(P, I, torch.zeros(2, dtype=torch.int64).cuda(), torch.zeros(2, dtype=torch.int64).cuda(),
                                     torch.tensor([0]).cuda(), torch.tensor([0]).cuda(), 3, "cubic", True, 2)
-    with pytest.raises(RuntimeError):                                           # sampling.rs:49 panic
+    assert issubclass(tg.PanicException, RuntimeError)
+    with pytest.raises(tg.PanicException):                                      # sampling.rs:49 panic
         tg.neighbor_sampling_homogenous(torch.tensor([0, 2, 2]).cuda(), torch.tensor([0, 1]).cuda(),
                                         torch.tensor([0]).cuda(), [1],      # 2 candidates, 1 slot: one float draw
                                         tg.WeightedEdgeSampler(torch.zeros(2, dtype=torch.float64).cuda()))
