@@ -1139,7 +1139,7 @@ void register_more(py::module_ &m); // negative sampling + hgt (python_module_mo
 PYBIND11_MODULE(tch_geometric, m) {
     m.doc() = "MI355X-native backend behind tch-geometric's operator surface (reference: src/python.rs)";
     // additive: the reference's RNG cannot be seeded from Python (utils/random.rs:14-17 is not exported)
-    static py::exception<PanicError> panic_exception(m, "PanicException", PyExc_RuntimeError);
+    py::register_exception<PanicError>(m, "PanicException", PyExc_RuntimeError);
     m.def("seed", [](uint64_t s) {
         RngState &st = rng_state();
         std::lock_guard<std::mutex> lk(st.mu);
