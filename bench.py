@@ -334,6 +334,12 @@ def main(argv=None):
         except Exception:
             traffic = None
 
+    # what the launches really took (a query of the library, not the flag that was asked for)
+    if ws is None or _cabi.ns_homo_batched_form(graph, out, G, B, fanout, ws=ws, form=form)[0] == 2:
+        pipeline_taken = "fused"
+    else:
+        pipeline_taken = "staged" if _cabi.ns_homo_batched_staged(graph, out, G, B, fanout, ws=ws, form=form) else "push"
+
     result = {
         "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [%s] on RMAT-%d" % (args.fanout, args.scale),
         "value": edges_all / dt_max,
@@ -355,7 +361,7 @@ def main(argv=None):
             "placement_policy": ("the launch is timed on the FASTEST of the slab / workspace placements x pipelines tried in "
                                  "untimed set-up (all listed in placements_tried_ms_per_launch; --placements 1 "
                                  "--pipelines push = take the first)" if placement_ms else "first allocation"),
-            "pipeline": pipeline if form != 2 else "fused",
+            "pipeline": pipeline_taken,
             "first_placement_ms_per_launch": (next(iter(placement_ms.values())) if placement_ms else None),
             "batches_per_launch": G,
             "placements_tried_ms_per_launch": placement_ms,

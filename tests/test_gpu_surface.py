@@ -350,3 +350,37 @@ def test_cpu_resident_graph_is_uploaded_once(tg):
     del idx2
     tg.graph_cache_clear()
     assert tg.graph_cache_info()["entries"] == 0
+
+
+@pytest.mark.parametrize("deg", [20_000, 100_000, 700_000])
+@pytest.mark.parametrize("filtered", [False, True])
+def test_weighted_sampling_of_long_columns(tg, deg, filtered):
+    """the weighted sampler's three forms by column length (csrc/ns_hop_scan.hip): one wavefront (<= 16 K edges), a
+    workgroup (chunk totals, carries, atomic-max slots), and -- beyond the workgroup's scratch of 8 192 chunks = 512 K
+    edges -- one wavefront walking the column inside that kernel; all equal the oracle's blocked running sum bit for bit"""
+    rs = np.random.default_rng(deg)
+    n = 2000
+    # vertex 7 owns a column of `deg` in-edges (multi-edges allowed, storage.rs keeps them); the others a few each
+    rows = np.concatenate([rs.integers(0, n, deg), rs.integers(0, n, 6 * n)])
+    cols = np.concatenate([np.full(deg, 7), rs.integers(0, n, 6 * n)])
+    ptrs, idx, _ = orc.to_csc(np.stack([rows, cols]).astype(np.int64), n)
+    w = rs.uniform(0.05, 3.0, len(idx))
+    ts = rs.integers(0, 100, len(idx))
+    P, I = torch.from_numpy(ptrs).cuda(), torch.from_numpy(idx).cuda()
+    inputs = np.array([7, 3, 7, 11, 500], dtype=np.int64)
+    st = np.array([50, 10, 90, 0, 20])
+    k = [12, 3]
+    tg.seed(21)
+    call = tg.rng_state()[1]
+    sampler = tg.WeightedEdgeSampler(torch.from_numpy(w).cuda())
+    flt = None
+    kw = {}
+    if filtered:
+        flt = (tg.TemporalEdgeFilter((-30, 30), torch.from_numpy(ts).cuda(), True, tg.TEMPORAL_SAMPLE_RELATIVE),
+               torch.from_numpy(st).cuda())
+        kw = dict(filter_mode=tg.TEMPORAL_SAMPLE_RELATIVE, forward=True, window=(-30, 30), timestamps=ts, inputs_state=st)
+    out = tg.neighbor_sampling_homogenous(P, I, torch.from_numpy(inputs).cuda(), k, sampler, flt)
+    o = orc.ns_homo(ptrs, idx, inputs, k, orc.rng_philox(21, call), sampler=orc.SAMPLER_WEIGHTED, weights=w, **kw)
+    assert out[4] == o[4] and int(out[1].numel()) > 20
+    for a, b in zip(out[:4], o[:4]):
+        assert np.array_equal(_np(a), b)
