@@ -17,6 +17,8 @@
 
 #include <rocprim/device/device_scan.hpp>
 
+#include <algorithm>
+
 #include "tg_device.h"
 #include "tg_host.h"
 #include "tg_scan.h"
@@ -354,17 +356,28 @@ constexpr int64_t HW_LONG_EDGES = 16384;  // columns longer than this go to hw_s
 constexpr int HW_LONG_BLOCKS = 256;       // its workgroups (each with its own scratch)
 constexpr int64_t HW_LONG_CHUNKS = 8192;  // chunks of 64 edges its scratch holds per workgroup (512 K edges); beyond: one
                                           // wavefront walks the column as before
-__global__ void hw_select_kernel(const HopScanParams p) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// the long columns of the frontier -> vgroups[1 ...], their number -> vgroups[0] (zeroed by the launcher)
+__global__ void hw_list_long_kernel(const HopScanParams p) {
     __shared__ HsSeg S[HS_MAX_SEG];
     const int64_t m = hs_load_segs(p, S);
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < m; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = p.vertices[v];
+        if (w < 0) continue;
+        const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+        if (sg.ptrs[w + 1] - sg.ptrs[w] > HW_LONG_EDGES)
+            p.vgroups[1 + atomicAdd(reinterpret_cast<unsigned long long *>(p.vgroups), 1ull)] = v;
+    }
+}
+
+__device__ __forceinline__ void hw_select_short(const HopScanParams &p, unsigned char *smem, const HsSeg *S, int64_t m,
+                                                int64_t block, int64_t n_blocks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kmax = p.k;
     int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem) + (size_t)wave * (2 * kmax + 64);
     uint32_t *slot_rank = reinterpret_cast<uint32_t *>(slot_ptr + kmax);
     // (64 doubles behind slot_ptr used to hold the serial prefix; the blocked running sum needs no scratch)
-    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t wave_id = (block * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = (n_blocks * blockDim.x) >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int64_t v = wave_id; v < m; v += n_waves) {
         const int64_t w = p.vertices[v];
@@ -376,10 +389,7 @@ __global__ void hw_select_kernel(const HopScanParams p) {
         if (w >= 0) {
             const int64_t st = p.states ? p.states[v] : 0;
             const int64_t e0 = sg.ptrs[w], e1 = sg.ptrs[w + 1];
-            if (e1 - e0 > HW_LONG_EDGES) { // a whole workgroup takes it (hw_select_long_kernel): list it and move on
-                if (lane == 0) p.vgroups[1 + atomicAdd(reinterpret_cast<unsigned long long *>(p.vgroups), 1ull)] = v;
-                continue;
-            }
+            if (e1 - e0 > HW_LONG_EDGES) continue; // a whole workgroup takes it (hw_list_long_kernel listed it)
             const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
             const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
             double w_sum = 0.0;
@@ -439,20 +449,17 @@ __global__ void hw_select_kernel(const HopScanParams p) {
 // wavefront draws for its chunks -- candidates of rank < k fill slot rank, an accepted later candidate raises its slot to
 // (rank, position) with a 64-bit atomic max, so that the LAST accepted candidate of a slot wins as in the reference's loop
 // whatever order the chunks run in -- (D) the slots are read out.  Same draws (named by (call, vertex, rank)), same result.
-__global__ void __launch_bounds__(1024) hw_select_long_kernel(const HopScanParams p) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ HsSeg S[HS_MAX_SEG];
-    __shared__ uint32_t n_total_s;
-    hs_load_segs(p, S);
+__device__ __forceinline__ void hw_select_long(const HopScanParams &p, unsigned char *smem, const HsSeg *S,
+                                               uint32_t &n_total_s, int64_t block, int64_t n_blocks) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int kmax = p.k;
     int64_t *slot_ptr = reinterpret_cast<int64_t *>(smem);
     unsigned long long *slot_best = reinterpret_cast<unsigned long long *>(slot_ptr + kmax);
-    double *tot = p.long_tot + (size_t)blockIdx.x * HW_LONG_CHUNKS;
-    uint32_t *cnt = p.long_cnt + (size_t)blockIdx.x * HW_LONG_CHUNKS;
+    double *tot = p.long_tot + (size_t)block * HW_LONG_CHUNKS;
+    uint32_t *cnt = p.long_cnt + (size_t)block * HW_LONG_CHUNKS;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int64_t n_long = p.vgroups[0];
-    for (int64_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+    for (int64_t li = block; li < n_long; li += n_blocks) {
         const int64_t v = p.vgroups[1 + li];
         const int64_t w = p.vertices[v];
         const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
@@ -567,6 +574,32 @@ __global__ void __launch_bounds__(1024) hw_select_long_kernel(const HopScanParam
         }
         __syncthreads();
     }
+}
+
+__global__ void hw_select_kernel(const HopScanParams p) { // the short columns only (any workgroup size)
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    hw_select_short(p, smem, S, m, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(1024) hw_select_long_kernel(const HopScanParams p) { // the long columns only
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ HsSeg S[HS_MAX_SEG];
+    __shared__ uint32_t n_total_s;
+    hs_load_segs(p, S);
+    hw_select_long(p, smem, S, n_total_s, blockIdx.x, gridDim.x);
+}
+// Both in ONE launch of 1 024-thread workgroups: the first HW_LONG_BLOCKS take the long columns, the others the short ones,
+// side by side -- the long columns' two passes (2 x 100 us on cfg4) no longer wait for the short ones to finish.
+__global__ void __launch_bounds__(1024) hw_select_all_kernel(const HopScanParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ HsSeg S[HS_MAX_SEG];
+    __shared__ uint32_t n_total_s;
+    const int64_t m = hs_load_segs(p, S);
+    if (blockIdx.x < HW_LONG_BLOCKS)
+        hw_select_long(p, smem, S, n_total_s, blockIdx.x, HW_LONG_BLOCKS);
+    else
+        hw_select_short(p, smem, S, m, (int64_t)blockIdx.x - HW_LONG_BLOCKS, (int64_t)gridDim.x - HW_LONG_BLOCKS);
 }
 
 // thread per (frontier vertex, slot): the slot's output position is offsets[v] + s -- no search, two rounds of loads
@@ -702,8 +735,17 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
         int64_t blocks = (p.m + n_waves - 1) / n_waves;
         if (blocks > 256 * 32) blocks = 256 * 32;
         TG_HIP(hipMemsetAsync(p.vgroups, 0, sizeof(int64_t), stream)); // the list of long columns: [0] = how many
-        hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
-        hipLaunchKernelGGL(hw_select_long_kernel, dim3(HW_LONG_BLOCKS), dim3(1024), (size_t)p.k * 16, stream, p);
+        hipLaunchKernelGGL(hw_list_long_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
+        const size_t lds_all = std::max((size_t)16 * (2 * p.k + 64) * sizeof(int64_t), (size_t)p.k * 16);
+        if (lds_all <= 60 * 1024) { // both roles in one launch
+            int64_t short_blocks = (p.m + 15) / 16;
+            if (short_blocks > 256 * 8) short_blocks = 256 * 8;
+            hipLaunchKernelGGL(hw_select_all_kernel, dim3((unsigned)(HW_LONG_BLOCKS + short_blocks)), dim3(1024), lds_all,
+                               stream, p);
+        } else {
+            hipLaunchKernelGGL(hw_select_kernel, dim3((unsigned)blocks), dim3(64 * n_waves), lds, stream, p);
+            hipLaunchKernelGGL(hw_select_long_kernel, dim3(HW_LONG_BLOCKS), dim3(1024), (size_t)p.k * 16, stream, p);
+        }
     } else {
         if (short_m) {
             hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
