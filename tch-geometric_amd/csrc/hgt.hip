@@ -25,6 +25,9 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -60,8 +63,8 @@ struct HgtType {
 
 // ---------------------------------------------------------------- generic single-workgroup scan
 // out[i] = sum of in[0..i), total[0] = sum of in[0..n) (+ *add_to if given: total accumulates)
-__global__ void scan_i64_kernel(const int64_t *__restrict__ in, const int64_t *n_ptr, int64_t n_imm, int64_t *out,
-                                int64_t *total) {
+__device__ __forceinline__ void scan_i64_body(const int64_t *__restrict__ in, const int64_t *n_ptr, int64_t n_imm,
+                                              int64_t *out, int64_t *total) {
     __shared__ int64_t wave_tot[16];
     __shared__ int64_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
@@ -91,18 +94,24 @@ __global__ void scan_i64_kernel(const int64_t *__restrict__ in, const int64_t *n
 // total of a flag array after its exclusive scan
 // exclusive scan of flag[0 .. n) into rank[0 .. n] (rank[n] = the total, also written to *total) in one launch of one
 // workgroup (tg_scan.h): the scans of a call are short and the call is bound by its number of launches
-__global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_kernel(const int64_t *__restrict__ flag, int64_t n, int64_t *rank,
-                                                                  int64_t *total) {
+__device__ __forceinline__ void hgt_scan1_body(const int64_t *__restrict__ flag, int64_t n, int64_t *rank, int64_t *total) {
     block_scan_exclusive_plus1(n, [&](int64_t i) { return flag[i]; }, rank);
     __syncthreads();
     if (threadIdx.x == 0) total[0] = rank[n];
 }
-__global__ void fill2_i64_kernel(int64_t *a, int64_t na, int64_t va, int64_t *b, int64_t nb, int64_t vb) {
+__global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_kernel(const int64_t *__restrict__ flag, int64_t n, int64_t *rank,
+                                                                  int64_t *total) {
+    hgt_scan1_body(flag, n, rank, total);
+}
+__device__ __forceinline__ void fill2_i64_body(int64_t *a, int64_t na, int64_t va, int64_t *b, int64_t nb, int64_t vb) {
     const int64_t n = na > nb ? na : nb;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < na) a[i] = va;
         if (i < nb) b[i] = vb;
     }
+}
+__global__ void fill2_i64_kernel(int64_t *a, int64_t na, int64_t va, int64_t *b, int64_t nb, int64_t vb) {
+    fill2_i64_body(a, na, va, b, nb, vb);
 }
 __global__ void scan_total_kernel(const int64_t *__restrict__ in, const int64_t *__restrict__ excl, int64_t n,
                                   int64_t *total) {
@@ -128,7 +137,7 @@ __global__ void hgt_init_inputs_kernel(HgtType ty, const int64_t *__restrict__ i
 
 // ---------------------------------------------------------------- update_budget (hgt_sampling.rs:27-102)
 // per sample of the layer: number of contributions = min(deg, 50); also marks the source budget present
-__global__ void hgt_contrib_count_kernel(HgtType dst, HgtTypeCtr *src_ctr, const int64_t *__restrict__ ptrs,
+__device__ __forceinline__ void hgt_contrib_count_body(HgtType dst, HgtTypeCtr *src_ctr, const int64_t *__restrict__ ptrs,
                                          int64_t *ccnt, int64_t cap) {
     const int64_t b = dst.ctr->lay_begin, e = dst.ctr->lay_end;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cap; j += (int64_t)gridDim.x * blockDim.x) {
@@ -142,7 +151,7 @@ __global__ void hgt_contrib_count_kernel(HgtType dst, HgtTypeCtr *src_ctr, const
     if (blockIdx.x == 0 && threadIdx.x == 0 && e > b) src_ctr->present = 1; // :38-40, :55
 }
 // one lane per (sample j, neighbour i): key or -1, 1/count, timestamp  (:58-100)
-__global__ void hgt_contrib_gen_kernel(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
+__device__ __forceinline__ void hgt_contrib_gen_body(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
                                        const int64_t *__restrict__ indices, const int64_t *__restrict__ edge_ts,
                                        int has_timerange, int64_t tr_lo, int64_t tr_hi, const int64_t *ccnt,
                                        const int64_t *coff, int64_t cap, int64_t *ckey, double *cinv, int64_t *cts) {
@@ -168,7 +177,7 @@ __global__ void hgt_contrib_gen_kernel(HgtType dst, HgtType src, const int64_t *
     }
 }
 // existing entry -> its index; new key -> remember the smallest contribution position
-__global__ void hgt_contrib_slots_kernel(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
+__device__ __forceinline__ void hgt_contrib_slots_body(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
                                          int64_t *cslot, int64_t *tmp_keys, int64_t *tmp_vals, int64_t tmp_mask) {
     const int64_t n = *mc;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
@@ -190,7 +199,7 @@ __global__ void hgt_contrib_slots_kernel(HgtType src, const int64_t *mc, const i
 // flags "p is the first contribution of a new key", kept per 64-position chunk: cmask[c] = the chunk's flags as a bit
 // mask, flag[c] = their number.  A scan over the few hundred chunk counts (one launch of one workgroup) then ranks any
 // position: rank(q) = prefix[q / 64] + popcount(cmask[q / 64] below bit q % 64).
-__global__ void hgt_first_flags_kernel(const int64_t *mc, const int64_t *__restrict__ ckey,
+__device__ __forceinline__ void hgt_first_flags_body(const int64_t *mc, const int64_t *__restrict__ ckey,
                                        const int64_t *__restrict__ cslot, const int64_t *tmp_keys,
                                        const int64_t *tmp_vals, int64_t tmp_mask, int64_t cap, int64_t *flag,
                                        uint64_t *cmask) {
@@ -218,7 +227,7 @@ __device__ __forceinline__ int64_t hgt_chunk_rank(const int64_t *__restrict__ ch
     return chunk_prefix[q >> 6] + __popcll(below);
 }
 // new keys get entries n_budget + rank(first contribution); the entry order is the reference's insertion order
-__global__ void hgt_new_slots_kernel(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
+__device__ __forceinline__ void hgt_new_slots_body(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
                                      int64_t *cslot, const int64_t *tmp_keys, const int64_t *tmp_vals,
                                      int64_t tmp_mask, const int64_t *__restrict__ rank, const uint64_t *__restrict__ cmask) {
     const int64_t n = *mc, nb = src.ctr->n_budget;
@@ -243,28 +252,28 @@ __global__ void hgt_new_slots_kernel(HgtType src, const int64_t *mc, const int64
 // sort keys = budget slots; padding sorts last with key `pad` = the budget's capacity, one above every slot, so the sort
 // only has to look at the bits of `pad`.  Also the budget grows by the entries hgt_new_slots_kernel just placed (that
 // kernel, the only reader of the old length in this step, has completed).
-__global__ void hgt_sort_input_kernel(const int64_t *mc, const int64_t *__restrict__ cslot, int64_t cap, int64_t pad,
-                                      int64_t *skey, int64_t *sval, HgtTypeCtr *ctr, const int64_t *n_new) {
+__device__ __forceinline__ void hgt_sort_input_body(const int64_t *mc, const int64_t *__restrict__ cslot, int64_t cap, int64_t pad,
+                                      int64_t prefix, int64_t *skey, int64_t *sval, HgtTypeCtr *ctr, const int64_t *n_new) {
     const int64_t n = *mc;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_budget += *n_new;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
-        skey[p] = (p < n && cslot[p] >= 0) ? cslot[p] : pad;
+        skey[p] = prefix | ((p < n && cslot[p] >= 0) ? cslot[p] : pad);
         sval[p] = p;
     }
 }
 // one lane per entry run: score += 1/deg in contribution order (:96), timestamp = the last one (:97)
-__global__ void hgt_accumulate_kernel(HgtType src, const int64_t *__restrict__ skey, const int64_t *__restrict__ sval,
-                                      int64_t cap, int64_t pad, const double *__restrict__ cinv,
+__device__ __forceinline__ void hgt_accumulate_body(HgtType src, const int64_t *__restrict__ skey, const int64_t *__restrict__ sval,
+                                      int64_t cap, int64_t pad, int64_t prefix, const double *__restrict__ cinv,
                                       const int64_t *__restrict__ cts) {
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < cap; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t entry = skey[q];
+        const int64_t key = skey[q], entry = key ^ prefix; // the step's slice holds keys of its prefix only
         if (entry == pad) continue;
-        if (q > 0 && skey[q - 1] == entry) continue; // not the head of its run
+        if (q > 0 && skey[q - 1] == key) continue; // not the head of its run
         double score = src.bscore[entry];
         int64_t lo = q, hi = cap; // the run is [q, end): keys are sorted, so its end is found by bisection
         while (hi - lo > 1) {
             const int64_t mid = (lo + hi) >> 1;
-            if (skey[mid] == entry)
+            if (skey[mid] == key)
                 lo = mid;
             else
                 hi = mid;
@@ -282,6 +291,68 @@ __global__ void hgt_accumulate_kernel(HgtType src, const int64_t *__restrict__ s
         src.bscore[entry] = score;
         src.bts[entry] = cts[sval[end - 1]];
     }
+}
+
+// ---------------------------------------------------------------- update_budget steps side by side (gridDim.y = steps)
+// A call is a chain of ~200 launches of a few microseconds each: bound by the LENGTH of the chain, not by work.  Steps of
+// update_budget that feed DIFFERENT source types' budgets are independent (a step reads its destination type's layer and
+// writes its source type's budget), so up to HGT_MAX_PAR of them run as ONE launch per phase, blockIdx.y = step, each on
+// scratch of its own; steps that feed the same budget stay in their canonical order (later rounds).  cfg4's eight steps
+// take three rounds.  (The same over six HIP streams cost more in fork / join events than it won: DESIGN.md 4.6.)
+constexpr int HGT_MAX_PAR = 4;
+struct HgtStep {
+    HgtType dst, src;
+    HgtTypeCtr *src_ctr;
+    const int64_t *ptrs, *indices, *edge_ts;
+    int64_t pad; // sort key of padding: the source budget's capacity
+    int64_t *ccnt, *coff, *ckey, *cts, *cslot, *skey, *sval, *skey2, *sval2, *tmp_keys, *tmp_vals, *flag, *rank, *scal;
+    double *cinv;
+    uint64_t *cmask;
+};
+struct HgtSteps {
+    HgtStep s[HGT_MAX_PAR];
+    int bits; // a sort key = (step << bits) | budget slot (or the step's pad)
+};
+__global__ void hgt_count_steps_kernel(const HgtSteps S, int64_t cap) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_contrib_count_body(a.dst, a.src_ctr, a.ptrs, a.ccnt, cap);
+}
+__global__ void hgt_scan_i64_steps_kernel(const HgtSteps S, int64_t n) {
+    const HgtStep &a = S.s[blockIdx.y];
+    scan_i64_body(a.ccnt, nullptr, n, a.coff, a.scal + 0);
+}
+__global__ void hgt_gen_steps_kernel(const HgtSteps S, int has_timerange, int64_t tr_lo, int64_t tr_hi, int64_t cap) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_contrib_gen_body(a.dst, a.src, a.ptrs, a.indices, a.edge_ts, has_timerange, tr_lo, tr_hi, a.ccnt, a.coff, cap, a.ckey,
+                         a.cinv, a.cts);
+}
+__global__ void hgt_fill_tmp_steps_kernel(const HgtSteps S, int64_t tmp_cap) {
+    const HgtStep &a = S.s[blockIdx.y];
+    fill2_i64_body(a.tmp_keys, tmp_cap, MAP_EMPTY, a.tmp_vals, tmp_cap, (int64_t)INT64_MAX);
+}
+__global__ void hgt_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_contrib_slots_body(a.src, a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask);
+}
+__global__ void hgt_first_flags_steps_kernel(const HgtSteps S, int64_t tmp_mask, int64_t cap) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_first_flags_body(a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask, cap, a.flag, a.cmask);
+}
+__global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_steps_kernel(const HgtSteps S, int64_t n) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_scan1_body(a.flag, n, a.rank, a.scal + 1);
+}
+__global__ void hgt_new_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_new_slots_body(a.src, a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask, a.rank, a.cmask);
+}
+__global__ void hgt_sort_input_steps_kernel(const HgtSteps S, int64_t cap) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_sort_input_body(a.scal + 0, a.cslot, cap, a.pad, (int64_t)blockIdx.y << S.bits, a.skey, a.sval, a.src_ctr, a.scal + 1);
+}
+__global__ void hgt_accumulate_steps_kernel(const HgtSteps S, int64_t cap) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_accumulate_body(a.src, a.skey2, a.sval2, cap, a.pad, (int64_t)blockIdx.y << S.bits, a.cinv, a.cts);
 }
 
 // ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
@@ -578,7 +649,7 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     pl.scan_cap = std::max(std::max(pl.mc_cap, pl.max_budget), pl.edge_cap);
     size_t st = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, st, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr,
-                                             (int64_t *)nullptr, (size_t)pl.mc_cap, 0, 64, (hipStream_t)0, false);
+                                             (int64_t *)nullptr, (size_t)pl.mc_cap * HGT_MAX_PAR, 0, 64, (hipStream_t)0, false);
     if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
     pl.sort_temp_bytes = st;
     size_t sc = 0;
@@ -593,9 +664,16 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
         b += align16(8 * (size_t)pl.cap_budget[t]) * 4;
         b += align16(8 * (size_t)pl.bm_cap[t]) * 2;
     }
-    b += align16(8 * (size_t)pl.max_layer) * 2;  // ccnt, coff
-    b += align16(8 * (size_t)pl.mc_cap) * 8;     // ckey, cinv, cts, cslot, skey, sval, skey2, sval2
-    b += align16(8 * (size_t)pl.tmp_cap) * 2;    // tmp map
+    { // scratch of one update_budget step, HGT_MAX_PAR of them side by side
+        size_t step = 0;
+        step += align16(8 * (size_t)pl.max_layer) * 2; // ccnt, coff
+        step += align16(8 * (size_t)pl.mc_cap) * 4;    // ckey, cinv, cts, cslot
+        step += align16(8 * (size_t)pl.tmp_cap) * 2;   // tmp map
+        step += align16(8 * (size_t)(pl.mc_cap / 64 + 3)) * 3; // chunk counts, their prefix, chunk masks
+        step += align16(8 * 8);                        // scalars
+        b += step * HGT_MAX_PAR;
+    }
+    b += align16(8 * (size_t)pl.mc_cap * HGT_MAX_PAR) * 4; // skey, sval, skey2, sval2 of all steps of a round, step-major
     b += align16(8 * (size_t)(pl.scan_cap + 1)) * 2; // flag, rank
     b += align16(8 * (size_t)(pl.scan_cap / 64 + 2)); // chunk masks
     for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
@@ -670,18 +748,29 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.bm_cap[t])), dim3(256), 0, stream, y.bm_keys, pl.bm_cap[t],
                            MAP_EMPTY);
     }
-    int64_t *ccnt = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
-    int64_t *coff = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
-    int64_t *ckey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    double *cinv = reinterpret_cast<double *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *cts = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *cslot = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *skey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *sval = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *skey2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *sval2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-    int64_t *tmp_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
-    int64_t *tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
+    struct StepScratch {
+        int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal;
+        double *cinv;
+        uint64_t *cmask;
+    } sc[HGT_MAX_PAR];
+    for (int y = 0; y < HGT_MAX_PAR; ++y) {
+        sc[y].ccnt = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
+        sc[y].coff = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
+        sc[y].ckey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+        sc[y].cinv = reinterpret_cast<double *>(take(8 * (size_t)pl.mc_cap));
+        sc[y].cts = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+        sc[y].cslot = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
+        sc[y].tmp_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
+        sc[y].tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
+        sc[y].flag = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.mc_cap / 64 + 3)));
+        sc[y].rank = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.mc_cap / 64 + 3)));
+        sc[y].cmask = reinterpret_cast<uint64_t *>(take(8 * (size_t)(pl.mc_cap / 64 + 3)));
+        sc[y].scal = reinterpret_cast<int64_t *>(take(8 * 8)); // [0] contributions [1] new entries
+    }
+    int64_t *skey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR)); // step-major slices
+    int64_t *sval = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR));
+    int64_t *skey2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR));
+    int64_t *sval2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR));
     int64_t *flag = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
     int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.scan_cap + 1)));
     uint64_t *cmask = reinterpret_cast<uint64_t *>(take(8 * (size_t)(pl.scan_cap / 64 + 2)));
@@ -711,38 +800,76 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         return TG_OK;
     };
 
-    // ---- update_budget for the current layer of node type nt (:27-102)
-    auto update_budget = [&](int nt) -> int {
-        for (int r = 0; r < R; ++r) { // :47 canonical relation order
-            if (pb->rel_dst[r] != nt) continue;
-            const int st = pb->rel_src[r];
-            const tg_graph &g = pb->graphs[r];
-            hipLaunchKernelGGL(hgt_contrib_count_kernel, dim3(grid_1d(pl.max_layer)), dim3(256), 0, stream, ty[nt],
-                               ctr + st, g.ptrs, ccnt, pl.max_layer);
-            hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(1024), 0, stream, ccnt, (const int64_t *)nullptr,
-                               pl.max_layer, coff, scal + 0);
-            hipLaunchKernelGGL(hgt_contrib_gen_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[nt], ty[st],
-                               g.ptrs, g.indices, g.timestamps, pb->has_timerange, pb->tr_lo, pb->tr_hi, ccnt, coff,
-                               pl.max_layer, ckey, cinv, cts);
-            hipLaunchKernelGGL(fill2_i64_kernel, dim3(grid_1d(pl.tmp_cap)), dim3(256), 0, stream, tmp_keys, pl.tmp_cap,
-                               MAP_EMPTY, tmp_vals, pl.tmp_cap, (int64_t)INT64_MAX);
-            hipLaunchKernelGGL(hgt_contrib_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st],
-                               scal + 0, ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1);
-            hipLaunchKernelGGL(hgt_first_flags_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, ckey,
-                               cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, pl.mc_cap, flag, cmask);
-            if (int rcs = device_scan((pl.mc_cap + 63) / 64, scal + 1)) return rcs; // over the chunks' counts
-            hipLaunchKernelGGL(hgt_new_slots_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], scal + 0,
-                               ckey, cslot, tmp_keys, tmp_vals, pl.tmp_cap - 1, rank, cmask);
-            const int64_t pad = pl.cap_budget[st]; // one above every budget slot
-            unsigned bits = 1;
-            while (bits < 64 && ((int64_t)1 << bits) <= pad) ++bits;
-            hipLaunchKernelGGL(hgt_sort_input_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, scal + 0, cslot,
-                               pl.mc_cap, pad, skey, sval, ctr + st, scal + 1);
-            size_t stb = pl.sort_temp_bytes;
-            TG_HIP(rocprim::radix_sort_pairs(sort_temp, stb, skey, skey2, sval, sval2, (size_t)pl.mc_cap, 0, bits, stream,
-                                             false)); // stable: equal entries keep contribution order
-            hipLaunchKernelGGL(hgt_accumulate_kernel, dim3(grid_1d(pl.mc_cap)), dim3(256), 0, stream, ty[st], skey2,
-                               sval2, pl.mc_cap, pad, cinv, cts);
+    // ---- update_budget (:27-102) for the layers of the node types `which`, in order (:47 relations in canonical order).
+    // A step = (node type nt, relation r into nt); steps are dealt to ROUNDS: a step goes to the round after the last
+    // step that fed the same source type's budget (their order must hold), else to the first round with a free place;
+    // the steps of a round run as one launch per phase (blockIdx.y = step).
+    auto update_budgets = [&](const std::vector<int> &which) -> int {
+        std::vector<std::vector<std::pair<int, int>>> rounds;
+        std::vector<int> last_round((size_t)T, -1);
+        for (int nt : which)
+            for (int r = 0; r < R; ++r) {
+                if (pb->rel_dst[r] != nt) continue;
+                size_t rd = (size_t)(last_round[(size_t)pb->rel_src[r]] + 1);
+                while (rd < rounds.size() && rounds[rd].size() >= (size_t)HGT_MAX_PAR) ++rd;
+                if (rd >= rounds.size()) rounds.resize(rd + 1);
+                rounds[rd].push_back({nt, r});
+                last_round[(size_t)pb->rel_src[r]] = (int)rd;
+            }
+        const int64_t n_chunks = (pl.mc_cap + 63) / 64;
+        for (const auto &round : rounds) {
+            const unsigned Y = (unsigned)round.size();
+            if (Y == 0) continue;
+            HgtSteps S;
+            std::memset(&S, 0, sizeof(S));
+            unsigned bits = 1; // of the largest pad key of the round
+            for (unsigned y = 0; y < Y; ++y) {
+                const int nt = round[y].first, r = round[y].second, st = pb->rel_src[r];
+                const tg_graph &g = pb->graphs[r];
+                HgtStep &a = S.s[y];
+                a.dst = ty[nt];
+                a.src = ty[st];
+                a.src_ctr = ctr + st;
+                a.ptrs = g.ptrs;
+                a.indices = g.indices;
+                a.edge_ts = g.timestamps;
+                a.pad = pl.cap_budget[st]; // one above every budget slot
+                while (bits < 64 && ((int64_t)1 << bits) <= a.pad) ++bits;
+                a.ccnt = sc[y].ccnt, a.coff = sc[y].coff, a.ckey = sc[y].ckey, a.cts = sc[y].cts, a.cslot = sc[y].cslot;
+                a.tmp_keys = sc[y].tmp_keys, a.tmp_vals = sc[y].tmp_vals, a.flag = sc[y].flag, a.rank = sc[y].rank;
+                a.scal = sc[y].scal, a.cinv = sc[y].cinv, a.cmask = sc[y].cmask;
+                a.skey = skey + (size_t)y * pl.mc_cap, a.sval = sval + (size_t)y * pl.mc_cap;
+                a.skey2 = skey2 + (size_t)y * pl.mc_cap, a.sval2 = sval2 + (size_t)y * pl.mc_cap;
+            }
+            S.bits = (int)bits;
+            auto g2 = [&](int64_t n) { return dim3(grid_1d(n), Y); };
+            hipLaunchKernelGGL(hgt_count_steps_kernel, g2(pl.max_layer), dim3(256), 0, stream, S, pl.max_layer);
+            hipLaunchKernelGGL(hgt_scan_i64_steps_kernel, dim3(1, Y), dim3(1024), 0, stream, S, pl.max_layer);
+            hipLaunchKernelGGL(hgt_gen_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pb->has_timerange, pb->tr_lo,
+                               pb->tr_hi, pl.max_layer);
+            hipLaunchKernelGGL(hgt_fill_tmp_steps_kernel, g2(pl.tmp_cap), dim3(256), 0, stream, S, pl.tmp_cap);
+            hipLaunchKernelGGL(hgt_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1);
+            hipLaunchKernelGGL(hgt_first_flags_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1, pl.mc_cap);
+            if (n_chunks <= 16384) { // the chunks' counts: one workgroup per step
+                hipLaunchKernelGGL(hgt_scan1_steps_kernel, dim3(1, Y), dim3(SCAN1_THREADS), 0, stream, S, n_chunks);
+            } else {
+                for (unsigned y = 0; y < Y; ++y) {
+                    size_t stb = pl.scan_temp_bytes;
+                    TG_HIP(rocprim::exclusive_scan(scan_temp, stb, S.s[y].flag, S.s[y].rank, (int64_t)0, (size_t)n_chunks,
+                                                   rocprim::plus<int64_t>(), stream, false));
+                    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, S.s[y].flag, S.s[y].rank, n_chunks,
+                                       S.s[y].scal + 1);
+                }
+            }
+            hipLaunchKernelGGL(hgt_new_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1);
+            hipLaunchKernelGGL(hgt_sort_input_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.mc_cap);
+            { // ONE stable sort for the round (equal entries keep contribution order): a key carries its step above its
+              // `bits` entry bits, and every step brings exactly mc_cap keys, so step y's keys come out in slice y
+                size_t stb = pl.sort_temp_bytes;
+                TG_HIP(rocprim::radix_sort_pairs(sort_temp, stb, skey, skey2, sval, sval2, (size_t)pl.mc_cap * Y, 0, bits + 2,
+                                                 stream, false));
+            }
+            hipLaunchKernelGGL(hgt_accumulate_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.mc_cap);
             TG_LAUNCH_CHECK();
         }
         return TG_OK;
@@ -758,11 +885,13 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         }
     }
     TG_LAUNCH_CHECK();
-    for (int t = 0; t < T; ++t)
-        if (pb->n_inputs[t] >= 0) {
-            rc = update_budget(t);
-            if (rc != TG_OK) return rc;
-        }
+    {
+        std::vector<int> which;
+        for (int t = 0; t < T; ++t)
+            if (pb->n_inputs[t] >= 0) which.push_back(t);
+        rc = update_budgets(which);
+        if (rc != TG_OK) return rc;
+    }
     // ---- :198-242 layers
     for (int layer = 0; layer < H; ++layer) {
         size_t lds_max = 8;
@@ -803,11 +932,12 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             hipLaunchKernelGGL(hgt_append_kernel, dim3(1), dim3(256), 0, stream, ty[t], live_t[(size_t)t],
                                chosen_t[(size_t)t], n_chosen_t + t);
         TG_LAUNCH_CHECK();
-        if (layer < H - 1)
-            for (int t = 0; t < T; ++t) { // :227 (types without samples return at :38-40)
-                rc = update_budget(t);
-                if (rc != TG_OK) return rc;
-            }
+        if (layer < H - 1) { // :227 (types without samples return at :38-40)
+            std::vector<int> which;
+            for (int t = 0; t < T; ++t) which.push_back(t);
+            rc = update_budgets(which);
+            if (rc != TG_OK) return rc;
+        }
     }
     // ---- :244-268 edges among the sampled nodes
     for (int r = 0; r < R; ++r) {
