@@ -136,19 +136,28 @@ __global__ void hgt_init_inputs_kernel(HgtType ty, const int64_t *__restrict__ i
 }
 
 // ---------------------------------------------------------------- update_budget (hgt_sampling.rs:27-102)
-// per sample of the layer: number of contributions = min(deg, 50); also marks the source budget present
-__device__ __forceinline__ void hgt_contrib_count_body(HgtType dst, HgtTypeCtr *src_ctr, const int64_t *__restrict__ ptrs,
-                                         int64_t *ccnt, int64_t cap) {
+// per sample of the layer: number of contributions = min(deg, 50), and their exclusive prefix in the same launch (one
+// workgroup: a layer is a few thousand samples); also marks the source budget present
+__device__ __forceinline__ void hgt_contrib_count_scan_body(HgtType dst, HgtTypeCtr *src_ctr, const int64_t *__restrict__ ptrs,
+                                                            int64_t *ccnt, int64_t *coff, int64_t cap, int64_t *total) {
     const int64_t b = dst.ctr->lay_begin, e = dst.ctr->lay_end;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cap; j += (int64_t)gridDim.x * blockDim.x) {
-        int64_t c = 0;
-        if (b + j < e) {
-            const int64_t w = dst.nodes[b + j];
-            c = min(ptrs[w + 1] - ptrs[w], (int64_t)HGT_MAX_NB);
-        }
-        ccnt[j] = c;
+    block_scan_exclusive_plus1(
+        cap,
+        [&](int64_t j) {
+            int64_t c = 0;
+            if (b + j < e) {
+                const int64_t w = dst.nodes[b + j];
+                c = min(ptrs[w + 1] - ptrs[w], (int64_t)HGT_MAX_NB);
+            }
+            ccnt[j] = c;
+            return c;
+        },
+        coff);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        total[0] = coff[cap];
+        if (e > b) src_ctr->present = 1; // :38-40, :55
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && e > b) src_ctr->present = 1; // :38-40, :55
 }
 // one lane per (sample j, neighbour i): key or -1, 1/count, timestamp  (:58-100)
 __device__ __forceinline__ void hgt_contrib_gen_body(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
@@ -226,45 +235,45 @@ __device__ __forceinline__ int64_t hgt_chunk_rank(const int64_t *__restrict__ ch
     const uint64_t below = (q & 63) ? (cmask[q >> 6] & (~0ull >> (64 - (q & 63)))) : 0ull;
     return chunk_prefix[q >> 6] + __popcll(below);
 }
-// new keys get entries n_budget + rank(first contribution); the entry order is the reference's insertion order
+// new keys get entries n_budget + rank(first contribution); the entry order is the reference's insertion order.  The
+// same lane then writes the round's sort input: key = (step prefix | entry, or the pad key for dropped / absent
+// contributions), value = position.  Keys only need the bits of `pad` (+ the step's): budget entries are small numbers.
 __device__ __forceinline__ void hgt_new_slots_body(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
-                                     int64_t *cslot, const int64_t *tmp_keys, const int64_t *tmp_vals,
-                                     int64_t tmp_mask, const int64_t *__restrict__ rank, const uint64_t *__restrict__ cmask) {
+                                                   int64_t *cslot, const int64_t *tmp_keys, const int64_t *tmp_vals,
+                                                   int64_t tmp_mask, const int64_t *__restrict__ rank,
+                                                   const uint64_t *__restrict__ cmask, int64_t cap, int64_t pad, int64_t prefix,
+                                                   int64_t *skey, int64_t *sval) {
     const int64_t n = *mc, nb = src.ctr->n_budget;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        if (cslot[p] != -1) continue;
-        const int64_t v = ckey[p];
-        const int64_t t = map_slot_find(tmp_keys, tmp_mask, v);
-        const int64_t first = tmp_vals[t];
-        const int64_t entry = nb + hgt_chunk_rank(rank, cmask, first);
-        cslot[p] = entry;
-        if (first == p) { // :95 entry(v).or_default()
-            src.bkey[entry] = v;
-            src.bscore[entry] = 0.0;
-            src.bts[entry] = 0;
-            src.balive[entry] = 1;
-            const int64_t s = map_slot_insert(src.bm_keys, src.bm_mask, v);
-            src.bm_vals[s] = entry;
-        }
-    }
-}
-// sort input: key = entry (padding sorts last), value = contribution position
-// sort keys = budget slots; padding sorts last with key `pad` = the budget's capacity, one above every slot, so the sort
-// only has to look at the bits of `pad`.  Also the budget grows by the entries hgt_new_slots_kernel just placed (that
-// kernel, the only reader of the old length in this step, has completed).
-__device__ __forceinline__ void hgt_sort_input_body(const int64_t *mc, const int64_t *__restrict__ cslot, int64_t cap, int64_t pad,
-                                      int64_t prefix, int64_t *skey, int64_t *sval, HgtTypeCtr *ctr, const int64_t *n_new) {
-    const int64_t n = *mc;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_budget += *n_new;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
-        skey[p] = prefix | ((p < n && cslot[p] >= 0) ? cslot[p] : pad);
+        int64_t entry = -2;
+        if (p < n) {
+            entry = cslot[p];
+            if (entry == -1) {
+                const int64_t v = ckey[p];
+                const int64_t t = map_slot_find(tmp_keys, tmp_mask, v);
+                const int64_t first = tmp_vals[t];
+                entry = nb + hgt_chunk_rank(rank, cmask, first);
+                cslot[p] = entry;
+                if (first == p) { // :95 entry(v).or_default()
+                    src.bkey[entry] = v;
+                    src.bscore[entry] = 0.0;
+                    src.bts[entry] = 0;
+                    src.balive[entry] = 1;
+                    const int64_t s = map_slot_insert(src.bm_keys, src.bm_mask, v);
+                    src.bm_vals[s] = entry;
+                }
+            }
+        }
+        skey[p] = prefix | (entry >= 0 ? entry : pad);
         sval[p] = p;
     }
 }
 // one lane per entry run: score += 1/deg in contribution order (:96), timestamp = the last one (:97)
 __device__ __forceinline__ void hgt_accumulate_body(HgtType src, const int64_t *__restrict__ skey, const int64_t *__restrict__ sval,
                                       int64_t cap, int64_t pad, int64_t prefix, const double *__restrict__ cinv,
-                                      const int64_t *__restrict__ cts) {
+                                      const int64_t *__restrict__ cts, const int64_t *n_new) {
+    // the budget grows by the entries hgt_new_slots_body placed (nothing reads the counter between the two launches)
+    if (blockIdx.x == 0 && threadIdx.x == 0) src.ctr->n_budget += *n_new;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < cap; q += (int64_t)gridDim.x * blockDim.x) {
         const int64_t key = skey[q], entry = key ^ prefix; // the step's slice holds keys of its prefix only
         if (entry == pad) continue;
@@ -294,7 +303,7 @@ __device__ __forceinline__ void hgt_accumulate_body(HgtType src, const int64_t *
 }
 
 // ---------------------------------------------------------------- update_budget steps side by side (gridDim.y = steps)
-// A call is a chain of ~200 launches of a few microseconds each: bound by the LENGTH of the chain, not by work.  Steps of
+// A call is a chain of launches of a few microseconds each: bound by the LENGTH of the chain, not by work.  Steps of
 // update_budget that feed DIFFERENT source types' budgets are independent (a step reads its destination type's layer and
 // writes its source type's budget), so up to HGT_MAX_PAR of them run as ONE launch per phase, blockIdx.y = step, each on
 // scratch of its own; steps that feed the same budget stay in their canonical order (later rounds).  cfg4's eight steps
@@ -313,22 +322,17 @@ struct HgtSteps {
     HgtStep s[HGT_MAX_PAR];
     int bits; // a sort key = (step << bits) | budget slot (or the step's pad)
 };
-__global__ void hgt_count_steps_kernel(const HgtSteps S, int64_t cap) {
+__global__ void __launch_bounds__(SCAN1_THREADS) hgt_count_scan_steps_kernel(const HgtSteps S, int64_t cap) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_contrib_count_body(a.dst, a.src_ctr, a.ptrs, a.ccnt, cap);
+    hgt_contrib_count_scan_body(a.dst, a.src_ctr, a.ptrs, a.ccnt, a.coff, cap, a.scal + 0);
 }
-__global__ void hgt_scan_i64_steps_kernel(const HgtSteps S, int64_t n) {
-    const HgtStep &a = S.s[blockIdx.y];
-    scan_i64_body(a.ccnt, nullptr, n, a.coff, a.scal + 0);
-}
-__global__ void hgt_gen_steps_kernel(const HgtSteps S, int has_timerange, int64_t tr_lo, int64_t tr_hi, int64_t cap) {
-    const HgtStep &a = S.s[blockIdx.y];
-    hgt_contrib_gen_body(a.dst, a.src, a.ptrs, a.indices, a.edge_ts, has_timerange, tr_lo, tr_hi, a.ccnt, a.coff, cap, a.ckey,
-                         a.cinv, a.cts);
-}
-__global__ void hgt_fill_tmp_steps_kernel(const HgtSteps S, int64_t tmp_cap) {
+// contributions, and the empty min-position map of the step's new keys
+__global__ void hgt_gen_steps_kernel(const HgtSteps S, int has_timerange, int64_t tr_lo, int64_t tr_hi, int64_t cap,
+                                     int64_t tmp_cap) {
     const HgtStep &a = S.s[blockIdx.y];
     fill2_i64_body(a.tmp_keys, tmp_cap, MAP_EMPTY, a.tmp_vals, tmp_cap, (int64_t)INT64_MAX);
+    hgt_contrib_gen_body(a.dst, a.src, a.ptrs, a.indices, a.edge_ts, has_timerange, tr_lo, tr_hi, a.ccnt, a.coff, cap, a.ckey,
+                         a.cinv, a.cts);
 }
 __global__ void hgt_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask) {
     const HgtStep &a = S.s[blockIdx.y];
@@ -342,39 +346,66 @@ __global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_steps_kernel(const Hg
     const HgtStep &a = S.s[blockIdx.y];
     hgt_scan1_body(a.flag, n, a.rank, a.scal + 1);
 }
-__global__ void hgt_new_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask) {
+__global__ void hgt_new_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask, int64_t cap) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_new_slots_body(a.src, a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask, a.rank, a.cmask);
-}
-__global__ void hgt_sort_input_steps_kernel(const HgtSteps S, int64_t cap) {
-    const HgtStep &a = S.s[blockIdx.y];
-    hgt_sort_input_body(a.scal + 0, a.cslot, cap, a.pad, (int64_t)blockIdx.y << S.bits, a.skey, a.sval, a.src_ctr, a.scal + 1);
+    hgt_new_slots_body(a.src, a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask, a.rank, a.cmask, cap, a.pad,
+                       (int64_t)blockIdx.y << S.bits, a.skey, a.sval);
 }
 __global__ void hgt_accumulate_steps_kernel(const HgtSteps S, int64_t cap) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_accumulate_body(a.src, a.skey2, a.sval2, cap, a.pad, (int64_t)blockIdx.y << S.bits, a.cinv, a.cts);
+    hgt_accumulate_body(a.src, a.skey2, a.sval2, cap, a.pad, (int64_t)blockIdx.y << S.bits, a.cinv, a.cts, a.scal + 1);
 }
+// rocPRIM sorts fewer than a million pairs by block sort + log2(n / 1024) merge passes (9 launches, ~60 us for a round
+// here); forcing its onesweep radix sort (merge_sort_limit below n) takes 5 kernels + 7 memsets and ~100 us: measured,
+// not used
+using HgtSortConfig = rocprim::default_config;
 
 // ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
-__global__ void hgt_live_flags_kernel(HgtType ty, int64_t cap, int64_t *flag, uint64_t *cmask) { // per chunk, as above
+// The node types of a layer sample from their own budgets independently (:201-221): ONE launch per layer, one workgroup
+// per type, which (1) compacts the type's live budget entries in entry order -- per 64-entry chunk a bit mask and a
+// count, a scan over the counts, then every live entry's rank -- (2) runs the weighted reservoir below and (3) moves
+// the chosen entries to the node list.  The phases hand their arrays over through global memory inside the workgroup.
+__device__ __forceinline__ void hgt_wg_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void hgt_live_list_body(const HgtType &ty, int64_t *flag, int64_t *rank, uint64_t *cmask,
+                                                   int64_t *__restrict__ live, int64_t *n_live) {
     const int64_t n = ty.ctr->n_budget;
-    const int lane = threadIdx.x & 63;
-    const int64_t n_chunks = (cap + 63) >> 6;
-    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks;
-         c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
-        const int64_t i = (c << 6) + lane;
-        const uint64_t m = __ballot(i < n && ty.balive[i] != 0);
-        if (lane == 0) {
-            cmask[c] = m;
-            flag[c] = __popcll(m);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int64_t n_chunks = (n + 63) >> 6;
+    constexpr int U = 8; // chunks in flight per wavefront
+    for (int64_t c0 = (int64_t)wave * U; c0 < n_chunks; c0 += (int64_t)n_waves * U) {
+        int64_t alive[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = ((c0 + u) << 6) + lane;
+            alive[u] = (i < n) ? ty.balive[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t m = __ballot(alive[u] != 0);
+            if (lane == 0 && c0 + u < n_chunks) {
+                cmask[c0 + u] = m;
+                flag[c0 + u] = __popcll(m);
+            }
         }
     }
-}
-__global__ void hgt_live_list_kernel(HgtType ty, const uint64_t *__restrict__ cmask, const int64_t *__restrict__ rank,
-                                     int64_t *live) {
-    const int64_t n = ty.ctr->n_budget;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        if ((cmask[i >> 6] >> (i & 63)) & 1ull) live[hgt_chunk_rank(rank, cmask, i)] = i;
+    hgt_wg_handoff();
+    block_scan_exclusive_plus1(n_chunks, [&](int64_t c) { return flag[c]; }, rank);
+    hgt_wg_handoff();
+    if (tid == 0) *n_live = rank[n_chunks];
+    for (int64_t i0 = (int64_t)tid * 4; i0 < n; i0 += (int64_t)blockDim.x * 4) { // one chunk mask covers a lane's 4 entries
+        const uint64_t m = cmask[i0 >> 6];
+        const int64_t r0 = rank[i0 >> 6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = (int)((i0 + u) & 63);
+            if ((m >> q) & 1ull) live[r0 + __popcll(q ? (m & (~0ull >> (64 - q))) : 0ull)] = i0 + u;
+        }
+    }
+    hgt_wg_handoff();
 }
 constexpr int64_t HGT_LDS_SLOTS = 8192; // samples per layer whose slot tables fit 64 KB of LDS
 // The reference's weighted reservoir over the live entries, weights score^2 (:104-135), by ONE WORKGROUP.  With
@@ -465,35 +496,9 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
     }
     if (tid == 0) *n_chosen = cnt;
 }
-__global__ void hgt_weighted_reservoir_kernel(HgtType ty, const int64_t *n_live_ptr, const int64_t *__restrict__ live,
-                                              int64_t k, uint64_t seed, uint64_t call_id, uint64_t draw_id,
-                                              int64_t *chosen, int64_t *n_chosen, int *panic, uint32_t *slots_global,
-                                              double *carries) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    hgt_reservoir_body(ty, n_live_ptr, live, k, seed, call_id, draw_id, chosen, n_chosen, panic, smem, carries, slots_global);
-}
-// The node types of a layer sample from their own budgets independently (:201-221): one workgroup per type, side by side.
-constexpr int HGT_MULTI_TYPES = 8;
-struct HgtMultiArgs {
-    HgtType ty[HGT_MULTI_TYPES];
-    const int64_t *n_live[HGT_MULTI_TYPES];
-    const int64_t *live[HGT_MULTI_TYPES];
-    int64_t *chosen[HGT_MULTI_TYPES];
-    int64_t *n_chosen[HGT_MULTI_TYPES];
-    int64_t k[HGT_MULTI_TYPES];
-    uint32_t *slots[HGT_MULTI_TYPES];
-    double *carries[HGT_MULTI_TYPES];
-};
-__global__ void hgt_weighted_reservoir_multi_kernel(const HgtMultiArgs a, uint64_t seed, uint64_t call_id, int64_t layer,
-                                                    int n_types, int *panic) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int t = blockIdx.x;
-    hgt_reservoir_body(a.ty[t], a.n_live[t], a.live[t], a.k[t], seed, call_id, (uint64_t)(layer * n_types + t), a.chosen[t],
-                       a.n_chosen[t], panic, smem, a.carries[t], a.slots[t]);
-}
 // :213-221 move the samples to the node list, give them local ids, erase them from the budget
-__global__ void hgt_append_kernel(HgtType ty, const int64_t *__restrict__ live, const int64_t *__restrict__ chosen,
-                                  const int64_t *n_chosen) {
+__device__ __forceinline__ void hgt_append_body(const HgtType &ty, const int64_t *__restrict__ live,
+                                                const int64_t *__restrict__ chosen, const int64_t *n_chosen) {
     const int64_t cnt = *n_chosen, base = ty.ctr->n_nodes;
     for (int64_t s = threadIdx.x; s < cnt; s += blockDim.x) {
         const int64_t entry = live[chosen[s]];
@@ -511,19 +516,53 @@ __global__ void hgt_append_kernel(HgtType ty, const int64_t *__restrict__ live, 
         ty.ctr->n_nodes = base + cnt;
     }
 }
-__global__ void hgt_empty_layer_kernel(HgtTypeCtr *ctr) { // a type without a budget contributes no samples
-    ctr->lay_begin = ctr->n_nodes;
-    ctr->lay_end = ctr->n_nodes;
+constexpr int HGT_MULTI_TYPES = 8; // node types per launch (more types: more launches)
+struct HgtSampleArgs {
+    HgtType ty[HGT_MULTI_TYPES];
+    int64_t *n_live[HGT_MULTI_TYPES], *live[HGT_MULTI_TYPES], *chosen[HGT_MULTI_TYPES], *n_chosen[HGT_MULTI_TYPES];
+    int64_t *flag[HGT_MULTI_TYPES], *rank[HGT_MULTI_TYPES];
+    uint64_t *cmask[HGT_MULTI_TYPES];
+    int64_t k[HGT_MULTI_TYPES];
+    uint32_t *slots[HGT_MULTI_TYPES];
+    double *carries[HGT_MULTI_TYPES];
+};
+__global__ void __launch_bounds__(SCAN1_THREADS)
+    hgt_sample_layer_kernel(const HgtSampleArgs a, uint64_t seed, uint64_t call_id, int64_t layer, int first_type, int n_types,
+                            int *panic) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int t = blockIdx.x;
+    hgt_live_list_body(a.ty[t], a.flag[t], a.rank[t], a.cmask[t], a.live[t], a.n_live[t]);
+    hgt_reservoir_body(a.ty[t], a.n_live[t], a.live[t], a.k[t], seed, call_id, (uint64_t)(layer * n_types + first_type + t),
+                       a.chosen[t], a.n_chosen[t], panic, smem, a.carries[t], a.slots[t]);
+    hgt_wg_handoff();
+    hgt_append_body(a.ty[t], a.live[t], a.chosen[t], a.n_chosen[t]);
+}
+// empty type tables and zeroed counters, all types of a call in one launch
+struct HgtInitArgs {
+    HgtType ty[HGT_MULTI_TYPES];
+    int64_t tl_cap[HGT_MULTI_TYPES], bm_cap[HGT_MULTI_TYPES];
+};
+__global__ void hgt_init_types_kernel(const HgtInitArgs a, int64_t *scalars, int n_scalars) {
+    const HgtType &y = a.ty[blockIdx.y];
+    fill2_i64_body(y.tl_keys, a.tl_cap[blockIdx.y], MAP_EMPTY, y.tl_vals, a.tl_cap[blockIdx.y], (int64_t)-1);
+    fill2_i64_body(y.bm_keys, a.bm_cap[blockIdx.y], MAP_EMPTY, nullptr, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        HgtTypeCtr z;
+        z.n_nodes = z.lay_begin = z.lay_end = z.n_budget = z.present = 0;
+        *y.ctr = z;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < n_scalars) scalars[threadIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------- edges (hgt_sampling.rs:244-268)
 // one WAVEFRONT per destination node; candidates at a fixed stride of 50, -1 where dropped.  Lane s owns
 // reservoir slot s: the ticket chain (k = 50 sequential bounded draws over a shrinking urn) is resolved with
 // ballots over the lanes' displaced entries, then all slots gather and look up `to_local` in parallel.
-__global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64_t *__restrict__ ptrs,
-                                           const int64_t *__restrict__ indices, int64_t cap_nodes, uint64_t seed,
-                                           uint64_t call_id, uint32_t tag, int64_t *cand_j, int64_t *cand_ep,
-                                           int64_t *kept) {
+__device__ __forceinline__ void hgt_edge_candidates_body(const HgtType &dst, const HgtType &src,
+                                                        const int64_t *__restrict__ ptrs,
+                                                        const int64_t *__restrict__ indices, int64_t cap_nodes,
+                                                        uint64_t seed, uint64_t call_id, uint32_t tag, int64_t *cand_j,
+                                                        int64_t *cand_ep, int64_t *kept) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int64_t n_nodes = dst.ctr->n_nodes;
     const CallKey ck = call_key(seed, call_id, tag);
@@ -575,9 +614,9 @@ __global__ void hgt_edge_candidates_kernel(HgtType dst, HgtType src, const int64
     }
 }
 // one wavefront per destination node: its kept candidates, in slot order, from off[i] on
-__global__ void hgt_edge_emit_kernel(const int64_t *__restrict__ cand_j, const int64_t *__restrict__ cand_ep,
-                                     const int64_t *__restrict__ off, int64_t n_nodes_cap, int64_t *rows, int64_t *cols,
-                                     int64_t *eidx) {
+__device__ __forceinline__ void hgt_edge_emit_body(const int64_t *__restrict__ cand_j, const int64_t *__restrict__ cand_ep,
+                                                   const int64_t *__restrict__ off, int64_t n_nodes_cap, int64_t *rows,
+                                                   int64_t *cols, int64_t *eidx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int64_t i = (int64_t)blockIdx.x * n_waves + wave; i < n_nodes_cap; i += (int64_t)gridDim.x * n_waves) {
@@ -592,19 +631,144 @@ __global__ void hgt_edge_emit_kernel(const int64_t *__restrict__ cand_j, const i
         }
     }
 }
-__global__ void hgt_copy_counts_kernel(const HgtTypeCtr *ctr, int n_types, int64_t *n_samples) {
-    if (threadIdx.x < n_types) n_samples[threadIdx.x] = ctr[threadIdx.x].n_nodes;
+// the relations of a call side by side (blockIdx.y = relation, HGT_EDGE_PAR per launch, scratch of its own each)
+constexpr int HGT_EDGE_PAR = 8;
+struct HgtEdgeRel {
+    HgtType dst, src;
+    const int64_t *ptrs, *indices;
+    int64_t cap_n;
+    uint32_t tag;
+    int64_t *cand_j, *cand_ep, *kept, *off, *rows, *cols, *eidx, *n_edges;
+};
+struct HgtEdgeRels {
+    HgtEdgeRel r[HGT_EDGE_PAR];
+};
+__global__ void hgt_edge_candidates_rels_kernel(const HgtEdgeRels E, uint64_t seed, uint64_t call_id) {
+    const HgtEdgeRel &a = E.r[blockIdx.y];
+    hgt_edge_candidates_body(a.dst, a.src, a.ptrs, a.indices, a.cap_n, seed, call_id, a.tag, a.cand_j, a.cand_ep, a.kept);
+}
+__global__ void __launch_bounds__(SCAN1_THREADS) hgt_edge_scan_rels_kernel(const HgtEdgeRels E) {
+    const HgtEdgeRel &a = E.r[blockIdx.y];
+    hgt_scan1_body(a.kept, a.cap_n, a.off, a.n_edges);
+}
+__global__ void hgt_edge_emit_rels_kernel(const HgtEdgeRels E) {
+    const HgtEdgeRel &a = E.r[blockIdx.y];
+    hgt_edge_emit_body(a.cand_j, a.cand_ep, a.off, a.cap_n, a.rows, a.cols, a.eidx);
+}
+__global__ void hgt_finish_kernel(const HgtTypeCtr *ctr, int n_types, int64_t *n_samples, const int *panic, int *panic_out) {
+    for (int t = threadIdx.x; t < n_types; t += blockDim.x) n_samples[t] = ctr[t].n_nodes;
+    if (threadIdx.x == 0) *panic_out = *panic;
 }
 
 // ---------------------------------------------------------------- workspace layout
 struct HgtPlan {
     int T, R, H;
     std::vector<int64_t> cap_nodes, cap_budget, tl_cap, bm_cap;
-    int64_t max_layer, mc_cap, tmp_cap, max_budget, max_k, edge_cap, scan_cap;
+    int64_t max_layer, mc_cap, tmp_cap, max_budget, max_k, max_nodes, edge_cap, scan_cap;
+    int edge_lanes; // relations whose edges are rebuilt side by side
     size_t sort_temp_bytes, scan_temp_bytes;
     size_t total_bytes;
 };
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+struct HgtStepScratch {
+    int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal;
+    double *cinv;
+    uint64_t *cmask;
+};
+struct HgtEdgeScratch {
+    int64_t *cand_j, *cand_ep, *kept, *off;
+};
+// every array of a call; hgt_carve hands them out of the workspace (base = NULL: only adds up the bytes)
+struct HgtBuffers {
+    HgtTypeCtr *ctr;
+    int64_t *scal; // 8 words behind the counters; the panic flag is the last
+    int *panic;
+    std::vector<HgtType> ty;
+    HgtStepScratch sc[HGT_MAX_PAR];
+    int64_t *skey, *sval, *skey2, *sval2; // a round's sort input / output, step-major slices of mc_cap
+    std::vector<int64_t *> live, chosen, lflag, lrank;
+    std::vector<uint64_t *> lcmask;
+    std::vector<uint32_t *> slots;
+    std::vector<double *> carries;
+    int64_t *n_live, *n_chosen;
+    std::vector<HgtEdgeScratch> ed;
+    void *sort_temp, *scan_temp;
+};
+static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char *p = base ? base + off : nullptr;
+        off += align16(bytes);
+        return p;
+    };
+    auto i64 = [&](size_t n) { return reinterpret_cast<int64_t *>(take(8 * n)); };
+    const int T = pl.T;
+    unsigned char *ctr_block = take(sizeof(HgtTypeCtr) * T + 64);
+    B.ctr = reinterpret_cast<HgtTypeCtr *>(ctr_block);
+    B.scal = reinterpret_cast<int64_t *>(ctr_block ? ctr_block + sizeof(HgtTypeCtr) * T : nullptr);
+    B.panic = reinterpret_cast<int *>(B.scal ? B.scal + 7 : nullptr);
+    B.ty.assign((size_t)T, HgtType{});
+    for (int t = 0; t < T; ++t) {
+        HgtType &y = B.ty[(size_t)t];
+        y.tl_keys = i64((size_t)pl.tl_cap[t]);
+        y.tl_vals = i64((size_t)pl.tl_cap[t]);
+        y.tl_mask = pl.tl_cap[t] - 1;
+        y.bkey = i64((size_t)pl.cap_budget[t]);
+        y.bts = i64((size_t)pl.cap_budget[t]);
+        y.balive = i64((size_t)pl.cap_budget[t]);
+        y.bscore = reinterpret_cast<double *>(i64((size_t)pl.cap_budget[t]));
+        y.bm_keys = i64((size_t)pl.bm_cap[t]);
+        y.bm_vals = i64((size_t)pl.bm_cap[t]);
+        y.bm_mask = pl.bm_cap[t] - 1;
+        y.ctr = B.ctr ? B.ctr + t : nullptr;
+    }
+    const size_t step_chunks = (size_t)(pl.mc_cap / 64 + 3);
+    for (int y = 0; y < HGT_MAX_PAR; ++y) {
+        HgtStepScratch &s = B.sc[y];
+        s.ccnt = i64((size_t)pl.max_layer);
+        s.coff = i64((size_t)pl.max_layer + 1);
+        s.ckey = i64((size_t)pl.mc_cap);
+        s.cinv = reinterpret_cast<double *>(i64((size_t)pl.mc_cap));
+        s.cts = i64((size_t)pl.mc_cap);
+        s.cslot = i64((size_t)pl.mc_cap);
+        s.tmp_keys = i64((size_t)pl.tmp_cap);
+        s.tmp_vals = i64((size_t)pl.tmp_cap);
+        s.flag = i64(step_chunks);
+        s.rank = i64(step_chunks);
+        s.cmask = reinterpret_cast<uint64_t *>(i64(step_chunks));
+        s.scal = i64(8); // [0] contributions [1] new entries
+    }
+    B.skey = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
+    B.sval = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
+    B.skey2 = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
+    B.sval2 = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
+    B.live.assign((size_t)T, nullptr), B.chosen.assign((size_t)T, nullptr), B.lflag.assign((size_t)T, nullptr);
+    B.lrank.assign((size_t)T, nullptr), B.lcmask.assign((size_t)T, nullptr), B.slots.assign((size_t)T, nullptr);
+    B.carries.assign((size_t)T, nullptr);
+    for (int t = 0; t < T; ++t) {
+        const size_t chunks = (size_t)(pl.cap_budget[t] / 64 + 3);
+        B.live[(size_t)t] = i64((size_t)pl.cap_budget[t]);
+        B.chosen[(size_t)t] = i64((size_t)pl.max_k);
+        B.slots[(size_t)t] = reinterpret_cast<uint32_t *>(i64((size_t)pl.max_k));
+        B.carries[(size_t)t] = reinterpret_cast<double *>(i64(chunks));
+        B.lflag[(size_t)t] = i64(chunks);
+        B.lrank[(size_t)t] = i64(chunks);
+        B.lcmask[(size_t)t] = reinterpret_cast<uint64_t *>(i64(chunks));
+    }
+    B.n_live = i64(2 * (size_t)T);
+    B.n_chosen = B.n_live ? B.n_live + T : nullptr;
+    B.ed.assign((size_t)pl.edge_lanes, HgtEdgeScratch{});
+    for (int l = 0; l < pl.edge_lanes; ++l) {
+        B.ed[(size_t)l].cand_j = i64((size_t)pl.edge_cap);
+        B.ed[(size_t)l].cand_ep = i64((size_t)pl.edge_cap);
+        B.ed[(size_t)l].kept = i64((size_t)pl.max_nodes + 1);
+        B.ed[(size_t)l].off = i64((size_t)pl.max_nodes + 2);
+    }
+    B.sort_temp = take(pl.sort_temp_bytes);
+    B.scan_temp = take(pl.scan_temp_bytes);
+    return off + 256;
+}
 
 static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     pl.T = pb->n_types;
@@ -632,24 +796,26 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
     }
     for (int r = 0; r < pl.R; ++r) pl.cap_budget[pb->rel_src[r]] += upd[pb->rel_dst[r]] * HGT_MAX_NB;
     pl.max_budget = 1;
-    int64_t max_nodes = 1;
+    pl.max_nodes = 1;
     pl.tl_cap.assign(pl.T, 0);
     pl.bm_cap.assign(pl.T, 0);
     for (int t = 0; t < pl.T; ++t) {
         if (pl.cap_budget[t] < 1) pl.cap_budget[t] = 1;
         // a budget can never hold more live entries than were inserted; samples per layer are capped by both
         if (pl.cap_budget[t] > pl.max_budget) pl.max_budget = pl.cap_budget[t];
-        if (pl.cap_nodes[t] > max_nodes) max_nodes = pl.cap_nodes[t];
+        if (pl.cap_nodes[t] > pl.max_nodes) pl.max_nodes = pl.cap_nodes[t];
         pl.tl_cap[t] = pow2_at_least(2 * pl.cap_nodes[t] + 2);
         pl.bm_cap[t] = pow2_at_least(2 * pl.cap_budget[t] + 2);
     }
     pl.mc_cap = pl.max_layer * HGT_MAX_NB;
     pl.tmp_cap = pow2_at_least(2 * pl.mc_cap + 2);
-    pl.edge_cap = max_nodes * HGT_MAX_NB;
-    pl.scan_cap = std::max(std::max(pl.mc_cap, pl.max_budget), pl.edge_cap);
+    pl.edge_cap = pl.max_nodes * HGT_MAX_NB;
+    pl.edge_lanes = std::max(1, std::min(pl.R, HGT_EDGE_PAR));
+    pl.scan_cap = std::max(pl.mc_cap / 64 + 3, pl.max_nodes + 2);
     size_t st = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, st, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr,
-                                             (int64_t *)nullptr, (size_t)pl.mc_cap * HGT_MAX_PAR, 0, 64, (hipStream_t)0, false);
+    hipError_t e = rocprim::radix_sort_pairs<HgtSortConfig>(nullptr, st, (int64_t *)nullptr, (int64_t *)nullptr,
+                                                            (int64_t *)nullptr, (int64_t *)nullptr,
+                                                            (size_t)pl.mc_cap * HGT_MAX_PAR, 0, 64, (hipStream_t)0, false);
     if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
     pl.sort_temp_bytes = st;
     size_t sc = 0;
@@ -657,33 +823,8 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
                                 rocprim::plus<int64_t>(), (hipStream_t)0, false);
     if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::exclusive_scan size query failed: %s", hipGetErrorString(e));
     pl.scan_temp_bytes = sc;
-    size_t b = 0;
-    b += align16(sizeof(HgtTypeCtr) * pl.T + 64); // counters + misc scalars
-    for (int t = 0; t < pl.T; ++t) {
-        b += align16(8 * (size_t)pl.tl_cap[t]) * 2;
-        b += align16(8 * (size_t)pl.cap_budget[t]) * 4;
-        b += align16(8 * (size_t)pl.bm_cap[t]) * 2;
-    }
-    { // scratch of one update_budget step, HGT_MAX_PAR of them side by side
-        size_t step = 0;
-        step += align16(8 * (size_t)pl.max_layer) * 2; // ccnt, coff
-        step += align16(8 * (size_t)pl.mc_cap) * 4;    // ckey, cinv, cts, cslot
-        step += align16(8 * (size_t)pl.tmp_cap) * 2;   // tmp map
-        step += align16(8 * (size_t)(pl.mc_cap / 64 + 3)) * 3; // chunk counts, their prefix, chunk masks
-        step += align16(8 * 8);                        // scalars
-        b += step * HGT_MAX_PAR;
-    }
-    b += align16(8 * (size_t)pl.mc_cap * HGT_MAX_PAR) * 4; // skey, sval, skey2, sval2 of all steps of a round, step-major
-    b += align16(8 * (size_t)(pl.scan_cap + 1)) * 2; // flag, rank
-    b += align16(8 * (size_t)(pl.scan_cap / 64 + 2)); // chunk masks
-    for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)pl.cap_budget[t]); // live, per type
-    b += align16(8 * (size_t)pl.max_k) * (size_t)pl.T * 2;                     // chosen + slot tables, per type
-    for (int t = 0; t < pl.T; ++t) b += align16(8 * (size_t)(pl.cap_budget[t] / 64 + 2)); // chunk carries, per type
-    b += align16(16 * (size_t)pl.T);                                           // n_live, n_chosen per type
-    b += align16(8 * (size_t)pl.edge_cap) * 2;   // cand_j, cand_ep
-    b += align16(pl.sort_temp_bytes);
-    b += align16(pl.scan_temp_bytes);
-    pl.total_bytes = b + 256;
+    HgtBuffers B;
+    pl.total_bytes = hgt_carve(pl, nullptr, B);
     return TG_OK;
 }
 
@@ -712,93 +853,42 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     TG_REQUIRE((size_t)workspace_bytes >= pl.total_bytes, "tg_hgt_sample: workspace too small (%lld < %lld)",
                (long long)workspace_bytes, (long long)pl.total_bytes);
     const int T = pl.T, R = pl.R, H = pl.H;
-
-    // ---- carve the workspace
-    unsigned char *base = reinterpret_cast<unsigned char *>(workspace);
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        unsigned char *p = base + off;
-        off += align16(bytes);
-        return p;
-    };
-    unsigned char *ctr_block = take(sizeof(HgtTypeCtr) * T + 64);
-    HgtTypeCtr *ctr = reinterpret_cast<HgtTypeCtr *>(ctr_block);
-    int64_t *scal = reinterpret_cast<int64_t *>(ctr_block + sizeof(HgtTypeCtr) * T); // [0] mc [1] n_new [2] n_live
-                                                                                     // [3] n_chosen [4] n_edges tmp
-    int *panic = reinterpret_cast<int *>(scal + 6);
-    TG_HIP(hipMemsetAsync(ctr_block, 0, sizeof(HgtTypeCtr) * T + 64, stream));
-    std::vector<HgtType> ty((size_t)T);
+    HgtBuffers B;
+    (void)hgt_carve(pl, reinterpret_cast<unsigned char *>(workspace), B);
+    std::vector<HgtType> &ty = B.ty;
+    HgtTypeCtr *ctr = B.ctr;
+    int *panic = B.panic;
     for (int t = 0; t < T; ++t) {
-        HgtType &y = ty[t];
-        y.nodes = out->samples[t];
-        y.ts = out->sample_ts[t];
-        y.tl_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tl_cap[t]));
-        y.tl_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tl_cap[t]));
-        y.tl_mask = pl.tl_cap[t] - 1;
-        y.bkey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
-        y.bts = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
-        y.balive = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
-        y.bscore = reinterpret_cast<double *>(take(8 * (size_t)pl.cap_budget[t]));
-        y.bm_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.bm_cap[t]));
-        y.bm_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.bm_cap[t]));
-        y.bm_mask = pl.bm_cap[t] - 1;
-        y.ctr = ctr + t;
-        hipLaunchKernelGGL(fill2_i64_kernel, dim3(grid_1d(pl.tl_cap[t])), dim3(256), 0, stream, y.tl_keys, pl.tl_cap[t],
-                           MAP_EMPTY, y.tl_vals, pl.tl_cap[t], (int64_t)-1);
-        hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_1d(pl.bm_cap[t])), dim3(256), 0, stream, y.bm_keys, pl.bm_cap[t],
-                           MAP_EMPTY);
+        ty[(size_t)t].nodes = out->samples[t];
+        ty[(size_t)t].ts = out->sample_ts[t];
     }
-    struct StepScratch {
-        int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal;
-        double *cinv;
-        uint64_t *cmask;
-    } sc[HGT_MAX_PAR];
-    for (int y = 0; y < HGT_MAX_PAR; ++y) {
-        sc[y].ccnt = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
-        sc[y].coff = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_layer));
-        sc[y].ckey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-        sc[y].cinv = reinterpret_cast<double *>(take(8 * (size_t)pl.mc_cap));
-        sc[y].cts = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-        sc[y].cslot = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap));
-        sc[y].tmp_keys = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
-        sc[y].tmp_vals = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.tmp_cap));
-        sc[y].flag = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.mc_cap / 64 + 3)));
-        sc[y].rank = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.mc_cap / 64 + 3)));
-        sc[y].cmask = reinterpret_cast<uint64_t *>(take(8 * (size_t)(pl.mc_cap / 64 + 3)));
-        sc[y].scal = reinterpret_cast<int64_t *>(take(8 * 8)); // [0] contributions [1] new entries
-    }
-    int64_t *skey = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR)); // step-major slices
-    int64_t *sval = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR));
-    int64_t *skey2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR));
-    int64_t *sval2 = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.mc_cap * HGT_MAX_PAR));
-    int64_t *flag = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.scan_cap));
-    int64_t *rank = reinterpret_cast<int64_t *>(take(8 * (size_t)(pl.scan_cap + 1)));
-    uint64_t *cmask = reinterpret_cast<uint64_t *>(take(8 * (size_t)(pl.scan_cap / 64 + 2)));
-    std::vector<int64_t *> live_t((size_t)T), chosen_t((size_t)T);
-    for (int t = 0; t < T; ++t) live_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.cap_budget[t]));
-    for (int t = 0; t < T; ++t) chosen_t[(size_t)t] = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.max_k));
-    std::vector<uint32_t *> slots_t((size_t)T);
-    for (int t = 0; t < T; ++t) slots_t[(size_t)t] = reinterpret_cast<uint32_t *>(take(8 * (size_t)pl.max_k));
-    std::vector<double *> carries_t((size_t)T);
-    for (int t = 0; t < T; ++t)
-        carries_t[(size_t)t] = reinterpret_cast<double *>(take(8 * (size_t)(pl.cap_budget[t] / 64 + 2)));
-    int64_t *n_live_t = reinterpret_cast<int64_t *>(take(16 * (size_t)T)), *n_chosen_t = n_live_t + T;
-    int64_t *cand_j = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
-    int64_t *cand_ep = reinterpret_cast<int64_t *>(take(8 * (size_t)pl.edge_cap));
-    void *sort_temp = take(pl.sort_temp_bytes);
-    void *scan_temp = take(pl.scan_temp_bytes);
-    // exclusive scan of flag[0..n) into rank[], total into *total (device-wide, rocPRIM)
-    auto device_scan = [&](int64_t n, int64_t *total) -> int {
-        if (n <= 16384) { // one workgroup beats the library's two launches + the total only up to about here
-            hipLaunchKernelGGL(hgt_scan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, flag, n, rank, total);
-            return TG_OK;
+
+    // ---- empty maps, zero counters: the types side by side
+    for (int t0 = 0; t0 < T; t0 += HGT_MULTI_TYPES) {
+        const int n = std::min(HGT_MULTI_TYPES, T - t0);
+        HgtInitArgs ia;
+        std::memset(&ia, 0, sizeof(ia));
+        int64_t widest = 1;
+        for (int i = 0; i < n; ++i) {
+            ia.ty[i] = ty[(size_t)(t0 + i)];
+            ia.tl_cap[i] = pl.tl_cap[t0 + i];
+            ia.bm_cap[i] = pl.bm_cap[t0 + i];
+            widest = std::max(widest, std::max(ia.tl_cap[i], ia.bm_cap[i]));
         }
+        hipLaunchKernelGGL(hgt_init_types_kernel, dim3(grid_1d(widest), (unsigned)n), dim3(256), 0, stream, ia, B.scal, 8);
+    }
+    TG_LAUNCH_CHECK();
+
+    // exclusive scan of flag[0..n) into rank[0..n), total into *total, for the sizes one workgroup is too slow for
+    auto library_scan = [&](const int64_t *flag, int64_t *rank, int64_t n, int64_t *total) -> int {
+        TG_REQUIRE(n <= pl.scan_cap, "tg_hgt_sample: scan of %lld elements exceeds the plan", (long long)n);
         size_t stb = pl.scan_temp_bytes;
-        TG_HIP(rocprim::exclusive_scan(scan_temp, stb, flag, rank, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), stream,
+        TG_HIP(rocprim::exclusive_scan(B.scan_temp, stb, flag, rank, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), stream,
                                        false));
         hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, flag, rank, n, total);
         return TG_OK;
     };
+    constexpr int64_t ONE_WORKGROUP_SCAN = 16384; // elements up to which one workgroup beats the library's launches
 
     // ---- update_budget (:27-102) for the layers of the node types `which`, in order (:47 relations in canonical order).
     // A step = (node type nt, relation r into nt); steps are dealt to ROUNDS: a step goes to the round after the last
@@ -826,48 +916,41 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             for (unsigned y = 0; y < Y; ++y) {
                 const int nt = round[y].first, r = round[y].second, st = pb->rel_src[r];
                 const tg_graph &g = pb->graphs[r];
+                const HgtStepScratch &sc = B.sc[y];
                 HgtStep &a = S.s[y];
-                a.dst = ty[nt];
-                a.src = ty[st];
+                a.dst = ty[(size_t)nt];
+                a.src = ty[(size_t)st];
                 a.src_ctr = ctr + st;
                 a.ptrs = g.ptrs;
                 a.indices = g.indices;
                 a.edge_ts = g.timestamps;
                 a.pad = pl.cap_budget[st]; // one above every budget slot
-                while (bits < 64 && ((int64_t)1 << bits) <= a.pad) ++bits;
-                a.ccnt = sc[y].ccnt, a.coff = sc[y].coff, a.ckey = sc[y].ckey, a.cts = sc[y].cts, a.cslot = sc[y].cslot;
-                a.tmp_keys = sc[y].tmp_keys, a.tmp_vals = sc[y].tmp_vals, a.flag = sc[y].flag, a.rank = sc[y].rank;
-                a.scal = sc[y].scal, a.cinv = sc[y].cinv, a.cmask = sc[y].cmask;
-                a.skey = skey + (size_t)y * pl.mc_cap, a.sval = sval + (size_t)y * pl.mc_cap;
-                a.skey2 = skey2 + (size_t)y * pl.mc_cap, a.sval2 = sval2 + (size_t)y * pl.mc_cap;
+                while (bits < 62 && ((int64_t)1 << bits) <= a.pad) ++bits;
+                a.ccnt = sc.ccnt, a.coff = sc.coff, a.ckey = sc.ckey, a.cts = sc.cts, a.cslot = sc.cslot;
+                a.tmp_keys = sc.tmp_keys, a.tmp_vals = sc.tmp_vals, a.flag = sc.flag, a.rank = sc.rank;
+                a.scal = sc.scal, a.cinv = sc.cinv, a.cmask = sc.cmask;
+                a.skey = B.skey + (size_t)y * pl.mc_cap, a.sval = B.sval + (size_t)y * pl.mc_cap;
+                a.skey2 = B.skey2 + (size_t)y * pl.mc_cap, a.sval2 = B.sval2 + (size_t)y * pl.mc_cap;
             }
             S.bits = (int)bits;
             auto g2 = [&](int64_t n) { return dim3(grid_1d(n), Y); };
-            hipLaunchKernelGGL(hgt_count_steps_kernel, g2(pl.max_layer), dim3(256), 0, stream, S, pl.max_layer);
-            hipLaunchKernelGGL(hgt_scan_i64_steps_kernel, dim3(1, Y), dim3(1024), 0, stream, S, pl.max_layer);
+            hipLaunchKernelGGL(hgt_count_scan_steps_kernel, dim3(1, Y), dim3(SCAN1_THREADS), 0, stream, S, pl.max_layer);
             hipLaunchKernelGGL(hgt_gen_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pb->has_timerange, pb->tr_lo,
-                               pb->tr_hi, pl.max_layer);
-            hipLaunchKernelGGL(hgt_fill_tmp_steps_kernel, g2(pl.tmp_cap), dim3(256), 0, stream, S, pl.tmp_cap);
+                               pb->tr_hi, pl.max_layer, pl.tmp_cap);
             hipLaunchKernelGGL(hgt_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1);
             hipLaunchKernelGGL(hgt_first_flags_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1, pl.mc_cap);
-            if (n_chunks <= 16384) { // the chunks' counts: one workgroup per step
+            if (n_chunks <= ONE_WORKGROUP_SCAN) { // over the chunks' counts: one workgroup per step
                 hipLaunchKernelGGL(hgt_scan1_steps_kernel, dim3(1, Y), dim3(SCAN1_THREADS), 0, stream, S, n_chunks);
             } else {
-                for (unsigned y = 0; y < Y; ++y) {
-                    size_t stb = pl.scan_temp_bytes;
-                    TG_HIP(rocprim::exclusive_scan(scan_temp, stb, S.s[y].flag, S.s[y].rank, (int64_t)0, (size_t)n_chunks,
-                                                   rocprim::plus<int64_t>(), stream, false));
-                    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, S.s[y].flag, S.s[y].rank, n_chunks,
-                                       S.s[y].scal + 1);
-                }
+                for (unsigned y = 0; y < Y; ++y)
+                    if (int rcs = library_scan(S.s[y].flag, S.s[y].rank, n_chunks, S.s[y].scal + 1)) return rcs;
             }
-            hipLaunchKernelGGL(hgt_new_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1);
-            hipLaunchKernelGGL(hgt_sort_input_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.mc_cap);
+            hipLaunchKernelGGL(hgt_new_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1, pl.mc_cap);
             { // ONE stable sort for the round (equal entries keep contribution order): a key carries its step above its
               // `bits` entry bits, and every step brings exactly mc_cap keys, so step y's keys come out in slice y
                 size_t stb = pl.sort_temp_bytes;
-                TG_HIP(rocprim::radix_sort_pairs(sort_temp, stb, skey, skey2, sval, sval2, (size_t)pl.mc_cap * Y, 0, bits + 2,
-                                                 stream, false));
+                TG_HIP(rocprim::radix_sort_pairs<HgtSortConfig>(B.sort_temp, stb, B.skey, B.skey2, B.sval, B.sval2,
+                                                                (size_t)pl.mc_cap * Y, 0, bits + 2, stream, false));
             }
             hipLaunchKernelGGL(hgt_accumulate_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.mc_cap);
             TG_LAUNCH_CHECK();
@@ -880,7 +963,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
         const int64_t n_in = pb->n_inputs[t];
         if (n_in > 0) {
             TG_REQUIRE(pb->inputs[t], "tg_hgt_sample: node type %d has n_inputs > 0 but no pointer", t);
-            hipLaunchKernelGGL(hgt_init_inputs_kernel, dim3(grid_1d(n_in)), dim3(256), 0, stream, ty[t], pb->inputs[t],
+            hipLaunchKernelGGL(hgt_init_inputs_kernel, dim3(grid_1d(n_in)), dim3(256), 0, stream, ty[(size_t)t], pb->inputs[t],
                                pb->input_ts ? pb->input_ts[t] : (const int64_t *)nullptr, n_in);
         }
     }
@@ -894,43 +977,23 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     }
     // ---- :198-242 layers
     for (int layer = 0; layer < H; ++layer) {
-        size_t lds_max = 8;
-        for (int t = 0; t < T; ++t) { // :201 every type that owns a budget samples from it: first the live lists
-            const int64_t k = pb->num_samples[(size_t)t * H + layer];
-            hipLaunchKernelGGL(hgt_live_flags_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t],
-                               pl.cap_budget[t], flag, cmask);
-            if (int rcs = device_scan((pl.cap_budget[t] + 63) / 64, n_live_t + t)) return rcs; // over the chunks' counts
-            hipLaunchKernelGGL(hgt_live_list_kernel, dim3(grid_1d(pl.cap_budget[t])), dim3(256), 0, stream, ty[t], cmask,
-                               rank, live_t[(size_t)t]);
-            const size_t lds = (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 4 : 8;
-            if (lds > lds_max) lds_max = lds;
-        }
-        if (T <= HGT_MULTI_TYPES) { // the types' reservoirs side by side, one workgroup each
-            HgtMultiArgs ma;
-            for (int t = 0; t < T; ++t) {
-                ma.ty[t] = ty[(size_t)t];
-                ma.n_live[t] = n_live_t + t;
-                ma.live[t] = live_t[(size_t)t];
-                ma.chosen[t] = chosen_t[(size_t)t];
-                ma.n_chosen[t] = n_chosen_t + t;
-                ma.k[t] = pb->num_samples[(size_t)t * H + layer];
-                ma.slots[t] = slots_t[(size_t)t];
-                ma.carries[t] = carries_t[(size_t)t];
+        for (int t0 = 0; t0 < T; t0 += HGT_MULTI_TYPES) { // :201 every type that owns a budget samples from it
+            const int n = std::min(HGT_MULTI_TYPES, T - t0);
+            HgtSampleArgs sa;
+            std::memset(&sa, 0, sizeof(sa));
+            size_t lds = 8;
+            for (int i = 0; i < n; ++i) {
+                const size_t t = (size_t)(t0 + i);
+                sa.ty[i] = ty[t];
+                sa.n_live[i] = B.n_live + t, sa.live[i] = B.live[t], sa.chosen[i] = B.chosen[t], sa.n_chosen[i] = B.n_chosen + t;
+                sa.flag[i] = B.lflag[t], sa.rank[i] = B.lrank[t], sa.cmask[i] = B.lcmask[t];
+                sa.k[i] = pb->num_samples[t * (size_t)H + (size_t)layer];
+                sa.slots[i] = B.slots[t], sa.carries[i] = B.carries[t];
+                if (sa.k[i] > 0 && sa.k[i] <= HGT_LDS_SLOTS) lds = std::max(lds, (size_t)sa.k[i] * 4);
             }
-            hipLaunchKernelGGL(hgt_weighted_reservoir_multi_kernel, dim3((unsigned)T), dim3(1024), lds_max, stream, ma,
-                               rng->seed, rng->call_id, (int64_t)layer, T, panic);
-        } else {
-            for (int t = 0; t < T; ++t) {
-                const int64_t k = pb->num_samples[(size_t)t * H + layer];
-                hipLaunchKernelGGL(hgt_weighted_reservoir_kernel, dim3(1), dim3(1024),
-                                   (k > 0 && k <= HGT_LDS_SLOTS) ? (size_t)k * 4 : 8, stream, ty[t], n_live_t + t,
-                                   live_t[(size_t)t], k, rng->seed, rng->call_id, (uint64_t)((int64_t)layer * T + t),
-                                   chosen_t[(size_t)t], n_chosen_t + t, panic, slots_t[(size_t)t], carries_t[(size_t)t]);
-            }
+            hipLaunchKernelGGL(hgt_sample_layer_kernel, dim3((unsigned)n), dim3(SCAN1_THREADS), lds, stream, sa, rng->seed,
+                               rng->call_id, (int64_t)layer, t0, T, panic);
         }
-        for (int t = 0; t < T; ++t)
-            hipLaunchKernelGGL(hgt_append_kernel, dim3(1), dim3(256), 0, stream, ty[t], live_t[(size_t)t],
-                               chosen_t[(size_t)t], n_chosen_t + t);
         TG_LAUNCH_CHECK();
         if (layer < H - 1) { // :227 (types without samples return at :38-40)
             std::vector<int> which;
@@ -939,21 +1002,36 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             if (rc != TG_OK) return rc;
         }
     }
-    // ---- :244-268 edges among the sampled nodes
-    for (int r = 0; r < R; ++r) {
-        const int st = pb->rel_src[r], dt = pb->rel_dst[r];
-        const tg_graph &g = pb->graphs[r];
-        const int64_t cap_n = pl.cap_nodes[dt] > 0 ? pl.cap_nodes[dt] : 1;
-        hipLaunchKernelGGL(hgt_edge_candidates_kernel, dim3(grid_1d(cap_n * 64)), dim3(256), 0, stream, ty[dt], ty[st],
-                           g.ptrs, g.indices, cap_n, rng->seed, rng->call_id, TAG_HGT | ((uint32_t)(r + 1) << 8), cand_j,
-                           cand_ep, flag);
-        if (int rcs = device_scan(cap_n, out->n_edges + r)) return rcs; // over the nodes' kept-edge counts
-        hipLaunchKernelGGL(hgt_edge_emit_kernel, dim3(grid_1d(cap_n * 64)), dim3(256), 0, stream, cand_j, cand_ep, rank,
-                           cap_n, out->rows[r], out->cols[r], out->edge_index[r]);
+    // ---- :244-268 edges among the sampled nodes, the relations side by side
+    for (int r0 = 0; r0 < R; r0 += pl.edge_lanes) {
+        const int n = std::min(pl.edge_lanes, R - r0);
+        HgtEdgeRels E;
+        std::memset(&E, 0, sizeof(E));
+        int64_t widest = 1;
+        for (int i = 0; i < n; ++i) {
+            const int r = r0 + i, st = pb->rel_src[r], dt = pb->rel_dst[r];
+            HgtEdgeRel &a = E.r[i];
+            a.dst = ty[(size_t)dt], a.src = ty[(size_t)st];
+            a.ptrs = pb->graphs[r].ptrs, a.indices = pb->graphs[r].indices;
+            a.cap_n = pl.cap_nodes[dt] > 0 ? pl.cap_nodes[dt] : 1;
+            a.tag = TAG_HGT | ((uint32_t)(r + 1) << 8);
+            a.cand_j = B.ed[(size_t)i].cand_j, a.cand_ep = B.ed[(size_t)i].cand_ep;
+            a.kept = B.ed[(size_t)i].kept, a.off = B.ed[(size_t)i].off;
+            a.rows = out->rows[r], a.cols = out->cols[r], a.eidx = out->edge_index[r], a.n_edges = out->n_edges + r;
+            widest = std::max(widest, a.cap_n);
+        }
+        const dim3 grid(grid_1d(widest * 64), (unsigned)n);
+        hipLaunchKernelGGL(hgt_edge_candidates_rels_kernel, grid, dim3(256), 0, stream, E, rng->seed, rng->call_id);
+        if (widest <= ONE_WORKGROUP_SCAN) { // over the nodes' kept-edge counts
+            hipLaunchKernelGGL(hgt_edge_scan_rels_kernel, dim3(1, (unsigned)n), dim3(SCAN1_THREADS), 0, stream, E);
+        } else {
+            for (int i = 0; i < n; ++i)
+                if (int rcs = library_scan(E.r[i].kept, E.r[i].off, E.r[i].cap_n, E.r[i].n_edges)) return rcs;
+        }
+        hipLaunchKernelGGL(hgt_edge_emit_rels_kernel, grid, dim3(256), 0, stream, E);
         TG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(hgt_copy_counts_kernel, dim3(1), dim3(1024), 0, stream, ctr, T, out->n_samples);
-    TG_HIP(hipMemcpyAsync(out->panic, panic, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(hgt_finish_kernel, dim3(1), dim3(256), 0, stream, ctr, T, out->n_samples, panic, out->panic);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
