@@ -236,69 +236,201 @@ __device__ __forceinline__ int64_t hgt_chunk_rank(const int64_t *__restrict__ ch
     return chunk_prefix[q >> 6] + __popcll(below);
 }
 // new keys get entries n_budget + rank(first contribution); the entry order is the reference's insertion order.  The
-// same lane then writes the round's sort input: key = (step prefix | entry, or the pad key for dropped / absent
-// contributions), value = position.  Keys only need the bits of `pad` (+ the step's): budget entries are small numbers.
+// same lane counts the contribution in its entry's bucket (below).
 __device__ __forceinline__ void hgt_new_slots_body(HgtType src, const int64_t *mc, const int64_t *__restrict__ ckey,
                                                    int64_t *cslot, const int64_t *tmp_keys, const int64_t *tmp_vals,
                                                    int64_t tmp_mask, const int64_t *__restrict__ rank,
-                                                   const uint64_t *__restrict__ cmask, int64_t cap, int64_t pad, int64_t prefix,
-                                                   int64_t *skey, int64_t *sval) {
+                                                   const uint64_t *__restrict__ cmask, uint32_t *bcnt) {
     const int64_t n = *mc, nb = src.ctr->n_budget;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < cap; p += (int64_t)gridDim.x * blockDim.x) {
-        int64_t entry = -2;
-        if (p < n) {
-            entry = cslot[p];
-            if (entry == -1) {
-                const int64_t v = ckey[p];
-                const int64_t t = map_slot_find(tmp_keys, tmp_mask, v);
-                const int64_t first = tmp_vals[t];
-                entry = nb + hgt_chunk_rank(rank, cmask, first);
-                cslot[p] = entry;
-                if (first == p) { // :95 entry(v).or_default()
-                    src.bkey[entry] = v;
-                    src.bscore[entry] = 0.0;
-                    src.bts[entry] = 0;
-                    src.balive[entry] = 1;
-                    const int64_t s = map_slot_insert(src.bm_keys, src.bm_mask, v);
-                    src.bm_vals[s] = entry;
-                }
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t entry = cslot[p];
+        if (entry == -1) {
+            const int64_t v = ckey[p];
+            const int64_t t = map_slot_find(tmp_keys, tmp_mask, v);
+            const int64_t first = tmp_vals[t];
+            entry = nb + hgt_chunk_rank(rank, cmask, first);
+            cslot[p] = entry;
+            if (first == p) { // :95 entry(v).or_default()
+                src.bkey[entry] = v;
+                src.bscore[entry] = 0.0;
+                src.bts[entry] = 0;
+                src.balive[entry] = 1;
+                const int64_t s = map_slot_insert(src.bm_keys, src.bm_mask, v);
+                src.bm_vals[s] = entry;
             }
         }
-        skey[p] = prefix | (entry >= 0 ? entry : pad);
-        sval[p] = p;
+        if (entry >= 0) atomicAdd(&bcnt[entry], 1u);
     }
 }
-// one lane per entry run: score += 1/deg in contribution order (:96), timestamp = the last one (:97)
-__device__ __forceinline__ void hgt_accumulate_body(HgtType src, const int64_t *__restrict__ skey, const int64_t *__restrict__ sval,
-                                      int64_t cap, int64_t pad, int64_t prefix, const double *__restrict__ cinv,
-                                      const int64_t *__restrict__ cts, const int64_t *n_new) {
-    // the budget grows by the entries hgt_new_slots_body placed (nothing reads the counter between the two launches)
+
+// ---- the contributions of every entry, in contribution order, WITHOUT a device-wide sort
+// (a stable rocPRIM sort by entry was 9 launches and ~60 us per round: block sort + 8 merge passes; its onesweep radix
+// form 5 kernels + 7 memsets and ~100 us.)  Buckets instead: new_slots counted every entry's contributions; (1) each
+// entry gets the start of its bucket -- prefix inside its 64-entry chunk here, the chunk totals scanned by one
+// workgroup; (2) the positions drop into their buckets in ARBITRARY order (atomic cursor); (3) accumulate puts each
+// bucket into ascending position order -- positions are unique, so that IS the contribution order -- as it sums.
+__device__ __forceinline__ void hgt_bucket_offsets_body(const HgtType &src, const uint32_t *__restrict__ bcnt, int64_t cap,
+                                                        uint32_t *bwithin, int64_t *tflag, const int64_t *n_new) {
+    // the budget grows by the entries hgt_new_slots_body placed (nothing else in this launch reads the counter)
     if (blockIdx.x == 0 && threadIdx.x == 0) src.ctr->n_budget += *n_new;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < cap; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t key = skey[q], entry = key ^ prefix; // the step's slice holds keys of its prefix only
-        if (entry == pad) continue;
-        if (q > 0 && skey[q - 1] == key) continue; // not the head of its run
-        double score = src.bscore[entry];
-        int64_t lo = q, hi = cap; // the run is [q, end): keys are sorted, so its end is found by bisection
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (skey[mid] == key)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const int64_t end = lo + 1;
-        // the sum keeps the contribution order, but the gathers of 8 contributions are issued together
-        for (int64_t r = q; r < end; r += 8) {
-            double c[8];
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (cap + 63) >> 6;
+    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks;
+         c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t e = (c << 6) + lane;
+        const uint32_t v = e < cap ? bcnt[e] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (e < cap) bwithin[e] = incl - v;
+        if (lane == 63) tflag[c] = (int64_t)incl;
+    }
+}
+__device__ __forceinline__ void hgt_bucket_scatter_body(const int64_t *mc, const int64_t *__restrict__ cslot,
+                                                        const int64_t *__restrict__ trank,
+                                                        const uint32_t *__restrict__ bwithin, uint32_t *bcur,
+                                                        uint32_t *bucket) {
+    const int64_t n = *mc;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = cslot[p];
+        if (e < 0) continue;
+        bucket[(uint32_t)trank[e >> 6] + bwithin[e] + atomicAdd(&bcur[e], 1u)] = (uint32_t)p;
+    }
+}
+__device__ __forceinline__ void hgt_ce(uint32_t &x, uint32_t &y) {
+    const uint32_t lo = min(x, y), hi = max(x, y);
+    x = lo;
+    y = hi;
+}
+// score += 1/deg in contribution order (:96), timestamp = the last contribution's (:97).  One lane per entry while its
+// bucket holds <= 8 positions (a 19-comparator network in registers; most entries hold 1-3); a longer bucket takes the
+// whole wavefront: up to 64 positions are ranked by counting in registers, more go through a wavefront-wide LSD radix
+// sort (8-bit digits, stable by ballot matching) between the bucket and its twin -- linear in the bucket's length, so a
+// hub that every sample points at costs its length, not its square.  The f64 sum itself stays left to right.
+constexpr int HGT_ACC_THREADS = 256;
+__device__ __forceinline__ void hgt_accumulate_body(const HgtType &src, const uint32_t *__restrict__ bcnt,
+                                                    const uint32_t *__restrict__ bwithin, const int64_t *__restrict__ trank,
+                                                    uint32_t *bucket, uint32_t *bucket2, int64_t cap, int pbits,
+                                                    const double *__restrict__ cinv, const int64_t *__restrict__ cts) {
+    __shared__ uint32_t hist_s[HGT_ACC_THREADS / 64][256];
+    __shared__ uint32_t perm_s[HGT_ACC_THREADS / 64][64];
+    __shared__ double sum_s[HGT_ACC_THREADS / 64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *hist = hist_s[wave], *perm = perm_s[wave];
+    double *sbuf = sum_s[wave];
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int64_t nbud = src.ctr->n_budget;
+    const int64_t n_chunks = (min(cap, nbud) + 63) >> 6;
+    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks;
+         c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t e = (c << 6) + lane;
+        const uint32_t L = (e < nbud && e < cap) ? bcnt[e] : 0u;
+        const uint32_t start = L ? (uint32_t)trank[c] + bwithin[e] : 0u;
+        if (L > 0 && L <= 8) {
+            uint32_t a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = cinv[sval[min(r + u, end - 1)]];
+            for (int u = 0; u < 8; ++u) a[u] = (uint32_t)u < L ? bucket[start + u] : 0xffffffffu;
+            hgt_ce(a[0], a[1]), hgt_ce(a[2], a[3]), hgt_ce(a[4], a[5]), hgt_ce(a[6], a[7]);
+            hgt_ce(a[0], a[2]), hgt_ce(a[1], a[3]), hgt_ce(a[4], a[6]), hgt_ce(a[5], a[7]);
+            hgt_ce(a[1], a[2]), hgt_ce(a[5], a[6]), hgt_ce(a[0], a[4]), hgt_ce(a[3], a[7]);
+            hgt_ce(a[1], a[5]), hgt_ce(a[2], a[6]);
+            hgt_ce(a[1], a[4]), hgt_ce(a[3], a[6]);
+            hgt_ce(a[2], a[4]), hgt_ce(a[3], a[5]);
+            hgt_ce(a[3], a[4]);
+            double cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cv[u] = (uint32_t)u < L ? cinv[a[u]] : 0.0; // the gathers are issued together
+            double score = src.bscore[e];
+            uint32_t last = a[0];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (r + u < end) score = score + c[u];
+                if ((uint32_t)u < L) {
+                    score = score + cv[u];
+                    last = a[u];
+                }
+            src.bscore[e] = score;
+            src.bts[e] = cts[last];
         }
-        src.bscore[entry] = score;
-        src.bts[entry] = cts[sval[end - 1]];
+        uint64_t longm = __ballot(L > 8);
+        while (longm) { // wave-uniform: one long bucket at a time, all 64 lanes on it
+            const int owner = __ffsll((long long)longm) - 1;
+            longm &= longm - 1;
+            const int64_t e2 = (c << 6) + owner;
+            const uint32_t L2 = (uint32_t)__builtin_amdgcn_readlane((int)L, owner);
+            const uint32_t st2 = (uint32_t)__builtin_amdgcn_readlane((int)start, owner);
+            double score = src.bscore[e2];
+            uint32_t last = 0;
+            if (L2 <= 64) {
+                const uint32_t p = (uint32_t)lane < L2 ? bucket[st2 + lane] : 0xffffffffu;
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < L2; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)p, (int)j) < p ? 1u : 0u;
+                if ((uint32_t)lane < L2) perm[r] = p;
+                wave_lds_handoff();
+                const uint32_t ps = (uint32_t)lane < L2 ? perm[lane] : 0u;
+                const double cv = (uint32_t)lane < L2 ? cinv[ps] : 0.0;
+                double total;
+                (void)wave_serial_prefix_f64(cv, score, &total, sbuf); // x + 0.0 = x: the lanes past the bucket add nothing
+                score = total;
+                last = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(L2 - 1));
+            } else {
+                uint32_t *a = bucket + st2, *b = bucket2 + st2;
+                for (int shift = 0; shift < pbits; shift += 8) {
+                    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+                    wave_lds_handoff();
+                    for (uint32_t t0 = 0; t0 < L2; t0 += 64)
+                        if (t0 + lane < L2) atomicAdd(&hist[(a[t0 + lane] >> shift) & 255u], 1u);
+                    wave_lds_handoff();
+                    { // exclusive scan of the 256 digit counts, four per lane
+                        const uint32_t x0 = hist[4 * lane], x1 = hist[4 * lane + 1], x2 = hist[4 * lane + 2],
+                                       x3 = hist[4 * lane + 3];
+                        const uint32_t sm = x0 + x1 + x2 + x3;
+                        const uint32_t base = wave_inclusive_scan(sm) - sm;
+                        wave_lds_handoff();
+                        hist[4 * lane] = base;
+                        hist[4 * lane + 1] = base + x0;
+                        hist[4 * lane + 2] = base + x0 + x1;
+                        hist[4 * lane + 3] = base + x0 + x1 + x2;
+                    }
+                    wave_lds_handoff();
+                    for (uint32_t t0 = 0; t0 < L2; t0 += 64) { // tiles in order; equal digits keep their order (stable)
+                        const bool valid = t0 + lane < L2;
+                        const uint32_t v = valid ? a[t0 + lane] : 0u;
+                        const uint32_t d = (v >> shift) & 255u;
+                        uint64_t same = __ballot(valid);
+#pragma unroll
+                        for (int bit = 0; bit < 8; ++bit) {
+                            const bool one = (d >> bit) & 1u;
+                            const uint64_t bal = __ballot(one);
+                            same &= one ? bal : ~bal;
+                        }
+                        const uint32_t before = (uint32_t)__popcll(same & lt_mask), group = (uint32_t)__popcll(same);
+                        const uint32_t at = hist[d];
+                        wave_lds_handoff();
+                        if (valid) {
+                            b[at + before] = v;
+                            if (before + 1 == group) hist[d] = at + group;
+                        }
+                        wave_lds_handoff();
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the next pass reads what this one wrote
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    uint32_t *t = a;
+                    a = b;
+                    b = t;
+                }
+                for (uint32_t t0 = 0; t0 < L2; t0 += 64) {
+                    const bool valid = t0 + lane < L2;
+                    const uint32_t ps = valid ? a[t0 + lane] : 0u;
+                    const double cv = valid ? cinv[ps] : 0.0;
+                    double total;
+                    (void)wave_serial_prefix_f64(cv, score, &total, sbuf);
+                    score = total;
+                    if (t0 + 64 >= L2) last = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(L2 - 1 - t0));
+                }
+            }
+            if (lane == 0) {
+                src.bscore[e2] = score;
+                src.bts[e2] = cts[last];
+            }
+        }
     }
 }
 
@@ -313,24 +445,29 @@ struct HgtStep {
     HgtType dst, src;
     HgtTypeCtr *src_ctr;
     const int64_t *ptrs, *indices, *edge_ts;
-    int64_t pad; // sort key of padding: the source budget's capacity
-    int64_t *ccnt, *coff, *ckey, *cts, *cslot, *skey, *sval, *skey2, *sval2, *tmp_keys, *tmp_vals, *flag, *rank, *scal;
+    int64_t pad; // the source budget's capacity
+    int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal, *tflag, *trank;
+    uint32_t *bcnt, *bwithin, *bcur, *bucket, *bucket2;
     double *cinv;
     uint64_t *cmask;
 };
 struct HgtSteps {
     HgtStep s[HGT_MAX_PAR];
-    int bits; // a sort key = (step << bits) | budget slot (or the step's pad)
+    int pbits; // bits of a contribution position
 };
 __global__ void __launch_bounds__(SCAN1_THREADS) hgt_count_scan_steps_kernel(const HgtSteps S, int64_t cap) {
     const HgtStep &a = S.s[blockIdx.y];
     hgt_contrib_count_scan_body(a.dst, a.src_ctr, a.ptrs, a.ccnt, a.coff, cap, a.scal + 0);
 }
-// contributions, and the empty min-position map of the step's new keys
+// contributions; also the empty min-position map of the step's new keys and the zeroed bucket counters
 __global__ void hgt_gen_steps_kernel(const HgtSteps S, int has_timerange, int64_t tr_lo, int64_t tr_hi, int64_t cap,
                                      int64_t tmp_cap) {
     const HgtStep &a = S.s[blockIdx.y];
     fill2_i64_body(a.tmp_keys, tmp_cap, MAP_EMPTY, a.tmp_vals, tmp_cap, (int64_t)INT64_MAX);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.pad; i += (int64_t)gridDim.x * blockDim.x) {
+        a.bcnt[i] = 0;
+        a.bcur[i] = 0;
+    }
     hgt_contrib_gen_body(a.dst, a.src, a.ptrs, a.indices, a.edge_ts, has_timerange, tr_lo, tr_hi, a.ccnt, a.coff, cap, a.ckey,
                          a.cinv, a.cts);
 }
@@ -346,19 +483,26 @@ __global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_steps_kernel(const Hg
     const HgtStep &a = S.s[blockIdx.y];
     hgt_scan1_body(a.flag, n, a.rank, a.scal + 1);
 }
-__global__ void hgt_new_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask, int64_t cap) {
+__global__ void hgt_new_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_new_slots_body(a.src, a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask, a.rank, a.cmask, cap, a.pad,
-                       (int64_t)blockIdx.y << S.bits, a.skey, a.sval);
+    hgt_new_slots_body(a.src, a.scal + 0, a.ckey, a.cslot, a.tmp_keys, a.tmp_vals, tmp_mask, a.rank, a.cmask, a.bcnt);
 }
-__global__ void hgt_accumulate_steps_kernel(const HgtSteps S, int64_t cap) {
+__global__ void hgt_bucket_offsets_steps_kernel(const HgtSteps S) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_accumulate_body(a.src, a.skey2, a.sval2, cap, a.pad, (int64_t)blockIdx.y << S.bits, a.cinv, a.cts, a.scal + 1);
+    hgt_bucket_offsets_body(a.src, a.bcnt, a.pad, a.bwithin, a.tflag, a.scal + 1);
 }
-// rocPRIM sorts fewer than a million pairs by block sort + log2(n / 1024) merge passes (9 launches, ~60 us for a round
-// here); forcing its onesweep radix sort (merge_sort_limit below n) takes 5 kernels + 7 memsets and ~100 us: measured,
-// not used
-using HgtSortConfig = rocprim::default_config;
+__global__ void __launch_bounds__(SCAN1_THREADS) hgt_bucket_scan_steps_kernel(const HgtSteps S) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_scan1_body(a.tflag, (a.pad + 63) >> 6, a.trank, a.scal + 2);
+}
+__global__ void hgt_bucket_scatter_steps_kernel(const HgtSteps S) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_bucket_scatter_body(a.scal + 0, a.cslot, a.trank, a.bwithin, a.bcur, a.bucket);
+}
+__global__ void __launch_bounds__(HGT_ACC_THREADS) hgt_accumulate_steps_kernel(const HgtSteps S) {
+    const HgtStep &a = S.s[blockIdx.y];
+    hgt_accumulate_body(a.src, a.bcnt, a.bwithin, a.trank, a.bucket, a.bucket2, a.pad, S.pbits, a.cinv, a.cts);
+}
 
 // ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
 // The node types of a layer sample from their own budgets independently (:201-221): ONE launch per layer, one workgroup
@@ -666,13 +810,14 @@ struct HgtPlan {
     std::vector<int64_t> cap_nodes, cap_budget, tl_cap, bm_cap;
     int64_t max_layer, mc_cap, tmp_cap, max_budget, max_k, max_nodes, edge_cap, scan_cap;
     int edge_lanes; // relations whose edges are rebuilt side by side
-    size_t sort_temp_bytes, scan_temp_bytes;
+    size_t scan_temp_bytes;
     size_t total_bytes;
 };
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 struct HgtStepScratch {
-    int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal;
+    int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal, *tflag, *trank;
+    uint32_t *bcnt, *bwithin, *bcur, *bucket, *bucket2;
     double *cinv;
     uint64_t *cmask;
 };
@@ -686,14 +831,13 @@ struct HgtBuffers {
     int *panic;
     std::vector<HgtType> ty;
     HgtStepScratch sc[HGT_MAX_PAR];
-    int64_t *skey, *sval, *skey2, *sval2; // a round's sort input / output, step-major slices of mc_cap
     std::vector<int64_t *> live, chosen, lflag, lrank;
     std::vector<uint64_t *> lcmask;
     std::vector<uint32_t *> slots;
     std::vector<double *> carries;
     int64_t *n_live, *n_chosen;
     std::vector<HgtEdgeScratch> ed;
-    void *sort_temp, *scan_temp;
+    void *scan_temp;
 };
 static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
     size_t off = 0;
@@ -737,12 +881,16 @@ static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
         s.flag = i64(step_chunks);
         s.rank = i64(step_chunks);
         s.cmask = reinterpret_cast<uint64_t *>(i64(step_chunks));
-        s.scal = i64(8); // [0] contributions [1] new entries
+        s.scal = i64(8); // [0] contributions [1] new entries [2] kept contributions
+        const size_t budget_chunks = (size_t)(pl.max_budget / 64 + 3);
+        s.tflag = i64(budget_chunks);
+        s.trank = i64(budget_chunks);
+        s.bcnt = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.max_budget));
+        s.bwithin = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.max_budget));
+        s.bcur = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.max_budget));
+        s.bucket = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap));
+        s.bucket2 = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap));
     }
-    B.skey = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
-    B.sval = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
-    B.skey2 = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
-    B.sval2 = i64((size_t)pl.mc_cap * HGT_MAX_PAR);
     B.live.assign((size_t)T, nullptr), B.chosen.assign((size_t)T, nullptr), B.lflag.assign((size_t)T, nullptr);
     B.lrank.assign((size_t)T, nullptr), B.lcmask.assign((size_t)T, nullptr), B.slots.assign((size_t)T, nullptr);
     B.carries.assign((size_t)T, nullptr);
@@ -765,7 +913,6 @@ static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
         B.ed[(size_t)l].kept = i64((size_t)pl.max_nodes + 1);
         B.ed[(size_t)l].off = i64((size_t)pl.max_nodes + 2);
     }
-    B.sort_temp = take(pl.sort_temp_bytes);
     B.scan_temp = take(pl.scan_temp_bytes);
     return off + 256;
 }
@@ -808,16 +955,12 @@ static int hgt_make_plan(const tg_hgt_problem *pb, HgtPlan &pl) {
         pl.bm_cap[t] = pow2_at_least(2 * pl.cap_budget[t] + 2);
     }
     pl.mc_cap = pl.max_layer * HGT_MAX_NB;
+    TG_REQUIRE(pl.mc_cap < ((int64_t)1 << 31), "tg_hgt: layers of %lld samples are not supported", (long long)pl.max_layer);
     pl.tmp_cap = pow2_at_least(2 * pl.mc_cap + 2);
     pl.edge_cap = pl.max_nodes * HGT_MAX_NB;
     pl.edge_lanes = std::max(1, std::min(pl.R, HGT_EDGE_PAR));
-    pl.scan_cap = std::max(pl.mc_cap / 64 + 3, pl.max_nodes + 2);
-    size_t st = 0;
-    hipError_t e = rocprim::radix_sort_pairs<HgtSortConfig>(nullptr, st, (int64_t *)nullptr, (int64_t *)nullptr,
-                                                            (int64_t *)nullptr, (int64_t *)nullptr,
-                                                            (size_t)pl.mc_cap * HGT_MAX_PAR, 0, 64, (hipStream_t)0, false);
-    if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::radix_sort_pairs size query failed: %s", hipGetErrorString(e));
-    pl.sort_temp_bytes = st;
+    pl.scan_cap = std::max(std::max(pl.mc_cap, pl.max_budget) / 64 + 3, pl.max_nodes + 2);
+    hipError_t e;
     size_t sc = 0;
     e = rocprim::exclusive_scan(nullptr, sc, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)pl.scan_cap,
                                 rocprim::plus<int64_t>(), (hipStream_t)0, false);
@@ -912,7 +1055,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
             if (Y == 0) continue;
             HgtSteps S;
             std::memset(&S, 0, sizeof(S));
-            unsigned bits = 1; // of the largest pad key of the round
+            int64_t widest_budget = 1;
             for (unsigned y = 0; y < Y; ++y) {
                 const int nt = round[y].first, r = round[y].second, st = pb->rel_src[r];
                 const tg_graph &g = pb->graphs[r];
@@ -924,15 +1067,15 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                 a.ptrs = g.ptrs;
                 a.indices = g.indices;
                 a.edge_ts = g.timestamps;
-                a.pad = pl.cap_budget[st]; // one above every budget slot
-                while (bits < 62 && ((int64_t)1 << bits) <= a.pad) ++bits;
+                a.pad = pl.cap_budget[st];
+                widest_budget = std::max(widest_budget, a.pad);
                 a.ccnt = sc.ccnt, a.coff = sc.coff, a.ckey = sc.ckey, a.cts = sc.cts, a.cslot = sc.cslot;
                 a.tmp_keys = sc.tmp_keys, a.tmp_vals = sc.tmp_vals, a.flag = sc.flag, a.rank = sc.rank;
-                a.scal = sc.scal, a.cinv = sc.cinv, a.cmask = sc.cmask;
-                a.skey = B.skey + (size_t)y * pl.mc_cap, a.sval = B.sval + (size_t)y * pl.mc_cap;
-                a.skey2 = B.skey2 + (size_t)y * pl.mc_cap, a.sval2 = B.sval2 + (size_t)y * pl.mc_cap;
+                a.scal = sc.scal, a.cinv = sc.cinv, a.cmask = sc.cmask, a.tflag = sc.tflag, a.trank = sc.trank;
+                a.bcnt = sc.bcnt, a.bwithin = sc.bwithin, a.bcur = sc.bcur, a.bucket = sc.bucket, a.bucket2 = sc.bucket2;
             }
-            S.bits = (int)bits;
+            S.pbits = 1;
+            while (((int64_t)1 << S.pbits) < pl.mc_cap) ++S.pbits;
             auto g2 = [&](int64_t n) { return dim3(grid_1d(n), Y); };
             hipLaunchKernelGGL(hgt_count_scan_steps_kernel, dim3(1, Y), dim3(SCAN1_THREADS), 0, stream, S, pl.max_layer);
             hipLaunchKernelGGL(hgt_gen_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pb->has_timerange, pb->tr_lo,
@@ -945,14 +1088,16 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                 for (unsigned y = 0; y < Y; ++y)
                     if (int rcs = library_scan(S.s[y].flag, S.s[y].rank, n_chunks, S.s[y].scal + 1)) return rcs;
             }
-            hipLaunchKernelGGL(hgt_new_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1, pl.mc_cap);
-            { // ONE stable sort for the round (equal entries keep contribution order): a key carries its step above its
-              // `bits` entry bits, and every step brings exactly mc_cap keys, so step y's keys come out in slice y
-                size_t stb = pl.sort_temp_bytes;
-                TG_HIP(rocprim::radix_sort_pairs<HgtSortConfig>(B.sort_temp, stb, B.skey, B.skey2, B.sval, B.sval2,
-                                                                (size_t)pl.mc_cap * Y, 0, bits + 2, stream, false));
+            hipLaunchKernelGGL(hgt_new_slots_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.tmp_cap - 1);
+            hipLaunchKernelGGL(hgt_bucket_offsets_steps_kernel, g2(widest_budget), dim3(256), 0, stream, S);
+            if ((widest_budget + 63) / 64 <= ONE_WORKGROUP_SCAN) { // over the budget chunks' contribution counts
+                hipLaunchKernelGGL(hgt_bucket_scan_steps_kernel, dim3(1, Y), dim3(SCAN1_THREADS), 0, stream, S);
+            } else {
+                for (unsigned y = 0; y < Y; ++y)
+                    if (int rcs = library_scan(S.s[y].tflag, S.s[y].trank, (S.s[y].pad + 63) / 64, S.s[y].scal + 2)) return rcs;
             }
-            hipLaunchKernelGGL(hgt_accumulate_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S, pl.mc_cap);
+            hipLaunchKernelGGL(hgt_bucket_scatter_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S);
+            hipLaunchKernelGGL(hgt_accumulate_steps_kernel, g2(widest_budget), dim3(HGT_ACC_THREADS), 0, stream, S);
             TG_LAUNCH_CHECK();
         }
         return TG_OK;

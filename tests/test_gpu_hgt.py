@@ -97,3 +97,27 @@ def test_hgt_more_than_8192_samples_per_layer(tg):
     g = (node_types, edge_types, P, I)
     o = _compare(tg, g, {"B": rs.integers(0, nB, 3000)}, None, {"A": [9000, 12000], "B": [10000, 100]}, 2, 3)
     assert len(o[0]["A"]) > 8192
+
+
+def test_hgt_hub_sources_long_contribution_runs(tg):
+    """Budget entries that hundreds of samples contribute to (hubs, parallel edges): their score is still the left-to-right
+    f64 sum in contribution order -- the runs here span one lane (<= 8), one wavefront (<= 64) and the wavefront-wide
+    radix sort (> 64, up to ~1500 contributions to one entry)."""
+    rs = np.random.default_rng(77)
+    nA, nB = 5000, 3000
+    src, dst = [], []
+    for b in range(nB):                         # A -> B: the first neighbours of every column are hubs 0..5
+        hubs = [0, 0, 1] + [2] * (b % 3) + ([3] if b % 2 else []) + ([4] if b % 7 == 0 else []) + ([5] if b % 40 == 0 else [])
+        rest = rs.integers(6, nA, int(rs.integers(0, 12))).tolist()
+        for a in hubs + rest:
+            src.append(a), dst.append(b)
+    e1 = np.stack([np.asarray(src), np.asarray(dst)])
+    e2 = np.stack([rs.integers(0, nB, 40000), rs.integers(0, nA, 40000)])     # B -> A
+    node_types, edge_types = ["A", "B"], [("A", "x", "B"), ("B", "y", "A")]
+    P, I = {}, {}
+    P["A__x__B"], I["A__x__B"], _ = orc.to_csc(e1, (nA, nB))
+    P["B__y__A"], I["B__y__A"], _ = orc.to_csc(e2, (nB, nA))
+    g = (node_types, edge_types, P, I)
+    for seed in (1, 2):
+        _compare(tg, g, {"B": rs.permutation(nB)[:700]}, None, {"A": [300, 200], "B": [600, 100]}, 2, seed)
+    _compare(tg, g, {"B": np.arange(60)}, None, {"A": [50, 50, 50], "B": [70, 70, 70]}, 3, 3)
