@@ -270,7 +270,8 @@ __device__ __forceinline__ void hgt_new_slots_body(HgtType src, const int64_t *m
 // workgroup; (2) the positions drop into their buckets in ARBITRARY order (atomic cursor); (3) accumulate puts each
 // bucket into ascending position order -- positions are unique, so that IS the contribution order -- as it sums.
 __device__ __forceinline__ void hgt_bucket_offsets_body(const HgtType &src, const uint32_t *__restrict__ bcnt, int64_t cap,
-                                                        uint32_t *bwithin, int64_t *tflag, const int64_t *n_new) {
+                                                        uint32_t *bwithin, int64_t *tflag, const int64_t *n_new,
+                                                        uint32_t *long_list, int64_t *n_long) {
     // the budget grows by the entries hgt_new_slots_body placed (nothing else in this launch reads the counter)
     if (blockIdx.x == 0 && threadIdx.x == 0) src.ctr->n_budget += *n_new;
     const int lane = threadIdx.x & 63;
@@ -282,6 +283,14 @@ __device__ __forceinline__ void hgt_bucket_offsets_body(const HgtType &src, cons
         const uint32_t incl = wave_inclusive_scan(v);
         if (e < cap) bwithin[e] = incl - v;
         if (lane == 63) tflag[c] = (int64_t)incl;
+        // entries with more than 8 contributions go on a list (any order): accumulate gives each a wavefront of its own
+        const uint64_t lm = __ballot(v > 8u);
+        if (lm) {
+            uint32_t at = 0;
+            if (lane == 0) at = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(n_long), (unsigned long long)__popcll(lm));
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (v > 8u) long_list[at + __popcll(lm & (lane ? (~0ull >> (64 - lane)) : 0ull))] = (uint32_t)e;
+        }
     }
 }
 __device__ __forceinline__ void hgt_bucket_scatter_body(const int64_t *mc, const int64_t *__restrict__ cslot,
@@ -300,27 +309,155 @@ __device__ __forceinline__ void hgt_ce(uint32_t &x, uint32_t &y) {
     x = lo;
     y = hi;
 }
+// Wavefront-wide stable LSD radix sort of n positions (8-bit digits; equal digits keep their order through ballot matching)
+// between the arrays a and b; returns the one that holds the result.  `hist` = 256 words of this wavefront's LDS.
+template <bool IN_GLOBAL>
+__device__ __forceinline__ uint32_t *hgt_wave_radix_sort(uint32_t *a, uint32_t *b, uint32_t n, int pbits, uint32_t *hist) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (int shift = 0; shift < pbits; shift += 8) {
+        for (int i = lane; i < 256; i += 64) hist[i] = 0;
+        wave_lds_handoff();
+        for (uint32_t t0 = 0; t0 < n; t0 += 256) { // four tiles' loads in flight
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t0 + u * 64 + lane < n ? a[t0 + u * 64 + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u * 64 + lane < n) atomicAdd(&hist[(v[u] >> shift) & 255u], 1u);
+        }
+        wave_lds_handoff();
+        { // exclusive scan of the 256 digit counts, four per lane
+            const uint32_t x0 = hist[4 * lane], x1 = hist[4 * lane + 1], x2 = hist[4 * lane + 2], x3 = hist[4 * lane + 3];
+            const uint32_t sm = x0 + x1 + x2 + x3;
+            const uint32_t base = wave_inclusive_scan(sm) - sm;
+            wave_lds_handoff();
+            hist[4 * lane] = base;
+            hist[4 * lane + 1] = base + x0;
+            hist[4 * lane + 2] = base + x0 + x1;
+            hist[4 * lane + 3] = base + x0 + x1 + x2;
+        }
+        wave_lds_handoff();
+        uint32_t nxt = lane < n ? a[lane] : 0u;
+        for (uint32_t t0 = 0; t0 < n; t0 += 64) { // tiles in order; the next tile's load overlaps this tile's ranking
+            const bool valid = t0 + lane < n;
+            const uint32_t v = nxt;
+            if (t0 + 64 < n) nxt = t0 + 64 + lane < n ? a[t0 + 64 + lane] : 0u;
+            const uint32_t d = (v >> shift) & 255u;
+            uint64_t same = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (d >> bit) & 1u;
+                const uint64_t bal = __ballot(one);
+                same &= one ? bal : ~bal;
+            }
+            const uint32_t before = (uint32_t)__popcll(same & lt_mask), group = (uint32_t)__popcll(same);
+            const uint32_t at = hist[d];
+            wave_lds_handoff();
+            if (valid) {
+                b[at + before] = v;
+                if (before + 1 == group) hist[d] = at + group;
+            }
+            wave_lds_handoff();
+        }
+        if (IN_GLOBAL) { // the next pass reads what this one wrote
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        uint32_t *t = a;
+        a = b;
+        b = t;
+    }
+    return a;
+}
 // score += 1/deg in contribution order (:96), timestamp = the last contribution's (:97).  One lane per entry while its
 // bucket holds <= 8 positions (a 19-comparator network in registers; most entries hold 1-3); a longer bucket takes the
-// whole wavefront: up to 64 positions are ranked by counting in registers, more go through a wavefront-wide LSD radix
-// sort (8-bit digits, stable by ballot matching) between the bucket and its twin -- linear in the bucket's length, so a
-// hub that every sample points at costs its length, not its square.  The f64 sum itself stays left to right.
+// whole wavefront: up to 64 positions are ranked by counting in registers, more go through the radix sort above -- in
+// the wavefront's LDS up to HGT_RUN_LDS positions, between the bucket and its twin in global memory beyond -- linear in
+// the bucket's length, so a hub that every sample points at costs its length, not its square.  The f64 sum itself stays
+// left to right.
 constexpr int HGT_ACC_THREADS = 256;
+constexpr uint32_t HGT_RUN_LDS = 1024;
+constexpr int HGT_ACC_LONG_BLOCKS = 128; // workgroups at the end of accumulate's grid that take the long buckets
 __device__ __forceinline__ void hgt_accumulate_body(const HgtType &src, const uint32_t *__restrict__ bcnt,
                                                     const uint32_t *__restrict__ bwithin, const int64_t *__restrict__ trank,
                                                     uint32_t *bucket, uint32_t *bucket2, int64_t cap, int pbits,
-                                                    const double *__restrict__ cinv, const int64_t *__restrict__ cts) {
+                                                    const double *__restrict__ cinv, const int64_t *__restrict__ cts,
+                                                    const uint32_t *__restrict__ long_list, const int64_t *n_long) {
     __shared__ uint32_t hist_s[HGT_ACC_THREADS / 64][256];
     __shared__ uint32_t perm_s[HGT_ACC_THREADS / 64][64];
     __shared__ double sum_s[HGT_ACC_THREADS / 64][64];
+    __shared__ uint32_t run_s[HGT_ACC_THREADS / 64][2][HGT_RUN_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_s[wave], *perm = perm_s[wave];
     double *sbuf = sum_s[wave];
-    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const int64_t nbud = src.ctr->n_budget;
     const int64_t n_chunks = (min(cap, nbud) + 63) >> 6;
-    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks;
-         c += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t short_blocks = (int64_t)gridDim.x - HGT_ACC_LONG_BLOCKS;
+    if ((int64_t)blockIdx.x >= short_blocks) { // the long buckets, one wavefront each
+        const int64_t n_l = *n_long, stride = (int64_t)HGT_ACC_LONG_BLOCKS * (HGT_ACC_THREADS / 64);
+        for (int64_t i = ((int64_t)blockIdx.x - short_blocks) * (HGT_ACC_THREADS / 64) + wave; i < n_l; i += stride) {
+            const int64_t e2 = long_list[i];
+            const uint32_t L2 = bcnt[e2];
+            const uint32_t st2 = (uint32_t)trank[e2 >> 6] + bwithin[e2];
+            double score = src.bscore[e2];
+            uint32_t last = 0;
+            if (L2 <= 64) {
+                const uint32_t p = (uint32_t)lane < L2 ? bucket[st2 + lane] : 0xffffffffu;
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < L2; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)p, (int)j) < p ? 1u : 0u;
+                if ((uint32_t)lane < L2) perm[r] = p;
+                wave_lds_handoff();
+                const uint32_t ps = (uint32_t)lane < L2 ? perm[lane] : 0u;
+                const double cv = (uint32_t)lane < L2 ? cinv[ps] : 0.0;
+                double total;
+                (void)wave_serial_prefix_f64(cv, score, &total, sbuf); // x + 0.0 = x: the lanes past the bucket add nothing
+                score = total;
+                last = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(L2 - 1));
+            } else {
+                const uint32_t *sorted;
+                if (L2 <= HGT_RUN_LDS) {
+                    uint32_t *ra = run_s[wave][0], *rb = run_s[wave][1];
+                    for (uint32_t t0 = 0; t0 < L2; t0 += 256) {
+                        uint32_t v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = t0 + u * 64 + lane < L2 ? bucket[st2 + t0 + u * 64 + lane] : 0u;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (t0 + u * 64 + lane < L2) ra[t0 + u * 64 + lane] = v[u];
+                    }
+                    wave_lds_handoff();
+                    sorted = hgt_wave_radix_sort<false>(ra, rb, L2, pbits, hist);
+                } else {
+                    sorted = hgt_wave_radix_sort<true>(bucket + st2, bucket2 + st2, L2, pbits, hist);
+                }
+                for (uint32_t t0 = 0; t0 < L2; t0 += 256) { // four tiles' gathers in flight, then their sums in order
+                    uint32_t ps[4];
+                    double cv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool valid = t0 + u * 64 + lane < L2;
+                        ps[u] = valid ? sorted[t0 + u * 64 + lane] : 0u;
+                        cv[u] = valid ? cinv[ps[u]] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (t0 + u * 64 >= L2) break; // uniform
+                        double total;
+                        (void)wave_serial_prefix_f64(cv[u], score, &total, sbuf);
+                        score = total;
+                        if (t0 + u * 64 + 64 >= L2) last = (uint32_t)__builtin_amdgcn_readlane((int)ps[u], (int)(L2 - 1 - t0 - u * 64));
+                    }
+                }
+            }
+            if (lane == 0) {
+                src.bscore[e2] = score;
+                src.bts[e2] = cts[last];
+            }
+        }
+        return;
+    }
+    for (int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_chunks; c += (short_blocks * blockDim.x) >> 6) {
         const int64_t e = (c << 6) + lane;
         const uint32_t L = (e < nbud && e < cap) ? bcnt[e] : 0u;
         const uint32_t start = L ? (uint32_t)trank[c] + bwithin[e] : 0u;
@@ -349,88 +486,6 @@ __device__ __forceinline__ void hgt_accumulate_body(const HgtType &src, const ui
             src.bscore[e] = score;
             src.bts[e] = cts[last];
         }
-        uint64_t longm = __ballot(L > 8);
-        while (longm) { // wave-uniform: one long bucket at a time, all 64 lanes on it
-            const int owner = __ffsll((long long)longm) - 1;
-            longm &= longm - 1;
-            const int64_t e2 = (c << 6) + owner;
-            const uint32_t L2 = (uint32_t)__builtin_amdgcn_readlane((int)L, owner);
-            const uint32_t st2 = (uint32_t)__builtin_amdgcn_readlane((int)start, owner);
-            double score = src.bscore[e2];
-            uint32_t last = 0;
-            if (L2 <= 64) {
-                const uint32_t p = (uint32_t)lane < L2 ? bucket[st2 + lane] : 0xffffffffu;
-                uint32_t r = 0;
-                for (uint32_t j = 0; j < L2; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)p, (int)j) < p ? 1u : 0u;
-                if ((uint32_t)lane < L2) perm[r] = p;
-                wave_lds_handoff();
-                const uint32_t ps = (uint32_t)lane < L2 ? perm[lane] : 0u;
-                const double cv = (uint32_t)lane < L2 ? cinv[ps] : 0.0;
-                double total;
-                (void)wave_serial_prefix_f64(cv, score, &total, sbuf); // x + 0.0 = x: the lanes past the bucket add nothing
-                score = total;
-                last = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(L2 - 1));
-            } else {
-                uint32_t *a = bucket + st2, *b = bucket2 + st2;
-                for (int shift = 0; shift < pbits; shift += 8) {
-                    for (int i = lane; i < 256; i += 64) hist[i] = 0;
-                    wave_lds_handoff();
-                    for (uint32_t t0 = 0; t0 < L2; t0 += 64)
-                        if (t0 + lane < L2) atomicAdd(&hist[(a[t0 + lane] >> shift) & 255u], 1u);
-                    wave_lds_handoff();
-                    { // exclusive scan of the 256 digit counts, four per lane
-                        const uint32_t x0 = hist[4 * lane], x1 = hist[4 * lane + 1], x2 = hist[4 * lane + 2],
-                                       x3 = hist[4 * lane + 3];
-                        const uint32_t sm = x0 + x1 + x2 + x3;
-                        const uint32_t base = wave_inclusive_scan(sm) - sm;
-                        wave_lds_handoff();
-                        hist[4 * lane] = base;
-                        hist[4 * lane + 1] = base + x0;
-                        hist[4 * lane + 2] = base + x0 + x1;
-                        hist[4 * lane + 3] = base + x0 + x1 + x2;
-                    }
-                    wave_lds_handoff();
-                    for (uint32_t t0 = 0; t0 < L2; t0 += 64) { // tiles in order; equal digits keep their order (stable)
-                        const bool valid = t0 + lane < L2;
-                        const uint32_t v = valid ? a[t0 + lane] : 0u;
-                        const uint32_t d = (v >> shift) & 255u;
-                        uint64_t same = __ballot(valid);
-#pragma unroll
-                        for (int bit = 0; bit < 8; ++bit) {
-                            const bool one = (d >> bit) & 1u;
-                            const uint64_t bal = __ballot(one);
-                            same &= one ? bal : ~bal;
-                        }
-                        const uint32_t before = (uint32_t)__popcll(same & lt_mask), group = (uint32_t)__popcll(same);
-                        const uint32_t at = hist[d];
-                        wave_lds_handoff();
-                        if (valid) {
-                            b[at + before] = v;
-                            if (before + 1 == group) hist[d] = at + group;
-                        }
-                        wave_lds_handoff();
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the next pass reads what this one wrote
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    uint32_t *t = a;
-                    a = b;
-                    b = t;
-                }
-                for (uint32_t t0 = 0; t0 < L2; t0 += 64) {
-                    const bool valid = t0 + lane < L2;
-                    const uint32_t ps = valid ? a[t0 + lane] : 0u;
-                    const double cv = valid ? cinv[ps] : 0.0;
-                    double total;
-                    (void)wave_serial_prefix_f64(cv, score, &total, sbuf);
-                    score = total;
-                    if (t0 + 64 >= L2) last = (uint32_t)__builtin_amdgcn_readlane((int)ps, (int)(L2 - 1 - t0));
-                }
-            }
-            if (lane == 0) {
-                src.bscore[e2] = score;
-                src.bts[e2] = cts[last];
-            }
-        }
     }
 }
 
@@ -447,7 +502,7 @@ struct HgtStep {
     const int64_t *ptrs, *indices, *edge_ts;
     int64_t pad; // the source budget's capacity
     int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal, *tflag, *trank;
-    uint32_t *bcnt, *bwithin, *bcur, *bucket, *bucket2;
+    uint32_t *bcnt, *bwithin, *bcur, *bucket, *bucket2, *bucket3;
     double *cinv;
     uint64_t *cmask;
 };
@@ -468,6 +523,7 @@ __global__ void hgt_gen_steps_kernel(const HgtSteps S, int has_timerange, int64_
         a.bcnt[i] = 0;
         a.bcur[i] = 0;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[3] = 0; // long buckets listed
     hgt_contrib_gen_body(a.dst, a.src, a.ptrs, a.indices, a.edge_ts, has_timerange, tr_lo, tr_hi, a.ccnt, a.coff, cap, a.ckey,
                          a.cinv, a.cts);
 }
@@ -489,7 +545,7 @@ __global__ void hgt_new_slots_steps_kernel(const HgtSteps S, int64_t tmp_mask) {
 }
 __global__ void hgt_bucket_offsets_steps_kernel(const HgtSteps S) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_bucket_offsets_body(a.src, a.bcnt, a.pad, a.bwithin, a.tflag, a.scal + 1);
+    hgt_bucket_offsets_body(a.src, a.bcnt, a.pad, a.bwithin, a.tflag, a.scal + 1, a.bucket2, a.scal + 3);
 }
 __global__ void __launch_bounds__(SCAN1_THREADS) hgt_bucket_scan_steps_kernel(const HgtSteps S) {
     const HgtStep &a = S.s[blockIdx.y];
@@ -501,7 +557,8 @@ __global__ void hgt_bucket_scatter_steps_kernel(const HgtSteps S) {
 }
 __global__ void __launch_bounds__(HGT_ACC_THREADS) hgt_accumulate_steps_kernel(const HgtSteps S) {
     const HgtStep &a = S.s[blockIdx.y];
-    hgt_accumulate_body(a.src, a.bcnt, a.bwithin, a.trank, a.bucket, a.bucket2, a.pad, S.pbits, a.cinv, a.cts);
+    hgt_accumulate_body(a.src, a.bcnt, a.bwithin, a.trank, a.bucket, a.bucket3, a.pad, S.pbits, a.cinv, a.cts, a.bucket2,
+                        a.scal + 3);
 }
 
 // ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
@@ -817,7 +874,7 @@ static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 struct HgtStepScratch {
     int64_t *ccnt, *coff, *ckey, *cts, *cslot, *tmp_keys, *tmp_vals, *flag, *rank, *scal, *tflag, *trank;
-    uint32_t *bcnt, *bwithin, *bcur, *bucket, *bucket2;
+    uint32_t *bcnt, *bwithin, *bcur, *bucket, *bucket2, *bucket3;
     double *cinv;
     uint64_t *cmask;
 };
@@ -881,7 +938,7 @@ static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
         s.flag = i64(step_chunks);
         s.rank = i64(step_chunks);
         s.cmask = reinterpret_cast<uint64_t *>(i64(step_chunks));
-        s.scal = i64(8); // [0] contributions [1] new entries [2] kept contributions
+        s.scal = i64(8); // [0] contributions [1] new entries [2] kept contributions [3] long buckets
         const size_t budget_chunks = (size_t)(pl.max_budget / 64 + 3);
         s.tflag = i64(budget_chunks);
         s.trank = i64(budget_chunks);
@@ -889,7 +946,8 @@ static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
         s.bwithin = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.max_budget));
         s.bcur = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.max_budget));
         s.bucket = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap));
-        s.bucket2 = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap));
+        s.bucket2 = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap)); // the list of long buckets
+        s.bucket3 = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap)); // the radix sort's second array
     }
     B.live.assign((size_t)T, nullptr), B.chosen.assign((size_t)T, nullptr), B.lflag.assign((size_t)T, nullptr);
     B.lrank.assign((size_t)T, nullptr), B.lcmask.assign((size_t)T, nullptr), B.slots.assign((size_t)T, nullptr);
@@ -1073,6 +1131,7 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                 a.tmp_keys = sc.tmp_keys, a.tmp_vals = sc.tmp_vals, a.flag = sc.flag, a.rank = sc.rank;
                 a.scal = sc.scal, a.cinv = sc.cinv, a.cmask = sc.cmask, a.tflag = sc.tflag, a.trank = sc.trank;
                 a.bcnt = sc.bcnt, a.bwithin = sc.bwithin, a.bcur = sc.bcur, a.bucket = sc.bucket, a.bucket2 = sc.bucket2;
+                a.bucket3 = sc.bucket3;
             }
             S.pbits = 1;
             while (((int64_t)1 << S.pbits) < pl.mc_cap) ++S.pbits;
@@ -1097,7 +1156,8 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                     if (int rcs = library_scan(S.s[y].tflag, S.s[y].trank, (S.s[y].pad + 63) / 64, S.s[y].scal + 2)) return rcs;
             }
             hipLaunchKernelGGL(hgt_bucket_scatter_steps_kernel, g2(pl.mc_cap), dim3(256), 0, stream, S);
-            hipLaunchKernelGGL(hgt_accumulate_steps_kernel, g2(widest_budget), dim3(HGT_ACC_THREADS), 0, stream, S);
+            hipLaunchKernelGGL(hgt_accumulate_steps_kernel, dim3(grid_1d(widest_budget) + HGT_ACC_LONG_BLOCKS, Y),
+                               dim3(HGT_ACC_THREADS), 0, stream, S);
             TG_LAUNCH_CHECK();
         }
         return TG_OK;
