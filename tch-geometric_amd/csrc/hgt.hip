@@ -37,6 +37,7 @@
 #include "tg_host.h"
 #include "tg_scan.h"
 #include "tg_map.h"
+#define HGT_MULTI_TYPES_STAMPS 8
 
 namespace tg {
 
@@ -563,47 +564,77 @@ __global__ void __launch_bounds__(HGT_ACC_THREADS) hgt_accumulate_steps_kernel(c
 
 // ---------------------------------------------------------------- sample_from (hgt_sampling.rs:104-135)
 // The node types of a layer sample from their own budgets independently (:201-221): ONE launch per layer, one workgroup
-// per type, which (1) compacts the type's live budget entries in entry order -- per 64-entry chunk a bit mask and a
-// count, a scan over the counts, then every live entry's rank -- (2) runs the weighted reservoir below and (3) moves
+// per type, which (1) compacts the type's live budget entries in entry order -- every wavefront counts the live entries
+// of its run of chunks, then places them behind the earlier wavefronts' -- (2) runs the weighted reservoir below and (3) moves
 // the chosen entries to the node list.  The phases hand their arrays over through global memory inside the workgroup.
+// -DTG_HGT_STAMPS (an experiment build, not the product): thread 0 of every sample_from workgroup stamps the 100 MHz
+// wall clock at its phase boundaries; tg_hgt_sample prints the last layer's phase times of every type to stderr.
+#ifdef TG_HGT_STAMPS
+__device__ long long hgt_stamps[HGT_MULTI_TYPES_STAMPS][16];
+#define HGT_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) hgt_stamps[blockIdx.x][i] = (long long)wall_clock64();                                   \
+    } while (0)
+#else
+#define HGT_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+    } while (0)
+#endif
 __device__ __forceinline__ void hgt_wg_handoff() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-__device__ __forceinline__ void hgt_live_list_body(const HgtType &ty, int64_t *flag, int64_t *rank, uint64_t *cmask,
-                                                   int64_t *__restrict__ live, int64_t *n_live) {
+__device__ __forceinline__ void hgt_live_list_body(const HgtType &ty, int64_t *__restrict__ live, double *__restrict__ wlive,
+                                                   int64_t *n_live) {
+    __shared__ int64_t wave_live[SCAN1_THREADS / 64];
     const int64_t n = ty.ctr->n_budget;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const uint64_t lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
     const int64_t n_chunks = (n + 63) >> 6;
-    constexpr int U = 8; // chunks in flight per wavefront
-    for (int64_t c0 = (int64_t)wave * U; c0 < n_chunks; c0 += (int64_t)n_waves * U) {
-        int64_t alive[U];
+    const int64_t per = (n_chunks + n_waves - 1) / n_waves; // every wavefront takes a contiguous run of 64-entry chunks
+    const int64_t c_lo = min(n_chunks, (int64_t)wave * per), c_hi = min(n_chunks, c_lo + per);
+    int64_t mine = 0;
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += 16) { // its live entries, sixteen chunks' loads in flight
+        int64_t alive[16];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int64_t i = ((c0 + u) << 6) + lane;
-            alive[u] = (i < n) ? ty.balive[i] : 0;
+            alive[u] = (c0 + u < c_hi && i < n) ? ty.balive[i] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t m = __ballot(alive[u] != 0);
-            if (lane == 0 && c0 + u < n_chunks) {
-                cmask[c0 + u] = m;
-                flag[c0 + u] = __popcll(m);
-            }
-        }
+        for (int u = 0; u < 16; ++u) mine += alive[u] != 0;
     }
-    hgt_wg_handoff();
-    block_scan_exclusive_plus1(n_chunks, [&](int64_t c) { return flag[c]; }, rank);
-    hgt_wg_handoff();
-    if (tid == 0) *n_live = rank[n_chunks];
-    for (int64_t i0 = (int64_t)tid * 4; i0 < n; i0 += (int64_t)blockDim.x * 4) { // one chunk mask covers a lane's 4 entries
-        const uint64_t m = cmask[i0 >> 6];
-        const int64_t r0 = rank[i0 >> 6];
+    mine = wave_sum(mine);
+    if (lane == 0) wave_live[wave] = mine;
+    __syncthreads();
+    int64_t at = 0, all = 0;
+    for (int w = 0; w < n_waves; ++w) {
+        if (w < wave) at += wave_live[w];
+        all += wave_live[w];
+    }
+    if (tid == 0) *n_live = all;
+    HGT_STAMP(1);
+    HGT_STAMP(2);
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += 8) { // second sweep: every live entry's place and weight, in entry order
+        int64_t alive[8];
+        double sc[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int q = (int)((i0 + u) & 63);
-            if ((m >> q) & 1ull) live[r0 + __popcll(q ? (m & (~0ull >> (64 - q))) : 0ull)] = i0 + u;
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = ((c0 + u) << 6) + lane;
+            const bool in = c0 + u < c_hi && i < n;
+            alive[u] = in ? ty.balive[i] : 0;
+            sc[u] = in ? ty.bscore[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t m = __ballot(alive[u] != 0);
+            if (alive[u] != 0) {
+                const int64_t r = at + __popcll(m & lt_mask);
+                live[r] = ((c0 + u) << 6) + lane;
+                wlive[r] = sc[u] * sc[u]; // the reservoir's weight (:104-110)
+            }
+            at += __popcll(m);
         }
     }
     hgt_wg_handoff();
@@ -619,7 +650,8 @@ constexpr int64_t HGT_LDS_SLOTS = 8192; // samples per layer whose slot tables f
 __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int64_t *n_live_ptr,
                                                    const int64_t *__restrict__ live, int64_t k, uint64_t seed,
                                                    uint64_t call_id, uint64_t draw_id, int64_t *chosen, int64_t *n_chosen,
-                                                   int *panic, unsigned char *smem, double *carries, uint32_t *slots_global) {
+                                                   int *panic, unsigned char *smem, double *carries, uint32_t *slots_global,
+                                                   const double *__restrict__ wlive) {
     // slot table: LDS up to 8192 samples per layer, the caller's global scratch beyond
     uint32_t *slot_rank = (k > HGT_LDS_SLOTS) ? slots_global : reinterpret_cast<uint32_t *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
@@ -644,52 +676,78 @@ __device__ __forceinline__ void hgt_reservoir_body(const HgtType &ty, const int6
     };
     const int64_t nc = (n + 63) >> 6;
     for (int64_t s = tid; s < k; s += blockDim.x) slot_rank[s] = 0;
-    for (int64_t c = wave; c < nc; c += n_waves) { // (A) chunk totals
-        const int64_t m = c * 64 + lane;
-        double wv = 0.0;
-        if (m < n) {
-            const double sc = ty.bscore[live[m]];
-            wv = sc * sc;
+    constexpr int U = 4; // chunks in flight per wavefront
+    HGT_STAMP(3);
+    for (int64_t c0 = (int64_t)wave * U; c0 < nc; c0 += (int64_t)n_waves * U) { // (A) weights and chunk totals
+        double wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = (c0 + u) * 64 + lane;
+            wv[u] = m < n ? wlive[m] : 0.0;
         }
-        double tot;
-        (void)wave_blocked_prefix_f64(wv, 0.0, &tot);
-        if (lane == 0) carries[c] = tot;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (tid == 0) { // (B) carries[c] = sum of the totals before chunk c, added left to right
-        double run = 0.0;
-        for (int64_t c = 0; c < nc; ++c) {
-            const double t = carries[c];
-            carries[c] = run;
-            run = run + t;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u >= nc) break; // uniform
+            double tot;
+            (void)wave_blocked_prefix_f64(wv[u], 0.0, &tot);
+            if (lane == 0) carries[c0 + u] = tot;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int64_t c = wave; c < nc; c += n_waves) { // (C) draws
-        const int64_t m = c * 64 + lane;
-        const bool ok = m < n;
-        double wv = 0.0;
-        if (ok) {
-            const double sc = ty.bscore[live[m]];
-            wv = sc * sc;
+    hgt_wg_handoff();
+    HGT_STAMP(4);
+    { // (B) carries[c] = sum of the totals before chunk c, added left to right: tiles of 1024 totals through LDS, one lane
+      // runs the dependent adds (the LDS reads pipeline ahead of them)
+        __shared__ double tile_s[1024];
+        __shared__ double run_s;
+        if (tid == 0) run_s = 0.0;
+        for (int64_t c0 = 0; c0 < nc; c0 += 1024) {
+            const int64_t c = c0 + tid;
+            if (tid < 1024 && c < nc) tile_s[tid] = carries[c];
+            __syncthreads();
+            if (tid == 0) {
+                double run = run_s;
+                const int cnt_t = (int)min((int64_t)1024, nc - c0);
+                for (int i = 0; i < cnt_t; ++i) {
+                    const double t = tile_s[i];
+                    tile_s[i] = run;
+                    run = run + t;
+                }
+                run_s = run;
+            }
+            __syncthreads();
+            if (tid < 1024 && c < nc) carries[c] = tile_s[tid];
+            __syncthreads();
         }
-        double tot;
-        const double pref = wave_blocked_prefix_f64(wv, carries[c], &tot); // blocked running sum, sampling.rs:40,48
-        if (ok && m >= k) {
-            if (!(0.0 < pref)) {
-                *panic = 1;
-            } else {
-                const Draw d = draw(ck, draw_id, (uint32_t)m, D1_WEIGHTED);
-                const double j = u64_to_f64_01(d.a()) * pref + 0.0;
-                if (j < wv) atomicMax(&slot_rank[bounded64(d.b(), (uint64_t)k)], (uint32_t)m);
+    }
+    hgt_wg_handoff();
+    HGT_STAMP(5);
+    for (int64_t c0 = (int64_t)wave * U; c0 < nc; c0 += (int64_t)n_waves * U) { // (C) draws
+        double wv[U], cr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = (c0 + u) * 64 + lane;
+            wv[u] = m < n ? wlive[m] : 0.0;
+            cr[u] = c0 + u < nc ? carries[c0 + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u >= nc) break; // uniform
+            const int64_t m = (c0 + u) * 64 + lane;
+            double tot;
+            const double pref = wave_blocked_prefix_f64(wv[u], cr[u], &tot); // blocked running sum, sampling.rs:40,48
+            if (m < n && m >= k) {
+                if (!(0.0 < pref)) {
+                    *panic = 1;
+                } else {
+                    const Draw d = draw(ck, draw_id, (uint32_t)m, D1_WEIGHTED);
+                    const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                    if (j < wv[u]) atomicMax(&slot_rank[bounded64(d.b(), (uint64_t)k)], (uint32_t)m);
+                }
             }
         }
     }
     block_handoff();
+    HGT_STAMP(6);
     const int64_t cnt = min(n, k); // (D)  (m >= k >= 1, so a rank of 0 means "never hit": the slot keeps entry s, :37-45)
     for (int64_t s = tid; s < cnt; s += blockDim.x) {
         const uint32_t r = gslots ? __atomic_load_n(&slot_rank[s], __ATOMIC_RELAXED) : slot_rank[s];
@@ -721,22 +779,23 @@ constexpr int HGT_MULTI_TYPES = 8; // node types per launch (more types: more la
 struct HgtSampleArgs {
     HgtType ty[HGT_MULTI_TYPES];
     int64_t *n_live[HGT_MULTI_TYPES], *live[HGT_MULTI_TYPES], *chosen[HGT_MULTI_TYPES], *n_chosen[HGT_MULTI_TYPES];
-    int64_t *flag[HGT_MULTI_TYPES], *rank[HGT_MULTI_TYPES];
-    uint64_t *cmask[HGT_MULTI_TYPES];
     int64_t k[HGT_MULTI_TYPES];
     uint32_t *slots[HGT_MULTI_TYPES];
-    double *carries[HGT_MULTI_TYPES];
+    double *carries[HGT_MULTI_TYPES], *wlive[HGT_MULTI_TYPES];
 };
 __global__ void __launch_bounds__(SCAN1_THREADS)
     hgt_sample_layer_kernel(const HgtSampleArgs a, uint64_t seed, uint64_t call_id, int64_t layer, int first_type, int n_types,
                             int *panic) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int t = blockIdx.x;
-    hgt_live_list_body(a.ty[t], a.flag[t], a.rank[t], a.cmask[t], a.live[t], a.n_live[t]);
+    HGT_STAMP(0);
+    hgt_live_list_body(a.ty[t], a.live[t], a.wlive[t], a.n_live[t]);
     hgt_reservoir_body(a.ty[t], a.n_live[t], a.live[t], a.k[t], seed, call_id, (uint64_t)(layer * n_types + first_type + t),
-                       a.chosen[t], a.n_chosen[t], panic, smem, a.carries[t], a.slots[t]);
+                       a.chosen[t], a.n_chosen[t], panic, smem, a.carries[t], a.slots[t], a.wlive[t]);
     hgt_wg_handoff();
+    HGT_STAMP(7);
     hgt_append_body(a.ty[t], a.live[t], a.chosen[t], a.n_chosen[t]);
+    HGT_STAMP(8);
 }
 // empty type tables and zeroed counters, all types of a call in one launch
 struct HgtInitArgs {
@@ -888,10 +947,9 @@ struct HgtBuffers {
     int *panic;
     std::vector<HgtType> ty;
     HgtStepScratch sc[HGT_MAX_PAR];
-    std::vector<int64_t *> live, chosen, lflag, lrank;
-    std::vector<uint64_t *> lcmask;
+    std::vector<int64_t *> live, chosen;
     std::vector<uint32_t *> slots;
-    std::vector<double *> carries;
+    std::vector<double *> carries, wlive;
     int64_t *n_live, *n_chosen;
     std::vector<HgtEdgeScratch> ed;
     void *scan_temp;
@@ -949,18 +1007,16 @@ static size_t hgt_carve(const HgtPlan &pl, unsigned char *base, HgtBuffers &B) {
         s.bucket2 = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap)); // the list of long buckets
         s.bucket3 = reinterpret_cast<uint32_t *>(take(4 * (size_t)pl.mc_cap)); // the radix sort's second array
     }
-    B.live.assign((size_t)T, nullptr), B.chosen.assign((size_t)T, nullptr), B.lflag.assign((size_t)T, nullptr);
-    B.lrank.assign((size_t)T, nullptr), B.lcmask.assign((size_t)T, nullptr), B.slots.assign((size_t)T, nullptr);
+    B.live.assign((size_t)T, nullptr), B.chosen.assign((size_t)T, nullptr), B.slots.assign((size_t)T, nullptr);
     B.carries.assign((size_t)T, nullptr);
+    B.wlive.assign((size_t)T, nullptr);
     for (int t = 0; t < T; ++t) {
         const size_t chunks = (size_t)(pl.cap_budget[t] / 64 + 3);
         B.live[(size_t)t] = i64((size_t)pl.cap_budget[t]);
         B.chosen[(size_t)t] = i64((size_t)pl.max_k);
         B.slots[(size_t)t] = reinterpret_cast<uint32_t *>(i64((size_t)pl.max_k));
         B.carries[(size_t)t] = reinterpret_cast<double *>(i64(chunks));
-        B.lflag[(size_t)t] = i64(chunks);
-        B.lrank[(size_t)t] = i64(chunks);
-        B.lcmask[(size_t)t] = reinterpret_cast<uint64_t *>(i64(chunks));
+        B.wlive[(size_t)t] = reinterpret_cast<double *>(i64((size_t)pl.cap_budget[t]));
     }
     B.n_live = i64(2 * (size_t)T);
     B.n_chosen = B.n_live ? B.n_live + T : nullptr;
@@ -1191,9 +1247,8 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
                 const size_t t = (size_t)(t0 + i);
                 sa.ty[i] = ty[t];
                 sa.n_live[i] = B.n_live + t, sa.live[i] = B.live[t], sa.chosen[i] = B.chosen[t], sa.n_chosen[i] = B.n_chosen + t;
-                sa.flag[i] = B.lflag[t], sa.rank[i] = B.lrank[t], sa.cmask[i] = B.lcmask[t];
                 sa.k[i] = pb->num_samples[t * (size_t)H + (size_t)layer];
-                sa.slots[i] = B.slots[t], sa.carries[i] = B.carries[t];
+                sa.slots[i] = B.slots[t], sa.carries[i] = B.carries[t], sa.wlive[i] = B.wlive[t];
                 if (sa.k[i] > 0 && sa.k[i] <= HGT_LDS_SLOTS) lds = std::max(lds, (size_t)sa.k[i] * 4);
             }
             hipLaunchKernelGGL(hgt_sample_layer_kernel, dim3((unsigned)n), dim3(SCAN1_THREADS), lds, stream, sa, rng->seed,
@@ -1238,5 +1293,18 @@ extern "C" int tg_hgt_sample(const tg_hgt_problem *pb, const tg_rng *rng, const 
     }
     hipLaunchKernelGGL(hgt_finish_kernel, dim3(1), dim3(256), 0, stream, ctr, T, out->n_samples, panic, out->panic);
     TG_LAUNCH_CHECK();
+#ifdef TG_HGT_STAMPS
+    {
+        long long st[HGT_MULTI_TYPES_STAMPS][16];
+        TG_HIP(hipStreamSynchronize(stream));
+        TG_HIP(hipMemcpyFromSymbol(st, HIP_SYMBOL(hgt_stamps), sizeof(st)));
+        static const char *names[8] = {"flags", "scan", "list", "A", "B", "C", "D", "append"};
+        for (int t = 0; t < T && t < HGT_MULTI_TYPES_STAMPS; ++t) {
+            fprintf(stderr, "hgt stamps type %d:", t);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f us", names[i], (double)(st[t][i + 1] - st[t][i]) * 0.01);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return TG_OK;
 }
