@@ -11,23 +11,22 @@
 //  update_budget        per relation into the sampled type: contributions (sample j, neighbour i < 50,
 //                       hgt_sampling.rs:72 takes a PREFIX of the column) are generated in the reference's
 //                       order; new keys get entries in first-contribution order (min-position hash map +
-//                       prefix sum); scores are summed per entry in contribution order after a stable
-//                       radix sort by entry (rocPRIM) -- same f64 rounding as the reference's `+=` chain
-//  sample_from          live entries compacted in entry order, then the reference's weighted reservoir
-//                       (sampling.rs:28-55) by one wavefront: left-to-right f64 running sum kept exactly,
-//                       one addressed Philox draw per candidate
-//  edges                lane per destination node: <= 50 column positions (reservoir by tickets when the
-//                       column is longer), kept when the source is a sampled node; compaction by prefix sum
+//                       prefix sum); every entry's contributions are collected in a bucket (count, offsets,
+//                       scatter) and put in contribution order inside one lane / one wavefront as they are
+//                       summed -- same f64 rounding as the reference's `+=` chain.  Relations that feed
+//                       different budgets run side by side (blockIdx.y)
+//  sample_from          one workgroup per node type, one launch per layer: live entries compacted in entry
+//                       order, the reference's weighted reservoir (sampling.rs:28-55) with philox-mode's
+//                       blocked running sum, one addressed Philox draw per candidate, then the append
+//  edges                wavefront per destination node: <= 50 column positions (reservoir by tickets when the
+//                       column is longer), kept when the source is a sampled node; compaction by prefix sum;
+//                       the relations side by side (blockIdx.y)
 //
 // Canonical order: node types in `node_types` order, relations in `edge_types` order (the reference's
-// HashMap order is not reproducible).  HBM traffic is tiny next to neighbor sampling; this path is
-// launch-bound (~100 small kernels per call).
+// HashMap order is not reproducible).  HBM traffic is tiny next to neighbor sampling; this path is bound by the
+// LENGTH of its chain of launches (48 for 3 node types / 5 relations / 2 layers), which is why steps share launches.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -62,36 +61,7 @@ struct HgtType {
     HgtTypeCtr *ctr;
 };
 
-// ---------------------------------------------------------------- generic single-workgroup scan
-// out[i] = sum of in[0..i), total[0] = sum of in[0..n) (+ *add_to if given: total accumulates)
-__device__ __forceinline__ void scan_i64_body(const int64_t *__restrict__ in, const int64_t *n_ptr, int64_t n_imm,
-                                              int64_t *out, int64_t *total) {
-    __shared__ int64_t wave_tot[16];
-    __shared__ int64_t carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    const int64_t n = n_ptr ? *n_ptr : n_imm;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += blockDim.x) {
-        const int64_t i = base + tid;
-        const int64_t v = (i < n) ? in[i] : 0;
-        const int64_t incl = wave_inclusive_scan(v);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int64_t off = carry_s;
-        for (int w = 0; w < wave; ++w) off += wave_tot[w];
-        if (i < n) out[i] = off + incl - v;
-        __syncthreads();
-        if (tid == 0) {
-            int64_t s = 0;
-            for (int w = 0; w < n_waves; ++w) s += wave_tot[w];
-            carry_s += s;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) total[0] = carry_s;
-}
-
+// ---------------------------------------------------------------- small scans and fills
 // total of a flag array after its exclusive scan
 // exclusive scan of flag[0 .. n) into rank[0 .. n] (rank[n] = the total, also written to *total) in one launch of one
 // workgroup (tg_scan.h): the scans of a call are short and the call is bound by its number of launches
@@ -100,19 +70,12 @@ __device__ __forceinline__ void hgt_scan1_body(const int64_t *__restrict__ flag,
     __syncthreads();
     if (threadIdx.x == 0) total[0] = rank[n];
 }
-__global__ void __launch_bounds__(SCAN1_THREADS) hgt_scan1_kernel(const int64_t *__restrict__ flag, int64_t n, int64_t *rank,
-                                                                  int64_t *total) {
-    hgt_scan1_body(flag, n, rank, total);
-}
 __device__ __forceinline__ void fill2_i64_body(int64_t *a, int64_t na, int64_t va, int64_t *b, int64_t nb, int64_t vb) {
     const int64_t n = na > nb ? na : nb;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < na) a[i] = va;
         if (i < nb) b[i] = vb;
     }
-}
-__global__ void fill2_i64_kernel(int64_t *a, int64_t na, int64_t va, int64_t *b, int64_t nb, int64_t vb) {
-    fill2_i64_body(a, na, va, b, nb, vb);
 }
 __global__ void scan_total_kernel(const int64_t *__restrict__ in, const int64_t *__restrict__ excl, int64_t n,
                                   int64_t *total) {
