@@ -26,6 +26,7 @@
 #include "tg_device.h"
 #include "tg_host.h"
 #include "tg_map.h"
+#include "tg_scan.h"
 
 namespace tg {
 
@@ -135,22 +136,44 @@ __global__ void neg_insert_items_kernel(NegRelTable tab, int dst_type, const int
 //  mode 0: flag = item targets dst_type, is not an input, and holds its node's minimum position (first sight)
 //  mode 1: flag = item accepted and of relation `sel`
 // rank[p] is written for flagged items; total[0] receives the flag count.
+__device__ __forceinline__ int64_t neg_flag_of(const NegRelTable &tab, int mode, int sel, const int64_t *__restrict__ cand,
+                                               const int32_t *__restrict__ rel_of, const int64_t *__restrict__ ids,
+                                               const int64_t *new_keys, const int64_t *new_vals, int64_t new_mask, int64_t p) {
+    int64_t f = 0;
+    const int64_t w = cand[p];
+    if (w >= 0) {
+        if (mode == 1) {
+            f = rel_of[p] == sel;
+        } else if (tab.r[rel_of[p]].dst_type == sel && ids[p] < 0) {
+            const int64_t t = map_slot_find(new_keys, new_mask, w);
+            f = (t >= 0 && new_vals[t] == p);
+        }
+    }
+    return f;
+}
 __global__ void neg_flag_kernel(NegRelTable tab, int mode, int sel, const int64_t *__restrict__ cand,
                                 const int32_t *__restrict__ rel_of, const int64_t *__restrict__ ids, int64_t begin,
                                 int64_t end, const int64_t *new_keys, const int64_t *new_vals, int64_t new_mask,
                                 int64_t *flag) {
-    for (int64_t p = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < end; p += (int64_t)gridDim.x * blockDim.x) {
-        int64_t f = 0;
-        const int64_t w = cand[p];
-        if (w >= 0) {
-            if (mode == 1) {
-                f = rel_of[p] == sel;
-            } else if (tab.r[rel_of[p]].dst_type == sel && ids[p] < 0) {
-                const int64_t t = map_slot_find(new_keys, new_mask, w);
-                f = (t >= 0 && new_vals[t] == p);
-            }
-        }
-        flag[p] = f;
+    for (int64_t p = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < end; p += (int64_t)gridDim.x * blockDim.x)
+        flag[p] = neg_flag_of(tab, mode, sel, cand, rel_of, ids, new_keys, new_vals, new_mask, p);
+}
+// the same for a short item range in ONE launch of one workgroup: flags, their ranks (rank[begin .. end], one word past
+// the range is written too) and the total, also stored where the caller reports it
+__global__ void __launch_bounds__(SCAN1_THREADS)
+    neg_rank1_kernel(NegRelTable tab, int mode, int sel, const int64_t *__restrict__ cand, const int32_t *__restrict__ rel_of,
+                     const int64_t *__restrict__ ids, int64_t begin, int64_t end, const int64_t *new_keys,
+                     const int64_t *new_vals, int64_t new_mask, int64_t *rank, int64_t *total, int64_t total_add,
+                     int64_t *report) {
+    block_scan_exclusive_plus1(
+        end - begin,
+        [&](int64_t i) { return neg_flag_of(tab, mode, sel, cand, rel_of, ids, new_keys, new_vals, new_mask, begin + i); },
+        rank + begin);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t t = rank[end] + total_add;
+        total[0] = t;
+        report[0] = t;
     }
 }
 // total[0] = number of flagged items in [begin, end) + total_add, from the exclusive scan `rank` of `flag`
@@ -206,7 +229,7 @@ extern "C" int tg_neg_workspace_bytes(const tg_neg_problem *pb, int64_t *bytes) 
     hipError_t e = rocprim::exclusive_scan(nullptr, scan_temp, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0,
                                            (size_t)(m > 0 ? m : 1), rocprim::plus<int64_t>(), (hipStream_t)0, false);
     if (e != hipSuccess) return tg::fail(TG_ERR_HIP, "rocprim::exclusive_scan size query failed: %s", hipGetErrorString(e));
-    *bytes = 8 * (5 * m + 2 * in_cap + 2 * new_cap + 8) + ((4 * m + 15) & ~(int64_t)15) + 64 + (int64_t)((scan_temp + 15) & ~(size_t)15) + 512;
+    *bytes = 8 * (5 * m + 2 + 2 * in_cap + 2 * new_cap + 8) + ((4 * m + 15) & ~(int64_t)15) + 64 + (int64_t)((scan_temp + 15) & ~(size_t)15) + 512;
     return TG_OK;
 }
 
@@ -233,8 +256,8 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
     }
     const int64_t in_cap = pow2_at_least(2 * max_in + 2), new_cap = pow2_at_least(2 * m + 2);
     int64_t *ws = reinterpret_cast<int64_t *>(workspace);
-    int64_t *cand = ws, *ids = cand + m, *rank = ids + m, *erank = rank + m;
-    int64_t *in_keys = erank + m, *in_vals = in_keys + in_cap, *new_keys = in_vals + in_cap, *new_vals = new_keys + new_cap;
+    int64_t *cand = ws, *ids = cand + m, *rank = ids + m, *erank = rank + m + 1; // one word of slack behind either rank array
+    int64_t *in_keys = erank + m + 1, *in_vals = in_keys + in_cap, *new_keys = in_vals + in_cap, *new_vals = new_keys + new_cap;
     int64_t *totals = new_vals + new_cap; // [0] scratch total
     int *panic = reinterpret_cast<int *>(totals + 4);
     int32_t *rel_of = reinterpret_cast<int32_t *>(totals + 8);
@@ -244,13 +267,20 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
     TG_HIP(rocprim::exclusive_scan(nullptr, scan_temp_bytes, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0,
                                    (size_t)(m > 0 ? m : 1), rocprim::plus<int64_t>(), stream, false));
     // ranks of the flagged items of [b, e) (device-wide: flag kernel + rocPRIM scan), their count (+ add) into total
-    auto ranks_of = [&](int mode, int sel, int64_t b, int64_t e, int64_t *rank_out, int64_t *total, int64_t add) -> int {
+    auto ranks_of = [&](int mode, int sel, int64_t b, int64_t e, int64_t *rank_out, int64_t *total, int64_t add,
+                        int64_t *report) -> int {
+        if (e - b <= 16384) { // one workgroup beats flag kernel + the library's scan + the total up to about here
+            hipLaunchKernelGGL(neg_rank1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, tab, mode, sel, cand, rel_of, ids, b, e,
+                               new_keys, new_vals, new_cap - 1, rank_out, total, add, report);
+            return TG_OK;
+        }
         hipLaunchKernelGGL(neg_flag_kernel, dim3(grid_1d(e - b)), dim3(256), 0, stream, tab, mode, sel, cand, rel_of, ids, b,
                            e, new_keys, new_vals, new_cap - 1, flag);
         size_t stb = scan_temp_bytes;
         TG_HIP(rocprim::exclusive_scan(scan_temp, stb, flag + b, rank_out + b, (int64_t)0, (size_t)(e - b),
                                        rocprim::plus<int64_t>(), stream, false));
         hipLaunchKernelGGL(neg_total_kernel, dim3(1), dim3(1), 0, stream, flag, rank_out, b, e, total, add);
+        TG_HIP(hipMemcpyAsync(report, total, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
         return TG_OK;
     };
     TG_HIP(hipMemsetAsync(panic, 0, sizeof(int), stream));
@@ -286,14 +316,13 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
         if (m > 0) {
             hipLaunchKernelGGL(neg_insert_items_kernel, dim3(grid_1d(m)), dim3(256), 0, stream, tab, dt, cand, rel_of,
                                m, in_keys, in_vals, in_cap - 1, new_keys, new_vals, new_cap - 1, ids);
-            if (int rcs = ranks_of(0, dt, 0, m, rank, totals, n_in)) return rcs;
+            if (int rcs = ranks_of(0, dt, 0, m, rank, totals, n_in, out->n_samples + dt)) return rcs;
             hipLaunchKernelGGL(neg_assign_ids_kernel, dim3(grid_1d(m)), dim3(256), 0, stream, tab, dt, cand, rel_of, m,
                                n_in, new_keys, new_vals, new_cap - 1, rank, ids, out->samples[dt]);
         } else {
-            hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, stream, totals, (int64_t)1, n_in);
+            hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(64), 0, stream, out->n_samples + dt, (int64_t)1, n_in);
         }
-        // n_samples[dt] = n_in + number of first sights
-        TG_HIP(hipMemcpyAsync(out->n_samples + dt, totals, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+        // n_samples[dt] = n_in + number of first sights (reported by ranks_of)
         TG_LAUNCH_CHECK();
     }
     // ---- 3. edges per relation, in item order
@@ -301,13 +330,12 @@ extern "C" int tg_neg_sample(const tg_neg_problem *pb, const tg_rng *rng, const 
         const int t = pb->rel_src[r];
         const int64_t b = item_begin[t], e = item_begin[t + 1];
         if (e > b) {
-            if (int rcs = ranks_of(1, r, b, e, erank, totals + 1, 0)) return rcs;
+            if (int rcs = ranks_of(1, r, b, e, erank, totals + 1, 0, out->n_edges + r)) return rcs;
             hipLaunchKernelGGL(neg_emit_edges_kernel, dim3(grid_1d(e - b)), dim3(256), 0, stream, r, cand, rel_of, ids,
                                erank, b, e, pb->num_neg, out->rows[r], out->cols[r]);
         } else {
-            TG_HIP(hipMemsetAsync(totals + 1, 0, sizeof(int64_t), stream));
+            TG_HIP(hipMemsetAsync(out->n_edges + r, 0, sizeof(int64_t), stream));
         }
-        TG_HIP(hipMemcpyAsync(out->n_edges + r, totals + 1, sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
         TG_LAUNCH_CHECK();
     }
     TG_HIP(hipMemcpyAsync(out->panic, panic, sizeof(int), hipMemcpyDeviceToDevice, stream));

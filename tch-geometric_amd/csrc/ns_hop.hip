@@ -14,6 +14,7 @@
 #include "ns_tickets.h"
 #include "tg_device.h"
 #include "tg_host.h"
+#include "tg_scan.h"
 
 namespace tg {
 
@@ -52,6 +53,25 @@ __global__ void hop_count_kernel(const HopParams p) {
         p.cnt[i] = c;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) p.offsets[0] = 0;
+}
+
+// short frontiers (a per-call hop is a few thousand vertices): counts and their prefix in ONE launch of one workgroup
+// instead of a count kernel + the library's scan launches
+__global__ void __launch_bounds__(SCAN1_THREADS) hop_count_scan1_kernel(const HopParams p) {
+    block_scan_exclusive_plus1(
+        p.m,
+        [&](int64_t i) {
+            const int64_t w = p.vertices[i];
+            int64_t c = 0;
+            if (w >= 0) {
+                int64_t e0, deg;
+                hop_range(p, w, e0, deg);
+                c = (deg <= 0) ? 0 : (p.replace ? (int64_t)p.k : min(deg, (int64_t)p.k));
+            }
+            p.cnt[i] = c;
+            return c;
+        },
+        p.offsets);
 }
 
 template <int KMAX>
@@ -253,17 +273,21 @@ extern "C" int tg_ns_hop(const tg_graph *csc, const tg_hop_in *in, const tg_rng 
         return TG_OK;
     }
     TG_REQUIRE(in->vertices && out->neighbors && out->edge_ptrs && out->parents && workspace, "tg_ns_hop: null buffers");
-    int64_t g = (p.m + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(hop_count_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);
-    size_t need = 0;
-    TG_HIP(rocprim::inclusive_scan(nullptr, need, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
-                                   false));
-    TG_REQUIRE((size_t)workspace_bytes >= need, "tg_ns_hop: workspace too small (%lld < %zu)", (long long)workspace_bytes,
-               need);
-    size_t st = (size_t)workspace_bytes;
-    TG_HIP(rocprim::inclusive_scan(workspace, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
-                                   false));
+    if (p.m <= 16384) { // one workgroup beats count + the library's launches up to about here (measured with HGT's scans)
+        hipLaunchKernelGGL(hop_count_scan1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+    } else {
+        int64_t g = (p.m + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(hop_count_kernel, dim3((unsigned)g), dim3(256), 0, stream, p);
+        size_t need = 0;
+        TG_HIP(rocprim::inclusive_scan(nullptr, need, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
+                                       false));
+        TG_REQUIRE((size_t)workspace_bytes >= need, "tg_ns_hop: workspace too small (%lld < %zu)", (long long)workspace_bytes,
+                   need);
+        size_t st = (size_t)workspace_bytes;
+        TG_HIP(rocprim::inclusive_scan(workspace, st, p.cnt, p.offsets + 1, (size_t)p.m, rocprim::plus<int64_t>(), stream,
+                                       false));
+    }
     if (p.k <= 16) return launch_hop_emit<16>(p, stream);
     if (p.k <= TG_MAX_FANOUT) return launch_hop_emit<32>(p, stream);
     if (p.k <= 128) return launch_hop_emit<0>(p, stream); // LDS ticket strips, lane per vertex
