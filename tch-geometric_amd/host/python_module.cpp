@@ -332,7 +332,9 @@ NsResult run_ns(const c10::Device &dev, const Tensor &ptrs, const Tensor &indice
     // fan-out above 128 (the batched kernel keeps its ticket strips in LDS; tg_ns_hop takes up to 4096)
     int64_t max_k = 1;
     for (int64_t k : fanout) max_k = std::max(max_k, k);
-    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || seeds.numel() > 2048 || max_k > 128) {
+    // ... or more hops than the one-launch kernel's TG_MAX_HOPS (the reference takes any number: neighbor_sampling.rs:188)
+    if (f.mode != TG_FILTER_NONE || s.kind == TG_SAMPLER_WEIGHTED || seeds.numel() > 2048 || max_k > 128 ||
+        fanout.size() > (size_t)TG_MAX_HOPS) {
         return run_ns_filtered_flat(dev, ptrs, indices, weights, timestamps, seeds, seeds_state, fanout, s, f, rng, tag,
                                     id_base, unchecked_seeds);
     }

@@ -3,11 +3,11 @@
 Tensors are int64 unless noted; they may live on a HIP device (adjacency stays resident in HBM) or on
 the CPU (uploaded per call).  Relation dicts are keyed "src__rel__dst" (neighbor_sampling.rs:257).
 
-Limits the reference does not have (each raises ValueError): at most 8 hops (TG_MAX_HOPS); per-hop fan-out at most
-4096 for the unweighted, unfiltered samplers and at most 1024 under a temporal filter or the weighted sampler (the
-C ABI's batched launch tg_ns_homo_batched takes fan-outs up to 255: the operators route larger ones to the flat
-per-hop kernels); heterogeneous sampling at most 8 node types / 16 relations in the fused launch (more fall back to one
-launch per relation and hop)."""
+Limits the reference does not have: per-hop fan-out at most 4096 for the unweighted, unfiltered samplers and at most
+1024 under a temporal filter or the weighted sampler (ValueError beyond; the C ABI's batched launch tg_ns_homo_batched
+takes fan-outs up to 255 and 8 hops, TG_MAX_HOPS: the operators route larger fan-outs to the flat per-hop kernels and
+deeper calls hop by hop); heterogeneous sampling at most 8 node types / 16 relations in the fused launch (more fall back
+to one launch per relation and hop)."""
 from typing import Dict, List, Optional, Tuple, Union
 
 from torch import Tensor

@@ -224,6 +224,28 @@ def test_large_single_call_takes_the_whole_device_path(tg):
             assert np.array_equal(_np(a), b)
 
 
+def test_more_hops_than_the_one_launch_kernel_takes(tg):
+    """the reference takes any number of hops (neighbor_sampling.rs:188); beyond TG_MAX_HOPS = 8 the operators go hop by hop"""
+    rs = np.random.default_rng(15)
+    n = 4000
+    ei = np.stack([rs.integers(0, n, n * 6), rs.integers(0, n, n * 6)])
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    seeds = rs.integers(0, n, 7)
+    fan = [2, 1, 2, 1, 1, 2, 1, 1, 2, 1, 1]                                  # 11 hops
+    P, I, S = (torch.from_numpy(a).cuda() for a in (ptrs, idx, seeds))
+    tg.seed(43)
+    s, r, c, e_, lo = tg.neighbor_sampling_homogenous(P, I, S, fan)
+    o = orc.ns_homo(ptrs, idx, seeds, fan, orc.rng_philox(43, 0))
+    assert lo == o[4] and len(lo) == 11
+    for a, b in zip((s, r, c, e_), o[:4]):
+        assert np.array_equal(_np(a), b)
+    et, k = ("a", "to", "a"), "a__to__a"
+    tg.seed(44)
+    hs, hr, hc, he, hlo = tg.neighbor_sampling_heterogenous(["a"], [et], {k: P}, {k: I}, {"a": S}, {k: fan[:10]}, 10)
+    ho = orc.ns_hetero(["a"], [et], {k: ptrs}, {k: idx}, {"a": seeds}, {k: fan[:10]}, 10, orc.rng_philox(44, 0))
+    assert np.array_equal(_np(hs["a"]), ho[0]["a"]) and np.array_equal(_np(he[k]), ho[3][k])
+
+
 @pytest.mark.parametrize("fan", [[200], [300, 2], [1000], [4096]])
 def test_fanouts_above_255_take_the_wavefront_per_vertex_path(tg, fan):
     rs = np.random.default_rng(14)
