@@ -121,3 +121,30 @@ def test_hgt_hub_sources_long_contribution_runs(tg):
     for seed in (1, 2):
         _compare(tg, g, {"B": rs.permutation(nB)[:700]}, None, {"A": [300, 200], "B": [600, 100]}, 2, seed)
     _compare(tg, g, {"B": np.arange(60)}, None, {"A": [50, 50, 50], "B": [70, 70, 70]}, 3, 3)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_hgt_many_node_types_and_relations(tg, seed):
+    """11 node types and 26 relations: more than one launch's 8 types (init, sample_from), more than 4 independent
+    update_budget steps per round, relations that feed the same budget (kept in canonical order), more than 8 relations in
+    the edge rebuild; timestamps on some relations."""
+    rs = np.random.default_rng(900 + seed)
+    T = 11
+    node_types = ["n%02d" % i for i in range(T)]
+    counts = {t: int(rs.integers(40, 300)) for t in node_types}
+    edge_types, P, I, rts = [], {}, {}, {}
+    pairs = [(i, (i + 1) % T) for i in range(T)] + [(i, (i + 3) % T) for i in range(T)] + [(0, 5), (5, 0), (2, 2), (7, 2)]
+    for r, (a, b) in enumerate(pairs):
+        et = (node_types[a], "r%02d" % r, node_types[b])
+        e = int(rs.integers(200, 3000))
+        ei = np.stack([rs.integers(0, counts[et[0]], e), rs.integers(0, counts[et[2]], e)])
+        ei[0, rs.integers(0, e, e // 5)] = rs.integers(0, 3)                    # a few busy sources
+        edge_types.append(et)
+        k = rel_key(et)
+        P[k], I[k], _ = orc.to_csc(ei, (counts[et[0]], counts[et[2]]))
+        if r % 3 == 0:
+            rts[k] = rs.integers(-1, 25, len(I[k]))
+    g = (node_types, edge_types, P, I)
+    inputs = {t: rs.integers(0, counts[t], int(rs.integers(3, 25))) for t in node_types[::2]}
+    _compare(tg, g, inputs, None, {t: [int(rs.integers(5, 60)), int(rs.integers(5, 60)), 20] for t in node_types}, 3, seed,
+             rts=rts)
