@@ -17,6 +17,7 @@
 #include "row_stream.h"
 #include "tg_device.h"
 #include "tg_host.h"
+#include "tg_map.h"
 
 namespace tg {
 
@@ -27,11 +28,72 @@ constexpr int RW_STAGE = 16; // steps staged per walker between flushes
 struct CsrView {
     const int64_t *ptrs, *indices;
     const uint32_t *ptrs32, *indices32;
+    const uint64_t *edge_set; // optional hash set of the edges (tg_edge_set_build) and its slot mask
+    uint64_t edge_mask;
     __device__ __forceinline__ int64_t ptr(int64_t i) const { return ptrs32 ? (int64_t)ptrs32[i] : ptrs[i]; }
     __device__ __forceinline__ int64_t idx(int64_t e) const { return indices32 ? (int64_t)indices32[e] : indices[e]; }
 };
 
+// ---- the edge set: has_edge as a hash probe --------------------------------------------------------------------------
+// graph.rs:80-83 answers has_edge(x, y) by a binary search of row x: log2(deg) DEPENDENT random line requests, ~13 on
+// RMAT-24, and node2vec with p != q asks once per proposal -- the walk then sits on the chip's random-request ceiling.
+// The set holds every edge once as the key x << 32 | y in an open-addressing table (linear probing, load <= 1/2, 8-byte
+// slots: a probe sequence usually stays inside one 128-byte line), so the same question is ONE line request, with the
+// same answer (a multi-edge is one key; ids must be < 2^32 - 1).
+constexpr uint64_t EDGE_SET_EMPTY = ~0ull;
+__device__ __forceinline__ uint64_t edge_key_hash(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 29;
+    return k;
+}
+__device__ __forceinline__ bool edge_set_has(const uint64_t *__restrict__ slots, uint64_t mask, int64_t x, int64_t y) {
+    const uint64_t key = ((uint64_t)x << 32) | (uint64_t)y;
+    for (uint64_t s = edge_key_hash(key) & mask;; s = (s + 1) & mask) {
+        const uint64_t v = slots[s];
+        if (v == key) return true;
+        if (v == EDGE_SET_EMPTY) return false;
+    }
+}
+__global__ void edge_set_clear_kernel(uint64_t *slots, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        slots[i] = EDGE_SET_EMPTY;
+}
+// the wavefronts walk the edge array in segments of 2 048 edges (coalesced); a segment's rows lie between the rows of its
+// first and last edge, found once per segment, so an edge's row is a short search in cached offsets
+constexpr int64_t EDGE_SET_SEGMENT = 2048;
+__device__ __forceinline__ int64_t row_of_edge(const int64_t *__restrict__ ptrs, int64_t lo, int64_t hi, int64_t e) {
+    while (lo < hi) { // last row r in [lo, hi] with ptrs[r] <= e
+        const int64_t mid = lo + ((hi - lo + 1) >> 1);
+        if (ptrs[mid] <= e)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+__global__ void edge_set_insert_kernel(const int64_t *__restrict__ ptrs, const int64_t *__restrict__ indices, int64_t n_major,
+                                       int64_t n_edges, uint64_t *slots, uint64_t mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_seg = (n_edges + EDGE_SET_SEGMENT - 1) / EDGE_SET_SEGMENT;
+    for (int64_t sgm = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; sgm < n_seg;
+         sgm += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const int64_t e0 = sgm * EDGE_SET_SEGMENT, e1 = min(n_edges, e0 + EDGE_SET_SEGMENT);
+        const int64_t r0 = row_of_edge(ptrs, 0, n_major - 1, e0), r1 = row_of_edge(ptrs, r0, n_major - 1, e1 - 1);
+        for (int64_t e = e0 + lane; e < e1; e += 64) {
+            const int64_t r = row_of_edge(ptrs, r0, r1, e);
+            const uint64_t key = ((uint64_t)r << 32) | (uint64_t)indices[e];
+            for (uint64_t s = edge_key_hash(key) & mask;; s = (s + 1) & mask) {
+                const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s]),
+                                               (unsigned long long)EDGE_SET_EMPTY, (unsigned long long)key);
+                if (old == EDGE_SET_EMPTY || old == key) break;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ bool has_edge(const CsrView &g, int64_t x, int64_t y) { // graph.rs:80-83
+    if (g.edge_set) return edge_set_has(g.edge_set, g.edge_mask, x, y);
     int64_t lo = g.ptr(x), hi = g.ptr(x + 1);
     while (lo < hi) {
         const int64_t mid = lo + ((hi - lo) >> 1);
@@ -45,11 +107,15 @@ __device__ __forceinline__ bool has_edge(const CsrView &g, int64_t x, int64_t y)
     return false;
 }
 
+// StageT = uint32_t for the has_edge variants when the vertex ids fit (0xffffffff stands for -1): half the LDS per
+// workgroup, twice the resident wavefronts -- those variants are bound by the latency of their dependent loads (p != q:
+// 11.8 -> 9.1 ms; p = q = 1 is not: 1.16 ms with int64 staging, 1.27 with u32, so it keeps int64)
+template <typename StageT>
 __global__ void rw_node2vec_kernel(const CsrView g, const int64_t *__restrict__ start, int64_t n, int64_t walk_length, float prob0,
                                    float prob1, float prob2, uint64_t seed, uint64_t call_id, int64_t *walks) {
-    __shared__ int64_t stage_all[4][64 * (RW_STAGE + 1)]; // [wave][walker * 17 + step]: odd pitch spreads LDS banks
+    __shared__ StageT stage_all[4][64 * (RW_STAGE + 1)]; // [wave][walker * 17 + step]: odd pitch spreads LDS banks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t *stage = stage_all[wave];
+    StageT *stage = stage_all[wave];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t wave_first = t - lane;
     const bool live = t < n;
@@ -93,7 +159,7 @@ __global__ void rw_node2vec_kernel(const CsrView g, const int64_t *__restrict__ 
                     val = cur;
                 }
             }
-            stage[lane * (RW_STAGE + 1) + j] = val;
+            stage[lane * (RW_STAGE + 1) + j] = (StageT)val; // -1 -> all ones
         }
         wave_lds_handoff();
         // flush: walker w of this wave owns ncols contiguous int64 at walks[(wave_first+w)*L + c0 ..]
@@ -101,7 +167,10 @@ __global__ void rw_node2vec_kernel(const CsrView g, const int64_t *__restrict__ 
         for (int q = lane; q < total; q += 64) {
             const int w = q / ncols, j = q - w * ncols;
             const int64_t tw = wave_first + w;
-            if (tw < n) walks[tw * L + c0 + j] = stage[w * (RW_STAGE + 1) + j];
+            if (tw < n) {
+                const StageT v = stage[w * (RW_STAGE + 1) + j];
+                walks[tw * L + c0 + j] = v == (StageT)-1 ? (int64_t)-1 : (int64_t)v;
+            }
         }
         wave_lds_handoff();
     }
@@ -186,11 +255,48 @@ __global__ void rw_tempo_kernel(const int64_t *__restrict__ ptrs, const int64_t 
 
 } // namespace tg
 
-extern "C" int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p,
-                              float q, const tg_rng *rng, int64_t *walks, void *stream) {
+static int64_t edge_set_slots(int64_t n_edges) {
+    int64_t cap = 64;
+    while (cap < 2 * n_edges) cap <<= 1;
+    return cap;
+}
+extern "C" int tg_edge_set_bytes(const tg_graph *csr, int64_t *bytes) {
+    TG_REQUIRE(csr && bytes && csr->n_edges >= 0 && csr->n_major >= 0, "tg_edge_set_bytes: bad arguments");
+    TG_REQUIRE(csr->n_major < (int64_t)0xffffffff, "tg_edge_set_bytes: ids of %lld vertices do not fit the 32-bit halves of a key",
+               (long long)csr->n_major);
+    *bytes = 8 * edge_set_slots(csr->n_edges);
+    return TG_OK;
+}
+extern "C" int tg_edge_set_build(const tg_graph *csr, void *edge_set, int64_t bytes, void *stream_) {
+    TG_REQUIRE(csr && csr->ptrs && (csr->indices || csr->n_edges == 0) && edge_set, "tg_edge_set_build: null argument");
+    TG_REQUIRE(csr->n_major < (int64_t)0xffffffff, "tg_edge_set_build: ids of %lld vertices do not fit a key", (long long)csr->n_major);
+    const int64_t cap = edge_set_slots(csr->n_edges);
+    TG_REQUIRE(bytes >= 8 * cap, "tg_edge_set_build: %lld bytes given, %lld needed", (long long)bytes, (long long)(8 * cap));
+    hipStream_t stream = (hipStream_t)stream_;
+    uint64_t *slots = reinterpret_cast<uint64_t *>(edge_set);
+    hipLaunchKernelGGL(tg::edge_set_clear_kernel, dim3(tg::grid_1d(cap)), dim3(256), 0, stream, slots, cap);
+    if (csr->n_edges > 0 && csr->n_major > 0) {
+        const int64_t n_seg = (csr->n_edges + tg::EDGE_SET_SEGMENT - 1) / tg::EDGE_SET_SEGMENT;
+        hipLaunchKernelGGL(tg::edge_set_insert_kernel, dim3(tg::grid_1d(n_seg * 64)), dim3(256), 0, stream, csr->ptrs, csr->indices,
+                           csr->n_major, csr->n_edges, slots, (uint64_t)(cap - 1));
+    }
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+extern "C" int tg_random_walk_es(const tg_graph *csr, const void *edge_set, int64_t edge_set_bytes, const int64_t *start, int64_t n,
+                                 int64_t walk_length, float p, float q, const tg_rng *rng, int64_t *walks, void *stream) {
     TG_REQUIRE(csr && csr->ptrs && (csr->indices || csr->n_edges == 0), "tg_random_walk: null graph");
     TG_REQUIRE(rng && n >= 0 && walk_length >= 0, "tg_random_walk: bad arguments");
     TG_REQUIRE(p > 0.0f && q > 0.0f, "tg_random_walk: p and q must be positive (random_walk.rs:29-30)");
+    uint64_t edge_mask = 0;
+    if (edge_set) {
+        const int64_t cap = edge_set_slots(csr->n_edges);
+        TG_REQUIRE(edge_set_bytes == 8 * cap && csr->n_major < (int64_t)0xffffffff,
+                   "tg_random_walk_es: the edge set (%lld bytes) was not built for this graph (%lld bytes)",
+                   (long long)edge_set_bytes, (long long)(8 * cap));
+        edge_mask = (uint64_t)(cap - 1);
+    }
     if (n == 0) return TG_OK;
     TG_REQUIRE(start && walks, "tg_random_walk: null buffers");
     // random_walk.rs:29-36, all in f32
@@ -200,11 +306,21 @@ extern "C" int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t
     if (inv_q >= max_prob) max_prob = inv_q;
     const float prob0 = 1.0f / p / max_prob, prob1 = 1.0f / max_prob, prob2 = 1.0f / q / max_prob;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    const tg::CsrView view{csr->ptrs, csr->indices, csr->ptrs32, csr->indices32};
-    hipLaunchKernelGGL(tg::rw_node2vec_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, view, start, n,
-                       walk_length, prob0, prob1, prob2, rng->seed, rng->call_id, walks);
+    const tg::CsrView view{csr->ptrs, csr->indices, csr->ptrs32, csr->indices32, reinterpret_cast<const uint64_t *>(edge_set),
+                           edge_mask};
+    const bool always_accept = prob0 >= 1.0f && prob1 >= 1.0f && prob2 >= 1.0f;
+    if (!always_accept && csr->n_major < (int64_t)0xffffffff)
+        hipLaunchKernelGGL(tg::rw_node2vec_kernel<uint32_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, view, start, n,
+                           walk_length, prob0, prob1, prob2, rng->seed, rng->call_id, walks);
+    else
+        hipLaunchKernelGGL(tg::rw_node2vec_kernel<int64_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, view, start, n,
+                           walk_length, prob0, prob1, prob2, rng->seed, rng->call_id, walks);
     TG_LAUNCH_CHECK();
     return TG_OK;
+}
+extern "C" int tg_random_walk(const tg_graph *csr, const int64_t *start, int64_t n, int64_t walk_length, float p, float q,
+                              const tg_rng *rng, int64_t *walks, void *stream) {
+    return tg_random_walk_es(csr, nullptr, 0, start, n, walk_length, p, q, rng, walks, stream);
 }
 
 extern "C" int tg_tempo_random_walk(const tg_graph *csr, const int64_t *node_ts, const int64_t *edge_ts,

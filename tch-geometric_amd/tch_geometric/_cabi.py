@@ -19,6 +19,7 @@ PART_REPLY_PACKED, PART_REPLY_PAIRS, PART_REPLY_TRIPLES, PART_REPLY_PACKED_STATE
 FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 
 EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_batched", "tg_random_walk",
+           "tg_edge_set_bytes", "tg_edge_set_build", "tg_random_walk_es",
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
            "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
@@ -262,11 +263,25 @@ def ns_win_stage_times():
     return [(names.raw[24 * i:24 * i + 24].split(b"\0", 1)[0].decode(), float(ms[i])) for i in range(min(n.value, cap))]
 
 
-def random_walk(graph, start, walk_length, p, q, seed, call_id):
+def edge_set(graph, device):
+    """hash set of the CSR's edges for tg_random_walk_es (has_edge as one probe): a uint64 tensor"""
+    nbytes = C.c_int64(0)
+    check(lib.tg_edge_set_bytes(C.byref(graph), C.byref(nbytes)))
+    es = torch.empty(nbytes.value // 8, dtype=torch.int64, device=device)
+    check(lib.tg_edge_set_build(C.byref(graph), ptr(es), nbytes, stream_ptr(device)))
+    return es
+
+
+def random_walk(graph, start, walk_length, p, q, seed, call_id, edge_set=None):
     walks = torch.empty((start.numel(), walk_length + 1), dtype=torch.int64, device=start.device)
     rng = TgRng(seed, call_id)
-    check(lib.tg_random_walk(C.byref(graph), ptr(start), C.c_int64(start.numel()), C.c_int64(walk_length),
-                             C.c_float(p), C.c_float(q), C.byref(rng), ptr(walks), stream_ptr(start.device)))
+    if edge_set is None:
+        check(lib.tg_random_walk(C.byref(graph), ptr(start), C.c_int64(start.numel()), C.c_int64(walk_length),
+                                 C.c_float(p), C.c_float(q), C.byref(rng), ptr(walks), stream_ptr(start.device)))
+    else:
+        check(lib.tg_random_walk_es(C.byref(graph), ptr(edge_set), C.c_int64(edge_set.numel() * 8), ptr(start),
+                                    C.c_int64(start.numel()), C.c_int64(walk_length), C.c_float(p), C.c_float(q),
+                                    C.byref(rng), ptr(walks), stream_ptr(start.device)))
     return walks
 
 

@@ -45,6 +45,10 @@ def test_random_walk_karate(cabi, dev, pq, walk_length):
     for row in w[:10]:                                   # random_walk.rs:322-330
         for a, b in zip(row[:-1], row[1:]):
             assert has_edge(ptrs, idx, a, b)
+    # has_edge answered from the edge set (one hash probe instead of a binary search of the row): the same walks
+    g = cabi.graph_view(p_d, i_d)
+    es = cabi.edge_set(g, dev)
+    assert np.array_equal(cabi.random_walk(g, s_d, walk_length, pq[0], pq[1], SEED, 7, edge_set=es).cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("pq", [(1.0, 1.0), (2.0, 0.5)])
@@ -59,6 +63,25 @@ def test_random_walk_rmat_with_dead_ends(cabi, dev, pq):
     # the optional u32 shadows of the CSR change the bytes read, not the walk
     g32 = cabi.graph_view(p_d, i_d, indices32=i_d.to(torch.int32), ptrs32=p_d.to(torch.int32))
     assert np.array_equal(cabi.random_walk(g32, s_d, 40, pq[0], pq[1], SEED, 1).cpu().numpy(), ref)
+    es = cabi.edge_set(g32, dev)                         # and so does the edge set (RMAT: multi-edges, self loops, hubs)
+    assert es.numel() >= 2 * idx.size and (es.numel() & (es.numel() - 1)) == 0
+    assert np.array_equal(cabi.random_walk(g32, s_d, 40, pq[0], pq[1], SEED, 1, edge_set=es).cpu().numpy(), ref)
+    keys = es[es != -1].cpu().numpy().astype(np.uint64)  # the set holds exactly the distinct edges
+    rows = np.repeat(np.arange(n), np.diff(ptrs)).astype(np.uint64)
+    assert np.array_equal(np.sort(keys), np.unique((rows << np.uint64(32)) | idx.astype(np.uint64)))
+
+
+def test_edge_set_of_an_empty_graph_and_a_wrong_size(cabi, dev):
+    ptrs = torch.zeros(6, dtype=torch.int64, device=dev)
+    idx = torch.zeros(0, dtype=torch.int64, device=dev)
+    g = cabi.graph_view(ptrs, idx)
+    es = cabi.edge_set(g, dev)
+    assert (es == -1).all()
+    start = torch.arange(5, device=dev)
+    w = cabi.random_walk(g, start, 3, 2.0, 0.5, SEED, 0, edge_set=es)
+    assert (w[:, 0] == start).all() and (w[:, 1:] == -1).all()
+    with pytest.raises(RuntimeError, match="was not built for this graph"):
+        cabi.random_walk(g, start, 3, 2.0, 0.5, SEED, 0, edge_set=torch.empty(8, dtype=torch.int64, device=dev))
 
 
 def test_random_walk_edge_cases(cabi, dev):

@@ -23,14 +23,21 @@ g_walk = _cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.
 n_walkers, L = 1 << 20, 80
 start = _cabi.seed_batches(0x57A27, 0, 1, n_walkers, n, dev)[0].contiguous()
 res = {}
-for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)) if os.environ.get("NODE2VEC", "1") == "1" else ():
-    _cabi.random_walk(g_walk, start, L, p, q, 0, 0)
+es, es_ms = None, None
+for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5), ("p1_q1.5_edge_set", 1.0, 1.5)) if os.environ.get("NODE2VEC", "1") == "1" else ():
+    if name.endswith("edge_set"):          # has_edge as a hash probe: built once per graph
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        es = _cabi.edge_set(g_walk, dev)
+        torch.cuda.synchronize()
+        es_ms = (time.perf_counter() - t0) * 1e3
+    _cabi.random_walk(g_walk, start, L, p, q, 0, 0, edge_set=es)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 3
     e0.record()
     for r in range(reps):
-        w = _cabi.random_walk(g_walk, start, L, p, q, 0, r + 1)
+        w = _cabi.random_walk(g_walk, start, L, p, q, 0, r + 1, edge_set=es)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
@@ -39,6 +46,10 @@ for name, p, q in (("p1_q1", 1.0, 1.0), ("p1_q1.5", 1.0, 1.5)) if os.environ.get
     alg = 32 * steps + 8 * n_walkers + 8 * (cells - steps)       # 32 B per executed step, 8 B per -1 cell
     res[name] = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3,
                  "algorithmic_GBps": alg / ms / 1e6, "frac_of_8TBps": alg / ms / 1e6 / 8000.0}
+    if es is not None:
+        res[name]["edge_set_build_ms"] = es_ms
+        res[name]["edge_set_GB"] = es.numel() * 8 / 1e9
+        res[name]["same_walks_as_without"] = bool(torch.equal(w, _cabi.random_walk(g_walk, start, L, p, q, 0, reps)))
 # ---- temporal walks on the same graph: edge timestamps in [0, 100), start timestamps in [0, 50)
 gen = torch.Generator(device=dev)
 gen.manual_seed(3)
