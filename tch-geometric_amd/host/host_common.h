@@ -275,6 +275,85 @@ inline void check_graph_ids(const Tensor &indices, int64_t hi, const c10::Device
                        indices.numel(), hi, version});
 }
 
+// Edge sets of resident CSRs (include/tchgeo.h tg_edge_set_build): node2vec with p != q asks has_edge once per proposal; the
+// set answers it with one hash probe instead of a binary search of the row.  Built on the first LARGE p != q call on a graph
+// (>= 2^20 walker steps: the build costs about two such calls) and kept per (ptrs, indices) identity + content version, least
+// recently used first out, within TG_EDGE_SET_GB (default 32) -- 16 bytes per edge; a graph whose set would not fit keeps the
+// binary search.  Same walks either way.
+struct EdgeSets {
+    struct Entry {
+        c10::weak_intrusive_ptr<c10::StorageImpl> sp, si;
+        const void *ip, *ii, *pp, *pi;
+        int64_t np, ni;
+        uint32_t vp, vi;
+        int dev;
+        Tensor set;
+        uint64_t used;
+    };
+    std::mutex mu;
+    std::vector<Entry> entries;
+    uint64_t tick = 0, hits = 0, builds = 0;
+    static int64_t limit_bytes() {
+        static const int64_t gb = [] {
+            const char *v = getenv("TG_EDGE_SET_GB");
+            return v ? atoll(v) : 32ll;
+        }();
+        return gb << 30;
+    }
+    int64_t bytes_locked() const {
+        int64_t b = 0;
+        for (const Entry &e : entries) b += (int64_t)e.set.nbytes();
+        return b;
+    }
+    // the set of (ptrs, idx) on `dev`, or an undefined tensor: not cached and `build` is false, or it does not fit
+    Tensor get(const Tensor &ptrs, const Tensor &idx, const tg_graph &g, const c10::Device &dev, bool build) {
+        if (g.n_major >= (int64_t)0xffffffff) return Tensor();
+        c10::StorageImpl *ip = ptrs.storage().unsafeGetStorageImpl(), *ii = idx.storage().unsafeGetStorageImpl();
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            for (size_t i = 0; i < entries.size();) {
+                if (entries[i].sp.expired() || entries[i].si.expired()) {
+                    entries.erase(entries.begin() + (long)i);
+                    continue;
+                }
+                Entry &e = entries[i];
+                if (e.ip == ip && e.ii == ii && e.pp == ptrs.data_ptr() && e.pi == idx.data_ptr() && e.np == ptrs.numel() &&
+                    e.ni == idx.numel() && e.vp == (uint32_t)ptrs._version() && e.vi == (uint32_t)idx._version() &&
+                    e.dev == dev.index()) {
+                    e.used = ++tick;
+                    ++hits;
+                    return e.set;
+                }
+                ++i;
+            }
+        }
+        if (!build) return Tensor();
+        int64_t bytes = 0;
+        check_rc(tg_edge_set_bytes(&g, &bytes));
+        if (bytes > limit_bytes()) return Tensor();
+        Tensor set = at::empty({bytes / 8}, at::TensorOptions().dtype(at::kLong).device(dev));
+        check_rc(tg_edge_set_build(&g, set.data_ptr<int64_t>(), bytes, stream_of(dev)));
+        std::lock_guard<std::mutex> lock(mu);
+        ++builds;
+        while (!entries.empty() && bytes_locked() + bytes > limit_bytes()) {
+            size_t lru = 0;
+            for (size_t i = 1; i < entries.size(); ++i)
+                if (entries[i].used < entries[lru].used) lru = i;
+            entries.erase(entries.begin() + (long)lru);
+        }
+        entries.push_back(Entry{c10::weak_intrusive_ptr<c10::StorageImpl>(ptrs.storage().getWeakStorageImpl()),
+                                c10::weak_intrusive_ptr<c10::StorageImpl>(idx.storage().getWeakStorageImpl()), ip, ii,
+                                ptrs.data_ptr(), idx.data_ptr(), ptrs.numel(), idx.numel(), (uint32_t)ptrs._version(),
+                                (uint32_t)idx._version(),
+                                (int)dev.index(), set, ++tick});
+        return set;
+    }
+    static EdgeSets &instance() {
+        static EdgeSets s;
+        return s;
+    }
+};
+
 inline std::string rel_key(const std::tuple<std::string, std::string, std::string> &e) { // neighbor_sampling.rs:257
     return std::get<0>(e) + "__" + std::get<1>(e) + "__" + std::get<2>(e);
 }

@@ -1040,8 +1040,13 @@ Tensor random_walk(const Tensor &row_ptrs, const Tensor &col_indices, const Tens
     g.n_major = ptrs.numel() - 1;
     g.n_edges = idx.numel();
     const tg_rng rng = next_rng();
-    check_rc(tg_random_walk(&g, st.numel() ? st.data_ptr<int64_t>() : nullptr, st.numel(), walk_length, p, q, &rng,
-                            walks.data_ptr<int64_t>(), stream_of(dev)));
+    // p != q: every proposal asks has_edge (random_walk.rs:57-63) -- from the graph's edge set once a large call paid for it
+    Tensor edge_set;
+    if (p > 0.0f && q > 0.0f && !(p == 1.0f && q == 1.0f) && walk_length > 1 && st.numel() > 0)
+        edge_set = EdgeSets::instance().get(ptrs, idx, g, dev, st.numel() * walk_length >= ((int64_t)1 << 20));
+    check_rc(tg_random_walk_es(&g, edge_set.defined() ? edge_set.data_ptr<int64_t>() : nullptr,
+                               edge_set.defined() ? (int64_t)edge_set.nbytes() : 0, st.numel() ? st.data_ptr<int64_t>() : nullptr,
+                               st.numel(), walk_length, p, q, &rng, walks.data_ptr<int64_t>(), stream_of(dev)));
     return back(walks, start.device()); // random_walk.rs:19-23 allocates on start.device()
 }
 
@@ -1158,13 +1163,28 @@ PYBIND11_MODULE(tch_geometric, m) {
         d["limit_bytes"] = g.limit_bytes();
         d["hits"] = g.hits;
         d["uploads"] = g.uploads;
+        {
+            EdgeSets &es = EdgeSets::instance();
+            std::lock_guard<std::mutex> lk2(es.mu);
+            d["edge_sets"] = es.entries.size();
+            d["edge_set_bytes"] = es.bytes_locked();
+            d["edge_set_limit_bytes"] = EdgeSets::limit_bytes();
+            d["edge_set_hits"] = es.hits;
+            d["edge_set_builds"] = es.builds;
+        }
         return d;
-    }, "Device copies kept of CPU-resident adjacency tensors: {entries, bytes, limit_bytes, hits, uploads}.");
+    }, "Device copies kept of CPU-resident adjacency tensors: {entries, bytes, limit_bytes, hits, uploads}, and the edge sets "
+       "kept for node2vec walks with p != q: {edge_sets, edge_set_bytes, edge_set_limit_bytes, edge_set_hits, edge_set_builds}.");
     m.def("graph_cache_clear", [] {
-        ResidentGraphs &g = ResidentGraphs::instance();
-        std::lock_guard<std::mutex> lk(g.mu);
-        g.entries.clear();
-    }, "Drop every device copy of a CPU-resident adjacency tensor.");
+        {
+            ResidentGraphs &g = ResidentGraphs::instance();
+            std::lock_guard<std::mutex> lk(g.mu);
+            g.entries.clear();
+        }
+        EdgeSets &es = EdgeSets::instance();
+        std::lock_guard<std::mutex> lk2(es.mu);
+        es.entries.clear();
+    }, "Drop every device copy of a CPU-resident adjacency tensor and every edge set.");
     m.def("rng_state", [] {
         RngState &st = rng_state();
         std::lock_guard<std::mutex> lk(st.mu);

@@ -28,7 +28,9 @@ def set_rng_state(seed: int, call_counter: int) -> None: ...
 def backend_version() -> str: ...
 class PanicException(RuntimeError): ...               # raised where the reference panics (pyo3_runtime.PanicException there)
 def graph_cache_info() -> Dict[str, int]: ...         # additive: CPU-resident adjacency tensors are uploaded once and
-def graph_cache_clear() -> None: ...                  # kept on the device (keyed on storage identity + content version)
+def graph_cache_clear() -> None: ...                  # kept on the device (keyed on storage identity + content version);
+                                                      # also the edge sets that answer has_edge for random_walk with
+                                                      # p != q (built by the first call of >= 2^20 walker steps on a graph)
 
 def to_csc(row_col: Tensor, size: Union[int, Tuple[int, int]]) -> Tuple[Tensor, Tensor, Tensor]: ...
 def to_csr(row_col: Tensor, size: Union[int, Tuple[int, int]]) -> Tuple[Tensor, Tensor, Tensor]: ...

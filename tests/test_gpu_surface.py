@@ -167,6 +167,40 @@ def test_walks_through_the_surface(tg):
     assert a.shape == (4, 10) and np.array_equal(_np(a), oa) and np.array_equal(_np(b), ob)
 
 
+def test_large_node2vec_calls_build_and_reuse_the_edge_set(tg):
+    """p != q asks has_edge per proposal: a call of >= 2^20 walker steps builds the graph's edge set, later calls on the same
+    tensors (small ones too) answer has_edge from it; walks equal the oracle's either way; a graph changed in place gets a
+    new set"""
+    rs = np.random.default_rng(21)
+    n = 1 << 12
+    ei = np.stack([rs.integers(0, n, n * 12), rs.integers(0, n, n * 12)])
+    ptrs, idx, _ = orc.to_csr(ei, n)
+    P, I = torch.from_numpy(ptrs).cuda(), torch.from_numpy(idx).cuda()
+    tg.graph_cache_clear()
+    small = rs.integers(0, n, 100)
+    tg.seed(8)
+    w0 = tg.random_walk(P, I, torch.from_numpy(small).cuda(), 20, 0.5, 2.0)
+    assert tg.graph_cache_info()["edge_sets"] == 0                                  # a small call does not pay for the set
+    assert np.array_equal(_np(w0), orc.random_walk(ptrs, idx, small, 20, 0.5, 2.0, orc.rng_philox(8, 0)))
+    big = rs.integers(0, n, 1 << 15)
+    w1 = tg.random_walk(P, I, torch.from_numpy(big).cuda(), 40, 0.5, 2.0)           # 1.3 M steps: builds it
+    info = tg.graph_cache_info()
+    assert info["edge_sets"] == 1 and info["edge_set_builds"] == 1 and info["edge_set_bytes"] >= 16 * len(idx)
+    assert np.array_equal(_np(w1), orc.random_walk(ptrs, idx, big, 40, 0.5, 2.0, orc.rng_philox(8, 1)))
+    w2 = tg.random_walk(P, I, torch.from_numpy(small).cuda(), 20, 0.5, 2.0)          # reuses it
+    assert tg.graph_cache_info()["edge_set_hits"] == 1
+    assert np.array_equal(_np(w2), orc.random_walk(ptrs, idx, small, 20, 0.5, 2.0, orc.rng_philox(8, 2)))
+    tg.random_walk(P, I, torch.from_numpy(big).cuda(), 40, 1.0, 1.0)                 # p = q = 1 never asks has_edge
+    assert tg.graph_cache_info()["edge_set_hits"] == 1
+    I[ptrs[5]:ptrs[6]] = torch.sort(torch.from_numpy(rs.integers(0, n, int(ptrs[6] - ptrs[5]))).cuda()).values  # row 5 rewritten in place
+    idx2 = _np(I)
+    w3 = tg.random_walk(P, I, torch.from_numpy(big).cuda(), 40, 0.5, 2.0)
+    assert tg.graph_cache_info()["edge_set_builds"] == 2
+    assert np.array_equal(_np(w3), orc.random_walk(ptrs, idx2, big, 40, 0.5, 2.0, orc.rng_philox(8, 4)))
+    tg.graph_cache_clear()
+    assert tg.graph_cache_info()["edge_sets"] == 0
+
+
 def test_out_of_range_node_ids_raise_instead_of_faulting(tg):
     """the reference panics (index out of bounds) on a node id outside the graph; here: IndexError, no device fault"""
     P, I = torch.tensor([0, 1, 2]).cuda(), torch.tensor([1, 0]).cuda()       # 2 nodes
