@@ -1143,6 +1143,32 @@ std::tuple<Tensor, Tensor> biased_tempo_random_walk(const Tensor &row_ptrs, cons
 
 void register_more(py::module_ &m); // negative sampling + hgt (python_module_more.cpp)
 
+// The loader's mini-batches are views of a super-batch's flat tensors (tch_geometric/loader.py).  Building the views of one
+// mini-batch in Python is a narrow() per tensor, ~2 us each -- more than the GPU spends sampling the mini-batch (~0.5 us in
+// a 16 384-batch launch); this object holds the super-batch's tensors once and cuts all views of mini-batch j in ONE call.
+struct BatchViews {
+    std::vector<Tensor> bases;
+    std::vector<int64_t> dims;  // the dimension the mini-batches are laid out along
+    std::vector<int64_t> kinds; // 0: a node tensor (sliced by node_ptr), 1: an edge tensor (edge_ptr)
+    std::vector<int64_t> node_ptr, edge_ptr;
+    BatchViews(std::vector<Tensor> b, std::vector<int64_t> d, std::vector<int64_t> k, std::vector<int64_t> np,
+               std::vector<int64_t> ep)
+        : bases(std::move(b)), dims(std::move(d)), kinds(std::move(k)), node_ptr(std::move(np)), edge_ptr(std::move(ep)) {
+        if (bases.size() != dims.size() || bases.size() != kinds.size() || node_ptr.size() != edge_ptr.size() ||
+            node_ptr.empty())
+            throw py::value_error("BatchViews: tensors, dims and kinds must have one length; node_ptr and edge_ptr too");
+    }
+    py::tuple at(int64_t j) const {
+        if (j < 0 || j + 1 >= (int64_t)node_ptr.size()) throw py::index_error("mini-batch index out of range");
+        const int64_t an = node_ptr[(size_t)j], ln = node_ptr[(size_t)j + 1] - an;
+        const int64_t ae = edge_ptr[(size_t)j], le = edge_ptr[(size_t)j + 1] - ae;
+        py::tuple out(bases.size());
+        for (size_t i = 0; i < bases.size(); ++i)
+            out[i] = kinds[i] == 0 ? bases[i].narrow(dims[i], an, ln) : bases[i].narrow(dims[i], ae, le);
+        return out;
+    }
+};
+
 PYBIND11_MODULE(tch_geometric, m) {
     m.doc() = "MI355X-native backend behind tch-geometric's operator surface (reference: src/python.rs)";
     // additive: the reference's RNG cannot be seeded from Python (utils/random.rs:14-17 is not exported)
@@ -1185,6 +1211,11 @@ PYBIND11_MODULE(tch_geometric, m) {
         std::lock_guard<std::mutex> lk2(es.mu);
         es.entries.clear();
     }, "Drop every device copy of a CPU-resident adjacency tensor and every edge set.");
+    py::class_<BatchViews>(m, "BatchViews", "All tensor views of mini-batch j of a loader super-batch in one call.")
+        .def(py::init<std::vector<Tensor>, std::vector<int64_t>, std::vector<int64_t>, std::vector<int64_t>,
+                      std::vector<int64_t>>(),
+             py::arg("tensors"), py::arg("dims"), py::arg("kinds"), py::arg("node_ptr"), py::arg("edge_ptr"))
+        .def("at", &BatchViews::at, py::arg("j"));
     m.def("rng_state", [] {
         RngState &st = rng_state();
         std::lock_guard<std::mutex> lk(st.mu);

@@ -15,6 +15,7 @@ import torch
 from torch import Tensor
 
 from . import _cabi
+from . import tch_geometric as _host
 from .transforms import Graph, HeteroGraph, _attr_kind, _num_nodes, _tensor_items, rel_key, to_csc, to_hetero_csc
 
 
@@ -35,7 +36,20 @@ class SuperBatch:
     mini-batches as `MiniBatch` views; a consumer that can take the whole super-batch (a model over a batch of
     sub-graphs with `ptr` offsets) pays no per-mini-batch host work at all."""
     __slots__ = ("n_id", "edge_index", "e_id", "node_attrs", "edge_attrs", "node_ptr", "edge_ptr", "layer_offsets",
-                 "batch_size", "call_id0", "n_hops")
+                 "batch_size", "call_id0", "n_hops", "_views", "_index")
+
+    def views_of(self, j):
+        """every tensor view of mini-batch j, cut by the host module in one call (BatchViews): (n_id, e_id, edge_index,
+        node attributes..., edge attributes...)"""
+        v = getattr(self, "_views", None)
+        if v is None:
+            names = ["n_id", "e_id", "edge_index"] + list(self.node_attrs) + list(self.edge_attrs)
+            bases = [self.n_id, self.e_id, self.edge_index] + list(self.node_attrs.values()) + list(self.edge_attrs.values())
+            dims = [0, 0, 1] + [0] * (len(bases) - 3)
+            kinds = [0, 1, 1] + [0] * len(self.node_attrs) + [1] * len(self.edge_attrs)
+            self._index = {k: i for i, k in enumerate(names)}
+            v = self._views = _host.BatchViews(bases, dims, kinds, self.node_ptr, self.edge_ptr)
+        return v.at(j)
 
     def __len__(self):
         return len(self.node_ptr) - 1
@@ -75,32 +89,26 @@ class MiniBatch:
     call_id = property(lambda self: self._sb.call_id0 + self._j)
     layer_offsets = property(lambda self: [tuple(x) for x in self._sb.layer_offsets[self._j][:self._sb.n_hops]])
 
-    def _node(self, t):
-        a = self._sb.node_ptr[self._j]
-        return t.narrow(0, a, self._sb.node_ptr[self._j + 1] - a)
+    def _all(self):  # the views of this mini-batch: one call into the host module on first use, then a tuple
+        c = self._cache
+        if c is None:
+            c = self._cache = self._sb.views_of(self._j)
+        return c
 
-    def _edge(self, t, dim=0):
-        a = self._sb.edge_ptr[self._j]
-        return t.narrow(dim, a, self._sb.edge_ptr[self._j + 1] - a)
-
-    n_id = property(lambda self: self._node(self._sb.n_id))
-    e_id = property(lambda self: self._edge(self._sb.e_id))
-    edge_index = property(lambda self: self._edge(self._sb.edge_index, 1))
+    n_id = property(lambda self: self._all()[0])
+    e_id = property(lambda self: self._all()[1])
+    edge_index = property(lambda self: self._all()[2])
 
     def __getattr__(self, name):  # node / edge attributes of the source graph (x, y, edge_attr, ...)
         sb = object.__getattribute__(self, "_sb")
-        if name in sb.node_attrs:
-            return self._node(sb.node_attrs[name])
-        if name in sb.edge_attrs:
-            return self._edge(sb.edge_attrs[name])
+        if name in sb.node_attrs or name in sb.edge_attrs:
+            views = self._all()
+            return views[sb._index[name]]
         raise AttributeError(name)
 
     def tensor_items(self):
-        sb = self._sb
-        items = [("n_id", self.n_id), ("e_id", self.e_id), ("edge_index", self.edge_index)]
-        items += [(k, self._node(v)) for k, v in sb.node_attrs.items()]
-        items += [(k, self._edge(v)) for k, v in sb.edge_attrs.items()]
-        return items
+        views = self._all()
+        return [(k, views[i]) for k, i in self._sb._index.items()]
 
 
 class NeighborLoader:
