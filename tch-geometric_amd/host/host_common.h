@@ -334,6 +334,13 @@ struct EdgeSets {
         Tensor set = at::empty({bytes / 8}, at::TensorOptions().dtype(at::kLong).device(dev));
         check_rc(tg_edge_set_build(&g, set.data_ptr<int64_t>(), bytes, stream_of(dev)));
         std::lock_guard<std::mutex> lock(mu);
+        for (Entry &e : entries) // another thread built the same set meanwhile: keep one
+            if (e.ip == ip && e.ii == ii && e.pp == ptrs.data_ptr() && e.pi == idx.data_ptr() && e.np == ptrs.numel() &&
+                e.ni == idx.numel() && e.vp == (uint32_t)ptrs._version() && e.vi == (uint32_t)idx._version() &&
+                e.dev == dev.index() && !e.sp.expired() && !e.si.expired()) {
+                e.used = ++tick;
+                return e.set;
+            }
         ++builds;
         while (!entries.empty() && bytes_locked() + bytes > limit_bytes()) {
             size_t lru = 0;
