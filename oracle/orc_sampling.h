@@ -133,6 +133,21 @@ static inline void orc_blocked_prefix(const double *x, int64_t n_raw, double *ou
     }
 }
 
+/* the same in f32 (biased_tempo_random_walk's one-slot reservoir, random_walk.rs:264-271 with f32 weights) */
+static inline void orc_blocked_prefix_f32(const float *x, int64_t n_raw, float *out) {
+    float carry = 0.0f;
+    for (int64_t base = 0; base < n_raw; base += 64) {
+        float y[64], t[64];
+        for (int i = 0; i < 64; i++) y[i] = (base + i < n_raw) ? x[base + i] : 0.0f;
+        for (int d = 1; d < 64; d <<= 1) {
+            for (int i = 0; i < 64; i++) t[i] = (i >= d) ? y[i] + y[i - d] : y[i];
+            for (int i = 0; i < 64; i++) y[i] = t[i];
+        }
+        for (int i = 0; i < 64 && base + i < n_raw; i++) out[base + i] = carry + y[i];
+        carry = carry + y[63];
+    }
+}
+
 /* src/utils/sampling.rs:28-55 reservoir_sampling_weighted over positions
  * [0,n) with weights w[pos]; returns min(n,k), or -1 where the reference
  * panics (empty float range: running weight sum <= 0, sampling.rs:49).

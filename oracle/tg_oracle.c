@@ -673,9 +673,10 @@ ORC_API int32_t orc_biased_tempo_random_walk(const int64_t *ptrs, const int64_t 
         walks[i] = -1;
         walks_ts[i] = -1;
     }
-    vec64 cn = {0}, ct = {0};
+    vec64 cn = {0}, ct = {0}, cr = {0}; /* candidates: neighbour, time, raw position in the row */
     int32_t *times = NULL;
-    float *w = NULL;
+    float *w = NULL, *raw_w = NULL, *blocked = NULL;
+    int64_t raw_cap = 0;
     int64_t cap = 0;
     int32_t status = 0;
     for (int64_t i = 0; i < n && status == 0; i++) {
@@ -686,13 +687,14 @@ ORC_API int32_t orc_biased_tempo_random_walk(const int64_t *ptrs, const int64_t 
             for (int64_t l = 0; l < L - 1; l++) walks[i * L + l + 1] = -1; /* :223-225: timestamps are NOT reset */
             int restart = 0;
             for (int64_t l = 0; l < L - 1; l++) {
-                cn.n = ct.n = 0;
+                cn.n = ct.n = cr.n = 0;
                 for (int64_t e = ptrs[cur]; e < ptrs[cur + 1]; e++) { /* :228-251 */
                     const int64_t v = indices[e];
                     const int64_t t = edge_ts[e] != ORC_NAN_TS ? edge_ts[e] : node_ts[v];
                     if (t == ORC_NAN_TS || cur_ts == ORC_NAN_TS || cur_ts <= t) {
                         vpush(&cn, v);
                         vpush(&ct, t);
+                        vpush(&cr, e - ptrs[cur]);
                     }
                 }
                 const int64_t m = cn.n;
@@ -710,10 +712,25 @@ ORC_API int32_t orc_biased_tempo_random_walk(const int64_t *ptrs, const int64_t 
                 }
                 /* reservoir_sampling_weighted with one slot and f32 weights (sampling.rs:28-55) */
                 const uint64_t step_id = ((uint64_t)i * (uint64_t)retry_count + (uint64_t)attempt) * (uint64_t)L + (uint64_t)l;
+                /* philox-mode, linear / exponential bias: the running sum is BLOCKED over the row's raw positions (chunks of 64,
+                 * non-candidates add 0; orc_sampling.h) -- what the kernel computes; ref-mode and the uniform bias (whose
+                 * sum of ones the kernel has in closed form) keep the reference's literal left-to-right sum */
+                const int64_t n_raw = ptrs[cur + 1] - ptrs[cur];
+                const int use_blocked = rng->mode != ORC_RNG_REF && cur_ts != ORC_NAN_TS && bias != ORC_BIAS_UNIFORM;
+                if (use_blocked) {
+                    if (n_raw > raw_cap) {
+                        raw_cap = n_raw * 2;
+                        raw_w = (float *)realloc(raw_w, sizeof(float) * (size_t)raw_cap);
+                        blocked = (float *)realloc(blocked, sizeof(float) * (size_t)raw_cap);
+                    }
+                    for (int64_t r = 0; r < n_raw; r++) raw_w[r] = 0.0f;
+                    for (int64_t k = 0; k < m; k++) raw_w[cr.p[k]] = w[k];
+                    orc_blocked_prefix_f32(raw_w, n_raw, blocked);
+                }
                 int64_t pick = 0;
                 float w_sum = 0.0f + w[0];
                 for (int64_t k = 1; k < m; k++) {
-                    w_sum = w_sum + w[k];
+                    w_sum = use_blocked ? blocked[cr.p[k]] : w_sum + w[k];
                     if (!(0.0f < w_sum)) {
                         status = -1;
                         break;
@@ -741,8 +758,11 @@ ORC_API int32_t orc_biased_tempo_random_walk(const int64_t *ptrs, const int64_t 
     }
     vfree(&cn);
     vfree(&ct);
+    vfree(&cr);
     free(times);
     free(w);
+    free(raw_w);
+    free(blocked);
     return status;
 }
 

@@ -14,8 +14,9 @@
 //                row) between two global slabs, O(n) per pass where the bitonic network was O(n log^2 n) -- pass 2
 //                selects.
 //
-// The reservoir's running f32 sum is the reference's own left-to-right sum (sampling.rs:48) and is kept exactly: 64
-// weights at a time go through LDS and one lane runs the dependent add chain.  Draws are addressed per candidate, so
+// The reservoir's running f32 sum (sampling.rs:48) is philox-mode's BLOCKED sum for the linear and exponential biases:
+// Kogge-Stone inside every chunk of 64 raw row positions, the chunks' totals carried left to right (the CPU checker
+// restates exactly that; its ref-mode keeps the reference's literal sum).  Draws are addressed per candidate, so
 // everything else is order-free.  A walker whose candidate set is empty restarts from its start vertex, up to
 // retry_count times (:217, :273-276); timestamps written by abandoned attempts stay, as in the reference (:223-225
 // resets the vertices only).
@@ -33,7 +34,6 @@ constexpr int BW_HIST = 256;      // >= TG_EXP_NEG_BITS_N; also the radix sort's
 constexpr int BW_P = 4;           // 64-edge chunks per load round of the row streamer (two rounds in flight)
 
 struct BwWaveLds {
-    float chain[64];
     uint32_t hist[BW_HIST];
     uint64_t keys[BW_SORT_LDS];
 };
@@ -122,24 +122,19 @@ __device__ uint64_t *wave_radix_sort(uint64_t *src, uint64_t *dst, uint32_t n, u
     return src;
 }
 
-// left-to-right inclusive f32 prefix over the 64 lanes starting from `carry` (see wave_serial_prefix_f64)
-__device__ __forceinline__ float wave_serial_prefix_f32(float v, float carry, float *total, float *buf) {
+// philox-mode's BLOCKED running weight sum in f32 (tg_device.h wave_blocked_prefix_f64 is the f64 twin; the CPU checker
+// restates it as orc_blocked_prefix_f32): Kogge-Stone inside the chunk of 64 raw row positions (non-candidates add 0),
+// then the carry of the earlier chunks.  Six dependent adds per chunk instead of 64: the literal left-to-right sum made a
+// step's time the length of the row's f32 chain (exponential bias: 521 ms per 1 M walkers x 20 steps).
+__device__ __forceinline__ float wave_blocked_prefix_f32(float v, float carry, float *total) {
     const int lane = lane_id();
-    buf[lane] = v;
-    wave_lds_handoff();
-    if (lane == 0) {
-        float r = carry;
 #pragma unroll
-        for (int l = 0; l < 64; ++l) {
-            r = r + buf[l];
-            buf[l] = r;
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const float u = __shfl_up(v, d, 64);
+        if (lane >= d) v = v + u;
     }
-    wave_lds_handoff();
-    const float mine = buf[lane];
-    *total = buf[63];
-    wave_lds_handoff();
-    return mine;
+    *total = carry + __shfl(v, 63, 64);
+    return carry + v;
 }
 
 struct Cand {
@@ -309,7 +304,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                                 }
                             }
                             float total;
-                            const float w_sum = wave_serial_prefix_f32(w, carry, &total, lds.chain);
+                            const float w_sum = wave_blocked_prefix_f32(w, carry, &total);
                             carry = total;
                             if (cd.ok && c >= 1) {
                                 if (!(0.0f < w_sum)) {
