@@ -31,7 +31,7 @@ constexpr uint32_t TAG_RW_BIASED = 11u;
 constexpr int BW_WAVES = 4;
 constexpr int BW_SORT_LDS = 1024; // keys per wavefront sorted in LDS
 constexpr int BW_HIST = 256;      // >= TG_EXP_NEG_BITS_N; also the radix sort's digit counters
-constexpr int BW_P = 4;           // 64-edge chunks per load round of the row streamer (two rounds in flight)
+constexpr int BW_P = 4;           // 64-edge chunks per load round of the row streamer (two rounds in flight); 1 is slower here: 116 / 483 / 452 ms
 
 struct BwWaveLds {
     uint32_t hist[BW_HIST];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
 
                 if (bias_now == 0) {
                     // ---- uniform: one pass; w_sum after candidate c is min(c + 1, 2^24) exactly in f32
-                    stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
+                    stream_row_ts<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t v, bool valid, int64_t ts) { // v: edge position
                         const Cand cd = classify(valid, ts, cur_ts);
                         const uint64_t mask = __ballot(cd.ok);
                         if (cd.ok) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                     }
                     float mx = -__builtin_inff();
                     uint32_t key_or = 0u, key_and = ~0u; // which bits of the time keys differ inside the row
-                    stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
+                    stream_row_ts<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t v, bool valid, int64_t ts) { // v: edge position
                         const Cand cd = classify(valid, ts, cur_ts);
                         const uint64_t mask = __ballot(cd.ok);
                         if (cd.ok) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                             for (int m = lane; m < BW_HIST; m += 64) lds.hist[m] = 0u;
                             wave_lds_handoff();
                             // ---- pass 2 (exponential): histogram of the integer exponents
-                            stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t, int64_t ts) {
+                            stream_row_ts<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t ts) {
                                 const Cand cd = classify(valid, ts, cur_ts);
                                 if (cd.ok) {
                                     const float m = mx - exp_delta(cd.time32, t32, forward);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                         // ---- selection pass: weighted reservoir with one slot (sampling.rs:47-53)
                         float carry = 0.0f;
                         n_c = 0;
-                        stream_row<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t, bool valid, int64_t v, int64_t ts) {
+                        stream_row_ts<BW_P>(indices, edge_ts, node_ts, b, e, lane, [&](int64_t v, bool valid, int64_t ts) { // v: edge position
                             const Cand cd = classify(valid, ts, cur_ts);
                             const uint64_t mask = __ballot(cd.ok);
                             const uint32_t c = n_c + (uint32_t)__popcll(mask & lt_mask);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void biased_walk_kernel(
                 for (int off = 32; off > 0; off >>= 1) mxr = max(mxr, __shfl_xor(mxr, off, 64));
                 const uint64_t owner = (mxr >= 1) ? __ballot(best_rank == mxr) : __ballot(has_first);
                 const int src = __ffsll((long long)owner) - 1;
-                const int64_t next = __shfl((mxr >= 1) ? best_v : first_v, src, 64);
+                const int64_t next = indices[__shfl((mxr >= 1) ? best_v : first_v, src, 64)]; // the one id the step needs
                 const int64_t next_t = __shfl((mxr >= 1) ? best_t : first_t, src, 64);
                 cur = next; // :278-284
                 if (next_t != -1) cur_ts = next_t;

@@ -54,4 +54,47 @@ __device__ __forceinline__ void stream_row(const int64_t *__restrict__ indices, 
     }
 }
 
+// The same walk over a row WITHOUT its neighbour ids: the walks only need the id of the ONE edge they pick (read afterwards
+// from its position) -- and of an edge without a timestamp, for the node-timestamp fallback -- so a pass moves 8 bytes per
+// inspected edge instead of 16.  visit(edge position, valid, effective timestamp).
+template <int P, typename Visit>
+__device__ __forceinline__ void stream_row_ts(const int64_t *__restrict__ indices, const int64_t *__restrict__ edge_ts,
+                                              const int64_t *__restrict__ node_ts, int64_t b, int64_t e, int lane,
+                                              Visit &&visit) {
+    if (b >= e) return;
+    struct Round {
+        int64_t ts[P];
+    };
+    auto issue = [&](Round &r, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int64_t ee = base + u * 64 + lane;
+            r.ts[u] = edge_ts[ee < e ? ee : b];
+        }
+    };
+    auto consume = [&](const Round &r, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            if (base + u * 64 >= e) break; // uniform
+            const int64_t ee = base + u * 64 + lane;
+            const bool valid = ee < e;
+            int64_t ts = r.ts[u];
+            const bool need = valid && ts == -1;
+            if (__ballot(need) != 0ull) {
+                if (need) ts = node_ts[indices[ee]];
+            }
+            visit(ee, valid, ts);
+        }
+    };
+    constexpr int64_t R = (int64_t)64 * P;
+    Round ra, rb;
+    issue(ra, b);
+    for (int64_t base = b; base < e; base += 2 * R) {
+        issue(rb, base + R);
+        consume(ra, base);
+        issue(ra, base + 2 * R);
+        consume(rb, base + R);
+    }
+}
+
 } // namespace tg
