@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libtg_oracle_asan.so" if os.environ.get("ORC_LIB") == "asan" else "libtg_oracle.so")
 
 RNG_REF, RNG_PHILOX = 0, 1
-RES_TICKETS, RES_LITERAL, RES_AUTO = 0, 1, -1
+RES_TICKETS, RES_LITERAL, RES_CHUNKED, RES_AUTO = 0, 1, 2, -1
 SAMPLER_UNIFORM, SAMPLER_UNIFORM_REPL, SAMPLER_WEIGHTED = 0, 1, 2
 FILTER_NONE, FILTER_STATIC, FILTER_RELATIVE, FILTER_DYNAMIC = -1, 0, 1, 2
 TAG_NS_HOMO, TAG_NS_HETERO, TAG_RW, TAG_RW_TEMPO, TAG_NEG_HOMO, TAG_NEG_HETERO, TAG_HGT = 1, 2, 3, 4, 5, 6, 7

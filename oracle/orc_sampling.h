@@ -22,7 +22,8 @@
 
 #define ORC_RES_TICKETS 0
 #define ORC_RES_LITERAL 1
-#define ORC_RES_AUTO (-1) /* what the device uses: tickets for neighbor sampling, literal for the temporal walk */
+#define ORC_RES_CHUNKED 2 /* one slot only: one draw per chunk of 64 raw positions (orc_reservoir_one_chunked) */
+#define ORC_RES_AUTO (-1) /* what the device uses: tickets for neighbor sampling, chunked for the temporal walk */
 
 typedef struct {
     orc_rng *rng;
@@ -95,6 +96,32 @@ static inline int64_t orc_reservoir(orc_ctx *c, uint64_t id, uint32_t d0_base, i
         orc_reservoir_tickets(c, id, d0_base, n, k, dst, scratch);
     }
     return filled;
+}
+
+/* The ONE-SLOT reservoir of the temporal walk (sampling.rs:12-24 with k = 1) with one draw per CHUNK of 64 raw row
+ * positions instead of one per candidate -- philox-mode's definition since round 3 (the kernel forms it with a handful of
+ * wave-wide operations per chunk; a Philox block per candidate was half of its time).  The law is the literal loop's:
+ * with n candidates the loop ends on candidate 0 iff n == 1 and on each of candidates 1..n-1 with probability 1/(n-1)
+ * (item i draws from 0..i, so item 1 always replaces item 0: the quirk noted above).  Here the candidates of rank >= 1
+ * are ELIGIBLE; a chunk holding m of them, after M eligible ones in earlier chunks, takes the slot with probability
+ * m / (M + m) (always when M = 0) and then holds each of its m with probability 1/m: every eligible candidate ends up
+ * chosen with probability 1/(n-1).  Draw of a chunk: (id, d0 = chunk index, d1 = "CHK"); half a decides the take, half b
+ * the candidate.  raw_pos[i] = candidate i's raw position (ascending).  Returns the chosen candidate, -1 when n == 0. */
+static inline int64_t orc_reservoir_one_chunked(orc_ctx *c, uint64_t id, int64_t n, const int64_t *raw_pos) {
+    if (n == 0) return -1;
+    int64_t pick = 0, seen = 0; /* eligible candidates before the current chunk */
+    int64_t i = 1;
+    while (i < n) {
+        const int64_t chunk = raw_pos[i] >> 6;
+        int64_t j = i;
+        while (j < n && (raw_pos[j] >> 6) == chunk) j++;
+        const int64_t m = j - i;
+        const orc_draw d = orc_ctx_draw(c, id, (uint32_t)chunk, 0x43484B00u);
+        if (seen == 0 || orc_bounded(d.a, (uint64_t)(seen + m)) < (uint64_t)m) pick = i + (int64_t)orc_bounded(d.b, (uint64_t)m);
+        seen += m;
+        i = j;
+    }
+    return pick;
 }
 
 /* src/utils/sampling.rs:57-69 replacement_sampling: k draws from [0,n), n>0 */

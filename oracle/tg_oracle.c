@@ -542,7 +542,7 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
         walks[i] = -1;
         walks_ts[i] = -1;
     }
-    vec64 cn = {0}, ct = {0};
+    vec64 cn = {0}, ct = {0}, cr = {0}; /* candidates: neighbour, time, raw position in the row */
     for (int64_t i = 0; i < n; i++) { /* :108 */
         int64_t cur = start[i];
         int64_t it = start_ts[i];
@@ -552,7 +552,7 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
             walks_ts[i * L] = it;
         }
         for (int64_t l = 0; l < walk_length - 1; l++) { /* :117 */
-            cn.n = ct.n = 0;
+            cn.n = ct.n = cr.n = 0;
             for (int64_t e = ptrs[cur]; e < ptrs[cur + 1]; e++) { /* :118-139 */
                 int64_t v = indices[e];
                 int64_t t = edge_ts[e] != ORC_NAN_TS ? edge_ts[e] : node_ts[v];
@@ -560,12 +560,19 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
                 if (ok) {
                     vpush(&cn, v);
                     vpush(&ct, t);
+                    vpush(&cr, e - ptrs[cur]);
                 }
             }
             int64_t pos, scratch[2];
             const uint64_t step_id = (uint64_t)i * (uint64_t)L + (uint64_t)l; /* philox address of this step */
-            int algo = reservoir_algo == ORC_RES_AUTO ? ORC_RES_LITERAL : reservoir_algo;
-            int64_t success = orc_reservoir(&c, step_id, 0, cn.n, 1, &pos, scratch, algo);
+            int algo = reservoir_algo == ORC_RES_AUTO ? ORC_RES_CHUNKED : reservoir_algo;
+            int64_t success;
+            if (rng->mode != ORC_RNG_REF && algo == ORC_RES_CHUNKED) { /* what the kernel computes */
+                pos = orc_reservoir_one_chunked(&c, step_id, cn.n, cr.p);
+                success = cn.n > 0;
+            } else {
+                success = orc_reservoir(&c, step_id, 0, cn.n, 1, &pos, scratch, algo == ORC_RES_CHUNKED ? ORC_RES_LITERAL : algo);
+            }
             int64_t next, next_t;
             if (success == 0) { /* :144-148 restart from an earlier position */
                 uint64_t rr;
@@ -586,6 +593,7 @@ ORC_API void orc_tempo_random_walk(const int64_t *ptrs, const int64_t *indices, 
     }
     vfree(&cn);
     vfree(&ct);
+    vfree(&cr);
 }
 
 /* ------------------------------------------------------------------ */

@@ -200,27 +200,53 @@ __global__ void rw_tempo_kernel(const int64_t *__restrict__ ptrs, const int64_t 
     for (int64_t l = 0; l < L - 1; ++l) { // :117
         const uint64_t step_id = (uint64_t)i * (uint64_t)L + (uint64_t)l;
         const int64_t b = ptrs[cur], e = ptrs[cur + 1];
-        uint32_t n_pass = 0;
-        int64_t best_rank = -1, best_v = -1, best_t = -1; // this lane's last reservoir hit: rank, edge position, time
-        int64_t first_v = -1, first_t = -1;               // candidate of rank 0 (held by one lane)
+        // one-slot reservoir over the candidates in row order (sampling.rs:12-24 with k = 1), philox-mode: ONE draw per chunk
+        // of 64 raw row positions (the CPU checker's orc_reservoir_one_chunked states the law).  Candidates of rank >= 1 are
+        // eligible; a chunk with m of them, after `seen` earlier ones, takes the slot with probability m / (seen + m) and
+        // gives it to one of its m.  The draws of 64 consecutive chunks are computed TOGETHER, lane l the block of chunk
+        // 64 g + l, when the row first needs one of group g: a Philox block per 4 096 row positions and wavefront instead
+        // of one per 64 (a block per chunk on the scalar unit costs what the per-candidate blocks cost on the vector unit:
+        // both issue once per chunk -- measured 101 ms against 75).
+        uint32_t n_pass = 0, seen = 0;
+        int64_t best_v = -1, best_t = -1; // the slot's candidate (edge position, time), held by one lane
+        bool have_best = false;
+        int64_t first_v = -1, first_t = -1; // candidate of rank 0 (held by one lane)
         bool has_first = false;
+        uint32_t group = 0xffffffffu; // the group of 64 chunks whose draws the lanes hold
+        Draw gd;
+        gd.w[0] = gd.w[1] = gd.w[2] = gd.w[3] = 0u;
         auto visit = [&](int64_t v, bool valid, int64_t ts) { // v: edge position
             const bool ok = valid && ((ts == -1 || it == -1) || (wlo <= ts && ts < whi)); // :129-138
             const uint64_t mask = __ballot(ok);
-            if (ok) {
-                const uint32_t rank = n_pass + (uint32_t)__popcll(mask & lt_mask);
-                if (rank == 0) {
-                    first_v = v;
-                    first_t = ts;
-                    has_first = true;
-                } else { // sampling.rs:19-21 with one slot: j drawn from 0..rank, replaces when j == 0
-                    const Draw d = draw(ck, step_id, rank, D1_LITERAL);
-                    if (bounded64(d.a(), (uint64_t)rank) == 0) {
-                        best_rank = rank;
+            const uint32_t rank = n_pass + (uint32_t)__popcll(mask & lt_mask);
+            if (ok && rank == 0) {
+                first_v = v;
+                first_t = ts;
+                has_first = true;
+            }
+            const bool eligible = ok && rank >= 1;
+            const uint64_t emask = __ballot(eligible);
+            const uint32_t m = (uint32_t)__popcll(emask);
+            if (m > 0) { // uniform
+                const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((v - b) >> 6));
+                if ((chunk >> 6) != group) { // uniform
+                    group = chunk >> 6;
+                    gd = draw(ck, step_id, (group << 6) + (uint32_t)lane, D1_CHUNK);
+                }
+                const int from = (int)(chunk & 63u);
+                const uint64_t da = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)gd.w[0], from) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)gd.w[1], from) << 32);
+                const uint64_t db = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)gd.w[2], from) |
+                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)gd.w[3], from) << 32);
+                if (seen == 0 || bounded64(da, (uint64_t)(seen + m)) < (uint64_t)m) {
+                    const uint32_t r = (uint32_t)bounded64(db, (uint64_t)m);
+                    have_best = eligible && (uint32_t)__popcll(emask & lt_mask) == r;
+                    if (have_best) {
                         best_v = v;
                         best_t = ts;
                     }
                 }
+                seen += m;
             }
             n_pass += (uint32_t)__popcll(mask);
         };
@@ -238,13 +264,10 @@ __global__ void rw_tempo_kernel(const int64_t *__restrict__ ptrs, const int64_t 
             next = hist[rr];
             next_t = hist[L + rr];
         } else {
-            int64_t mx = best_rank;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-            const uint64_t owner = (mx >= 1) ? __ballot(best_rank == mx) : __ballot(has_first);
+            const uint64_t owner = (seen > 0) ? __ballot(have_best) : __ballot(has_first);
             const int src = __ffsll((long long)owner) - 1;
-            next = indices[__shfl((mx >= 1) ? best_v : first_v, src, 64)]; // the one neighbour id the step needs
-            next_t = __shfl((mx >= 1) ? best_t : first_t, src, 64);
+            next = indices[__shfl((seen > 0) ? best_v : first_v, src, 64)]; // the one neighbour id the step needs
+            next_t = __shfl((seen > 0) ? best_t : first_t, src, 64);
         }
         cur = next; // :150-153
         if (lane == 0) {

@@ -22,6 +22,7 @@ constexpr uint32_t D1_REPLACE = 0x52455000u;  // "REP"
 constexpr uint32_t D1_LITERAL = 0x4C495400u;  // "LIT"
 constexpr uint32_t D1_WEIGHTED = 0x57475400u; // "WGT"
 constexpr uint32_t D1_RESTART = 0x52535400u;  // "RST"
+constexpr uint32_t D1_CHUNK = 0x43484B00u;    // "CHK"
 
 struct Draw {
     uint32_t w[4];
