@@ -511,55 +511,103 @@ __device__ __forceinline__ void hw_select_long(const HopScanParams &p, unsigned 
             }
             __syncthreads();
         } else {
-            for (int64_t c = wave; c < nc; c += n_waves) { // (A)
-                bool ok;
-                uint64_t mask;
-                double wv, t2;
-                int64_t e;
-                chunk(c, ok, mask, wv, e);
-                (void)wave_blocked_prefix_f64(wv, 0.0, &t2);
-                if (lane == 0) {
-                    tot[c] = t2;
-                    cnt[c] = (uint32_t)__popcll(mask);
+            constexpr int U = 4; // chunks whose loads a wavefront keeps in flight
+            for (int64_t c0 = (int64_t)wave * U; c0 < nc; c0 += (int64_t)n_waves * U) { // (A) chunk totals and counts
+                bool ok[U];
+                uint64_t mask[U];
+                double wv[U];
+                int64_t e[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) chunk(min(c0 + u, nc - 1), ok[u], mask[u], wv[u], e[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c0 + u >= nc) break; // uniform
+                    double t2;
+                    (void)wave_blocked_prefix_f64(wv[u], 0.0, &t2);
+                    if (lane == 0) {
+                        tot[c0 + u] = t2;
+                        cnt[c0 + u] = (uint32_t)__popcll(mask[u]);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (tid == 0) { // (B)
-                double run = 0.0;
-                uint32_t n = 0;
-                for (int64_t c = 0; c < nc; ++c) {
-                    const double t2 = tot[c];
-                    const uint32_t q = cnt[c];
-                    tot[c] = run;
-                    cnt[c] = n;
-                    run = run + t2;
-                    n += q;
+            { // (B) carries and ranks before every chunk, added left to right: tiles of 1 024 chunks through LDS, where one
+              // lane's dependent chain costs ~10 ns per chunk (in global memory every step of it waited for a load: 0.5 us
+              // per chunk, 0.8 ms for a column of 10^5 edges -- the whole call's time)
+                __shared__ double tile_t[1024];
+                __shared__ uint32_t tile_c[1024];
+                __shared__ double run_s;
+                __shared__ uint32_t n_s;
+                if (tid == 0) {
+                    run_s = 0.0;
+                    n_s = 0;
                 }
-                n_total_s = n;
+                for (int64_t c0 = 0; c0 < nc; c0 += 1024) {
+                    const int64_t c = c0 + tid;
+                    if (tid < 1024 && c < nc) {
+                        tile_t[tid] = tot[c];
+                        tile_c[tid] = cnt[c];
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        double run = run_s;
+                        uint32_t n = n_s;
+                        const int len = (int)min((int64_t)1024, nc - c0);
+                        for (int i = 0; i < len; ++i) {
+                            const double t2 = tile_t[i];
+                            const uint32_t q = tile_c[i];
+                            tile_t[i] = run;
+                            tile_c[i] = n;
+                            run = run + t2;
+                            n += q;
+                        }
+                        run_s = run;
+                        n_s = n;
+                    }
+                    __syncthreads();
+                    if (tid < 1024 && c < nc) {
+                        tot[c] = tile_t[tid];
+                        cnt[c] = tile_c[tid];
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0) n_total_s = n_s;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            for (int64_t c = wave; c < nc; c += n_waves) { // (C)
-                bool ok;
-                uint64_t mask;
-                double wv, t2;
-                int64_t e;
-                chunk(c, ok, mask, wv, e);
-                const uint32_t rank = cnt[c] + (uint32_t)__popcll(mask & lt_mask);
-                const double pref = wave_blocked_prefix_f64(wv, tot[c], &t2); // blocked running sum, sampling.rs:40,48
-                if (ok && rank < (uint32_t)k) slot_ptr[rank] = e; // sampling.rs:37-45
-                if (ok && rank >= (uint32_t)k) {
-                    if (!(0.0 < pref)) {
-                        atomicOr(p.status, 2);
-                    } else {
-                        const Draw d = draw(ck, did, rank, D1_WEIGHTED);
-                        const double j = u64_to_f64_01(d.a()) * pref + 0.0;
-                        if (j < wv)
-                            atomicMax(&slot_best[bounded64(d.b(), (uint64_t)k)],
-                                      ((unsigned long long)rank << 32) | (unsigned long long)(e - e0));
+            for (int64_t c0 = (int64_t)wave * U; c0 < nc; c0 += (int64_t)n_waves * U) { // (C) draws
+                bool ok[U];
+                uint64_t mask[U];
+                double wv[U], carry[U];
+                int64_t e[U];
+                uint32_t before[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t c = min(c0 + u, nc - 1);
+                    chunk(c, ok[u], mask[u], wv[u], e[u]);
+                    carry[u] = tot[c];
+                    before[u] = cnt[c];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c0 + u >= nc) break; // uniform
+                    double t2;
+                    const uint32_t rank = before[u] + (uint32_t)__popcll(mask[u] & lt_mask);
+                    const double pref = wave_blocked_prefix_f64(wv[u], carry[u], &t2); // blocked running sum, sampling.rs:40,48
+                    if (ok[u] && rank < (uint32_t)k) slot_ptr[rank] = e[u]; // sampling.rs:37-45
+                    if (ok[u] && rank >= (uint32_t)k) {
+                        if (!(0.0 < pref)) {
+                            atomicOr(p.status, 2);
+                        } else {
+                            const Draw d = draw(ck, did, rank, D1_WEIGHTED);
+                            const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                            if (j < wv[u])
+                                atomicMax(&slot_best[bounded64(d.b(), (uint64_t)k)],
+                                          ((unsigned long long)rank << 32) | (unsigned long long)(e[u] - e0));
+                        }
                     }
                 }
             }

@@ -34,7 +34,17 @@ seeds = [_cabi.seed_batches(0xBA7C4, c, 1, 1024, 1 << 23, dev)[0].contiguous() f
 ns = {t: [512, 512] for t in node_types}
 
 
+if what == "homo_weighted":   # the homogeneous operator with weights on RMAT-24 (hub columns of 10^5 edges)
+    row, col = _cabi.rmat_edges(24, 16 << 24, 0x5EED0000 + 24, dev)
+    HP, HI, _ = _cabi.coo_to_csx(row, col, 1 << 24, 1 << 24, True)
+    del row, col
+    HW = torch.rand(HI.numel(), device=dev, generator=g, dtype=torch.float64) + 0.1
+    seeds = [_cabi.seed_batches(0xBA7C4, c, 1, 1024, 1 << 24, dev)[0].contiguous() for c in range(calls + 1)]
+
+
 def call(sd):
+    if what == "homo_weighted":
+        return tg.neighbor_sampling_homogenous(HP, HI, sd, [15, 10], tg.WeightedEdgeSampler(HW))
     if what == "filtered":
         flt_h = (tg.TemporalEdgeFilter((0, 49), hts, False, tg.TEMPORAL_SAMPLE_STATIC), {"A": torch.full_like(sd, 50)})
         return tg.neighbor_sampling_heterogenous(node_types, edge_types, P, I, {"A": sd}, nn, 2, None, flt_h)
