@@ -9,7 +9,9 @@ SOL=1 timeout -k 10 400 python tools/ab_tuning.py "staged:staged=1" "push_r02_pi
 timeout -k 10 200 tools/bin/probe_permute 26 > gpurun_out/r03/probe_permute.jsonl 2>/dev/null
 timeout -k 10 600 python tools/bench_loader.py > gpurun_out/r03/loader.json 2> gpurun_out/r03/loader.err || { tail gpurun_out/r03/loader.err; exit 1; }
 timeout -k 10 300 python tools/bench_hetero.py > gpurun_out/r03/hetero.json 2> gpurun_out/r03/hetero.err
-bash tools/trace_het.sh hgt 50 > /dev/null 2>&1; bash tools/trace_het.sh weighted 50 > /dev/null 2>&1; bash tools/trace_het.sh filtered 50 > /dev/null 2>&1
+timeout -k 10 300 python tools/bench_secondary.py > gpurun_out/r03/secondary_random_walk.json 2> gpurun_out/r03/secondary_random_walk.err
+timeout -k 10 300 python tools/bench_misc.py > gpurun_out/r03/secondary_misc.json 2> gpurun_out/r03/secondary_misc.err
+bash tools/trace_het.sh hgt 50 > /dev/null 2>&1; bash tools/trace_het.sh weighted 50 > /dev/null 2>&1; bash tools/trace_het.sh filtered 50 > /dev/null 2>&1; bash tools/trace_het.sh homo_weighted 30 > /dev/null 2>&1
 python bench.py --mode partitioned --steps 6 --warmup 2 > gpurun_out/r03/part_w1.json 2> gpurun_out/r03/part_w1.err
 python bench.py > gpurun_out/r03/bench_default.json 2> gpurun_out/r03/bench_default.err || { tail gpurun_out/r03/bench_default.err; exit 1; }
 tail -c 600 gpurun_out/r03/ab_final.jsonl; python3 -c "
