@@ -59,6 +59,10 @@ struct HopScanParams {
     uint64_t *gchunk; // [group_cap] admissible edges of each of the group's 8 chunks, one byte each (<= 64)
     int64_t *gpref;   // [group_cap + 1] exclusive prefix of gcount
     int64_t *park;    // [m * k]
+    double *gtot;     // weighted sampler, group form: [group_cap * 8] chunk totals -> carries before the chunks
+    uint32_t *grank;  // [group_cap] candidates of the vertex before the group
+    unsigned long long *slot_best; // [m * k] (rank << 32 | position in the column) of a slot's last accepted candidate
+    uint32_t *vck;    // [m * 2] the call key of every vertex's draws
     double *long_tot; // weighted sampler, long columns: per workgroup HW_LONG_CHUNKS chunk totals -> carries ...
     uint32_t *long_cnt; // ... and admissible edges per chunk -> candidates before the chunk
     int32_t *status;  // [0] overflow flag
@@ -354,6 +358,7 @@ __global__ void hs_select_kernel(const HopScanParams p) {
 // takes such a column (hw_select_long_kernel).  status[0] |= 2 where the reference panics (running sum <= 0).
 constexpr int64_t HW_LONG_EDGES = 16384;  // columns longer than this go to hw_select_long_kernel
 constexpr int HW_LONG_BLOCKS = 256;       // its workgroups (each with its own scratch)
+constexpr int64_t HW_GROUP_FORM_MIN = 1024; // group_cap from which the weighted sampler takes its group form
 constexpr int64_t HW_LONG_CHUNKS = 8192;  // chunks of 64 edges its scratch holds per workgroup (512 K edges); beyond: one
                                           // wavefront walks the column as before
 // the long columns of the frontier -> vgroups[1 ...], their number -> vgroups[0] (zeroed by the launcher)
@@ -669,6 +674,188 @@ __global__ void hs_emit_kernel(const HopScanParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------- weighted sampler, GROUP FORM
+// The same algorithm with the work cut like the filtered path's: a hub column of 10^5 edges no longer sits on one wavefront
+// (or one workgroup) while the device idles.  (1) hw_gtotals: FLAT over the 512-edge groups of all frontier columns --
+// admissible counts and the blocked sum's chunk totals; (2) hw_gcarry: a wavefront per vertex turns its chunk totals into
+// the carries before every chunk (left to right: the defined order) and its group counts into candidate ranks, sets the
+// vertex's count and clears its slots; (3) hw_gdraw: FLAT over the groups again -- candidates of rank < k fill slot rank,
+// an accepted later candidate raises its slot to (rank, position) with a 64-bit atomic max: the LAST accepted candidate of
+// a slot wins, as in the reference's loop, whatever order the groups run in; (4) hw_gresolve reads the slots out.  Same
+// draws (named by (call, vertex, rank)), same running sums, same result as the column-at-a-time kernels above.
+template <typename Body>
+__device__ __forceinline__ void hs_for_groups(const HopScanParams &p, const HsSeg *S, int64_t m, Body &&body) {
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t gt = p.vgroups[m];
+    if (gt >= p.group_cap) return;
+    const int64_t run = max((int64_t)1, min((int64_t)HS_RUN, (gt + n_waves - 1) / n_waves));
+    for (int64_t g0 = wave_id * run; g0 < gt; g0 += n_waves * run) {
+        int64_t lo = 0, hi = m - 1; // vertex owning group g0: last v with vgroups[v] <= g0
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (p.vgroups[mid] <= g0)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        int64_t v = lo;
+        const int64_t g1 = min(g0 + run, gt);
+        for (int64_t g = g0; g < g1; ++g) {
+            while (g >= p.vgroups[v + 1]) ++v; // skip to the owner (vertices without groups own nothing)
+            body(g, v, S[hs_seg_of(S, p.n_seg, v)]);
+        }
+    }
+}
+__global__ void hw_gtotals_kernel(const HopScanParams p) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    const int lane = threadIdx.x & 63;
+    const bool filtered = p.filter_mode != TG_FILTER_NONE;
+    hs_for_groups(p, S, m, [&](int64_t g, int64_t v, const HsSeg &sg) {
+        const int64_t w = p.vertices[v];
+        const int64_t st = p.states ? p.states[v] : 0;
+        const int64_t e1 = sg.ptrs[w + 1];
+        const int64_t gb = sg.ptrs[w] + (g - p.vgroups[v]) * HS_GROUP;
+        int64_t tsv[HS_CHUNKS];
+        double wvv[HS_CHUNKS];
+#pragma unroll
+        for (int u = 0; u < HS_CHUNKS; ++u) {
+            const int64_t e = gb + u * 64 + lane;
+            tsv[u] = (filtered && e < e1) ? __builtin_nontemporal_load(&sg.timestamps[e]) : 0;
+            wvv[u] = (e < e1) ? __builtin_nontemporal_load(&sg.weights[e]) : 0.0;
+        }
+        uint32_t c = 0;
+        uint64_t per_chunk = 0;
+        double mine = 0.0; // lane u keeps chunk u's total
+#pragma unroll
+        for (int u = 0; u < HS_CHUNKS; ++u) {
+            const int64_t e = gb + u * 64 + lane;
+            const bool ok = e < e1 && hs_pass(p, st, tsv[u]);
+            const uint32_t cu = (uint32_t)__popcll(__ballot(ok));
+            c += cu;
+            per_chunk |= (uint64_t)cu << (8 * u);
+            double tot;
+            (void)wave_blocked_prefix_f64(ok ? wvv[u] : 0.0, 0.0, &tot); // x + 0.0 == x: excluded edges add nothing
+            if (lane == u) mine = tot;
+        }
+        if (lane < HS_CHUNKS) p.gtot[g * HS_CHUNKS + lane] = mine;
+        if (lane == 0) {
+            p.gcount[g] = c;
+            p.gchunk[g] = per_chunk;
+        }
+    });
+}
+// wavefront per vertex
+__global__ void hw_gcarry_kernel(const HopScanParams p) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    __shared__ double chain_s[4][64];
+    const int64_t m = hs_load_segs(p, S);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const bool overflow = p.vgroups[m] >= p.group_cap;
+    const int kmax = p.k;
+    for (int64_t v = wave_id; v < m; v += n_waves) {
+        const HsSeg &sg = S[hs_seg_of(S, p.n_seg, v)];
+        const int64_t g0 = p.vgroups[v], g1 = overflow ? g0 : p.vgroups[v + 1];
+        for (int sl = lane; sl < kmax; sl += 64) p.slot_best[v * kmax + sl] = 0ull;
+        if (lane == 0) {
+            const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
+            p.vck[2 * v] = ck.k0;
+            p.vck[2 * v + 1] = ck.k1;
+        }
+        double carry = 0.0;
+        const int64_t c_begin = g0 * HS_CHUNKS, c_end = g1 * HS_CHUNKS;
+        for (int64_t c0 = c_begin; c0 < c_end; c0 += 64) { // carries before the chunks: the totals added left to right
+            const int64_t c = c0 + lane;
+            const double t = c < c_end ? p.gtot[c] : 0.0;
+            double total;
+            const double incl = wave_serial_prefix_f64(t, carry, &total, chain_s[wave]);
+            const double before = __shfl_up(incl, 1, 64);
+            if (c < c_end) p.gtot[c] = lane == 0 ? carry : before;
+            carry = total;
+        }
+        uint32_t n = 0;
+        for (int64_t gq = g0; gq < g1; gq += 64) { // candidates before every group
+            const int64_t g = gq + lane;
+            const uint32_t cg = g < g1 ? p.gcount[g] : 0u;
+            const uint32_t incl = wave_inclusive_scan(cg);
+            if (g < g1) p.grank[g] = n + incl - cg;
+            n += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) p.cnt[v] = min(n, (uint32_t)sg.k);
+    }
+}
+__global__ void hw_gdraw_kernel(const HopScanParams p) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool filtered = p.filter_mode != TG_FILTER_NONE;
+    const int kmax = p.k;
+    hs_for_groups(p, S, m, [&](int64_t g, int64_t v, const HsSeg &sg) {
+        const int64_t w = p.vertices[v];
+        const int64_t st = p.states ? p.states[v] : 0;
+        const int k = sg.k;
+        const int64_t e0 = sg.ptrs[w], e1 = sg.ptrs[w + 1];
+        const int64_t gb = e0 + (g - p.vgroups[v]) * HS_GROUP;
+        const uint64_t did = p.ids ? (uint64_t)p.ids[v] : (uint64_t)(p.id_base + v);
+        const CallKey ck{p.vck[2 * v], p.vck[2 * v + 1]};
+        int64_t tsv[HS_CHUNKS];
+        double wvv[HS_CHUNKS];
+#pragma unroll
+        for (int u = 0; u < HS_CHUNKS; ++u) {
+            const int64_t e = gb + u * 64 + lane;
+            tsv[u] = (filtered && e < e1) ? __builtin_nontemporal_load(&sg.timestamps[e]) : 0;
+            wvv[u] = (e < e1) ? __builtin_nontemporal_load(&sg.weights[e]) : 0.0;
+        }
+        const double my_carry = lane < HS_CHUNKS ? p.gtot[g * HS_CHUNKS + lane] : 0.0;
+        uint32_t n = p.grank[g];
+#pragma unroll
+        for (int u = 0; u < HS_CHUNKS; ++u) {
+            if (gb + u * 64 >= e1) break; // uniform
+            const int64_t e = gb + u * 64 + lane;
+            const bool ok = e < e1 && hs_pass(p, st, tsv[u]);
+            const uint64_t mask = __ballot(ok);
+            const uint32_t rank = n + (uint32_t)__popcll(mask & lt_mask);
+            const double wv = ok ? wvv[u] : 0.0;
+            double tot;
+            const double pref = wave_blocked_prefix_f64(wv, __shfl(my_carry, u, 64), &tot); // blocked running sum, sampling.rs:40,48
+            if (ok && rank < (uint32_t)k) p.park[v * kmax + rank] = e; // sampling.rs:37-45
+            if (ok && rank >= (uint32_t)k) {
+                if (!(0.0 < pref)) {
+                    atomicOr(p.status, 2);
+                } else {
+                    const Draw d = draw(ck, did, rank, D1_WEIGHTED);
+                    const double j = u64_to_f64_01(d.a()) * pref + 0.0;
+                    if (j < wv)
+                        atomicMax(&p.slot_best[v * kmax + (int64_t)bounded64(d.b(), (uint64_t)k)],
+                                  ((unsigned long long)rank << 32) | (unsigned long long)(e - e0));
+                }
+            }
+            n += (uint32_t)__popcll(mask);
+        }
+    });
+}
+// one lane per (vertex, slot)  (rank >= k >= 1: a slot_best of 0 = never hit)
+__global__ void hw_gresolve_kernel(const HopScanParams p) {
+    __shared__ HsSeg S[HS_MAX_SEG];
+    const int64_t m = hs_load_segs(p, S);
+    const int kmax = p.k;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < m * kmax; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = q / kmax;
+        const int sl = (int)(q - v * kmax);
+        if ((uint32_t)sl >= (uint32_t)p.cnt[v]) {
+            p.park[q] = -1;
+            continue;
+        }
+        const unsigned long long sb = p.slot_best[q];
+        if (sb) p.park[q] = S[hs_seg_of(S, p.n_seg, v)].ptrs[p.vertices[v]] + (int64_t)(sb & 0xffffffffull);
+    }
+}
+
 static inline size_t hs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t hs_scan_temp(int64_t n) {
     size_t a = 0, b = 0;
@@ -688,7 +875,10 @@ extern "C" int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t
     *bytes = (int64_t)(hs_align(8 * (size_t)(m + 1)) + hs_align(4 * (size_t)group_cap) + hs_align(8 * (size_t)group_cap) +
                        hs_align(8 * (size_t)(group_cap + 1)) +
                        hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(hs_scan_temp(big)) + 512 +
-                       hs_align(12 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS)); // long columns of the weighted sampler
+                       hs_align(12 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS) + // long columns of the weighted sampler
+                       // ... and its group form: chunk totals, ranks before the groups, slots, call keys
+                       hs_align(8 * (size_t)group_cap * HS_CHUNKS) + hs_align(4 * (size_t)group_cap) +
+                       hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(8 * (size_t)(m > 0 ? m : 1)));
     return TG_OK;
 }
 
@@ -754,6 +944,10 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
         p.long_tot = reinterpret_cast<double *>(ls);
         p.long_cnt = reinterpret_cast<uint32_t *>(ls + 8 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS);
     }
+    p.gtot = reinterpret_cast<double *>(take(8 * (size_t)group_cap * HS_CHUNKS));
+    p.grank = reinterpret_cast<uint32_t *>(take(4 * (size_t)group_cap));
+    p.slot_best = reinterpret_cast<unsigned long long *>(take(8 * (size_t)p.m * p.k));
+    p.vck = reinterpret_cast<uint32_t *>(take(8 * (size_t)p.m));
     void *temp = base + off;
     size_t temp_bytes = (size_t)workspace_bytes - off;
     p.status = status;
@@ -776,7 +970,24 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
                "%s: a device-side layout needs a frontier bound <= %lld and a group bound <= %lld", who, (long long)SCAN1_MAX,
                (long long)SCAN1_GROUPS_MAX);
     size_t st = temp_bytes;
-    if (c.weighted) {
+    // the weighted sampler takes the GROUP FORM whenever the caller sized the workspace for the frontier's groups (the
+    // same bound as the filtered path's; reached: status |= 1, all counts 0, retry with more) -- with the historical
+    // group_cap = 1 it keeps the column-at-a-time kernels
+    const bool weighted_groups = c.weighted && group_cap >= HW_GROUP_FORM_MIN;
+    if (weighted_groups) {
+        if (short_m) {
+            hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL(hs_groups_kernel, grid(p.m, 256), dim3(256), 0, stream, p);
+            TG_HIP(rocprim::inclusive_scan(temp, st, p.vgroups + 1, p.vgroups + 1, (size_t)p.m, rocprim::plus<int64_t>(),
+                                           stream, false));
+            hipLaunchKernelGGL(hs_check_kernel, dim3(1), dim3(64), 0, stream, p);
+        }
+        hipLaunchKernelGGL(hw_gtotals_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(hw_gcarry_kernel, grid(p.m * 64, 256), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(hw_gdraw_kernel, dim3(256 * 8), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(hw_gresolve_kernel, grid(p.m * p.k, 256), dim3(256), 0, stream, p);
+    } else if (c.weighted) {
         int n_waves = 4;
         while (n_waves > 1 && (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t) > 60 * 1024) n_waves >>= 1;
         const size_t lds = (size_t)n_waves * (2 * p.k + 64) * sizeof(int64_t);
@@ -866,6 +1077,25 @@ extern "C" int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, cons
     return hs_run("tg_ns_hop_weighted", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes, 1,
                   (hipStream_t)stream_);
 }
+// the same hop in the weighted sampler's GROUP FORM (chunk totals and draws flat over the 512-edge groups of all columns)
+extern "C" int tg_ns_hop_weighted_groups(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *flt, const tg_rng *rng,
+                                         const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
+                                         int64_t workspace_bytes, int64_t group_cap, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(csc && csc->ptrs && in && rng && out && status, "tg_ns_hop_weighted_groups: null argument");
+    TG_REQUIRE(csc->weights, "tg_ns_hop_weighted_groups: the graph has no edge weights");
+    const int filter_mode = flt ? flt->filter_mode : TG_FILTER_NONE;
+    TG_REQUIRE(filter_mode >= TG_FILTER_NONE && filter_mode <= TG_FILTER_DYNAMIC, "tg_ns_hop_weighted_groups: bad filter");
+    TG_REQUIRE(filter_mode == TG_FILTER_NONE || (csc->timestamps && flt->states && states_out),
+               "tg_ns_hop_weighted_groups: the filter needs edge timestamps and states");
+    HsCall c{};
+    c.seg[0] = HsSeg{csc->ptrs, csc->indices, csc->timestamps, csc->weights, 0, in->fanout, in->rng_tag ? in->rng_tag : TG_TAG_NS_HOMO};
+    c.n_seg = 1;
+    c.kmax = in->fanout;
+    c.weighted = true;
+    return hs_run("tg_ns_hop_weighted_groups", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes, group_cap,
+                  (hipStream_t)stream_);
+}
 
 extern "C" int tg_ns_hop_segments(const tg_hop_segment *segments, int32_t n_segments, const tg_hop_in *in,
                                   const int64_t *layout_dev, const tg_hop_filter *flt, const tg_rng *rng,
@@ -899,6 +1129,6 @@ extern "C" int tg_ns_hop_segments(const tg_hop_segment *segments, int32_t n_segm
                          g.rng_tag ? g.rng_tag : TG_TAG_NS_HOMO};
         if (g.fanout > c.kmax) c.kmax = g.fanout;
     }
-    return hs_run("tg_ns_hop_segments", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes,
-                  weighted ? 1 : group_cap, (hipStream_t)stream_);
+    return hs_run("tg_ns_hop_segments", c, in, flt, rng, out, states_out, status, workspace, workspace_bytes, group_cap,
+                  (hipStream_t)stream_); // weighted: the group form from group_cap >= 1024 on, column at a time below
 }

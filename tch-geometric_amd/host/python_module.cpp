@@ -150,7 +150,7 @@ bool run_ns_filtered_device(NsResult &r, const c10::Device &dev, const tg_graph 
     int64_t status_h = 0;
     for (int64_t group_mult = 1;; group_mult *= 8) { // a retry only when the column-group guess was too low
         auto groups = [&](int h) {
-            return weighted ? (int64_t)1 : group_mult * std::max<int64_t>(1024, g.n_edges / 512 + 2 * cap_f[(size_t)h] + 2);
+            return group_mult * std::max<int64_t>(1024, g.n_edges / 512 + 2 * cap_f[(size_t)h] + 2); // weighted: group form
         };
         int64_t ws_max = 0;
         for (int h = 0; h < H; ++h) {
@@ -276,16 +276,22 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
             Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
             check_rc(tg_ns_hop(&g, &in, &rng, &out, ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
             total = read_scalar<int64_t>(offsets[m]);
-        } else if (weighted) { // sampling.rs:28-55, one wavefront per frontier vertex all over the device
-            Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
-            int64_t ws_bytes = 0;
-            check_rc(tg_ns_hop_scan_workspace_bytes(m, (int32_t)k, 1, &ws_bytes));
-            Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
-            check_rc(tg_ns_hop_weighted(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
-                                        ws.data_ptr<int64_t>(), ws_bytes, stream_of(dev)));
-            total = read_scalar<int64_t>(offsets[m]);
-            if (read_scalar<int32_t>(status) & 2) // sampling.rs:49: gen_range over an empty float range panics
-                throw PanicError("weighted sampling met a non-positive running weight sum (the reference panics here)");
+        } else if (weighted) { // sampling.rs:28-55 in the group form: flat over the 512-edge groups of the frontier's columns
+            for (;;) {
+                Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
+                int64_t ws_bytes = 0;
+                check_rc(tg_ns_hop_scan_workspace_bytes(m, (int32_t)k, group_cap, &ws_bytes));
+                Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
+                check_rc(tg_ns_hop_weighted_groups(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
+                                                   status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes, group_cap,
+                                                   stream_of(dev)));
+                total = read_scalar<int64_t>(offsets[m]);
+                const int32_t st_h = read_scalar<int32_t>(status);
+                if (st_h & 2) // sampling.rs:49: gen_range over an empty float range panics
+                    throw PanicError("weighted sampling met a non-positive running weight sum (the reference panics here)");
+                if (!(st_h & 1)) break;
+                group_cap *= 8; // the frontier's columns need more groups than guessed
+            }
         } else
         for (;;) { // the frontier's columns need sum(ceil(deg/512)) groups; grow the workspace if the guess was low
             Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
@@ -803,8 +809,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                            ep.data_ptr<int64_t>(), par.data_ptr<int64_t>()};
             for (int64_t group_mult = 1;; group_mult *= 8) { // a retry only when a column-group guess was too low
                 auto groups_of_hop = [&](int h) {
-                    return weighted ? (int64_t)1
-                                    : group_mult * std::max<int64_t>(1024, hop_groups[(size_t)h] + 2 * hop_m[(size_t)h] + 2);
+                    return group_mult * std::max<int64_t>(1024, hop_groups[(size_t)h] + 2 * hop_m[(size_t)h] + 2);
                 };
                 int64_t ws_max = 0; // one workspace for every step of the call
                 for (int h = 0; h < H; ++h) {

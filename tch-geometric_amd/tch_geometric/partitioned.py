@@ -255,14 +255,15 @@ class PartitionedSampler:
         # the column-group workspace is a guess (a vertex requested many times counts its groups every time); a hop whose
         # guess was too low raises status bit 1 and samples nothing -- sample() sees it in the call's ONE read-back,
         # enlarges the guess (kept for later calls) and runs the call again: no read-back per hop
-        group_cap = 1 if weighted else max(1, int(self._group_mult * max(1024, graph.n_edges // 512 + 2 * m_cap + 2)))
+        group_cap = max(1, int(self._group_mult * max(1024, graph.n_edges // 512 + 2 * m_cap + 2)))
         _cabi.check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m_cap), C.c_int32(k), C.c_int64(group_cap),
                                                        C.byref(nbytes)))
         ws = self._buf("g_ws", nbytes.value // 8 + 1, i64)
         status.zero_()
         if weighted:
-            _cabi.check(lib.tg_ns_hop_weighted(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
-                                               ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), stream))
+            _cabi.check(lib.tg_ns_hop_weighted_groups(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
+                                                      ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value),
+                                                      C.c_int64(group_cap), stream))
         else:
             _cabi.check(lib.tg_ns_hop_scan(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
                                            ptr(st_out), ptr(status), ptr(ws), C.c_int64(nbytes.value), C.c_int64(group_cap),
