@@ -251,8 +251,8 @@ TG_API int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, const tg
                               int64_t workspace_bytes, void *stream);
 /* The same hop in the GROUP FORM: the columns are cut into the 512-edge groups of the filtered hop above; chunk totals and
  * draws run flat over the groups of ALL frontier columns, the carries of the blocked running sum per column between
- * them -- a hub column no longer occupies one wavefront or one workgroup while the device idles (RMAT-24, 64 batches:
- * 39.7 -> see DESIGN.md 4.2).  Same draws, same sums, same result.  group_cap >= 1024 bounds the frontier's groups as in
+ * them -- a hub column no longer occupies one wavefront or one workgroup while the device idles (RMAT-24, 64 batches of
+ * 1 024 seeds: 39.7 -> 15.3 ms).  Same draws, same sums, same result.  group_cap >= 1024 bounds the frontier's groups as in
  * tg_ns_hop_scan (reached: status[0] |= 1, all counts 0 -- retry with more); workspace:
  * tg_ns_hop_scan_workspace_bytes(m, fanout, group_cap).  tg_ns_hop_segments takes this form under the same condition. */
 TG_API int tg_ns_hop_weighted_groups(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *filter, const tg_rng *rng,
