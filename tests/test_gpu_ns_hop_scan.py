@@ -157,3 +157,59 @@ def _one(cabi, graph, verts, states, k, mode, window, ids, tag, weighted):
                                            cabi.ptr(st_out), cabi.ptr(status), cabi.ptr(ws), C.c_int64(nbytes.value),
                                            cabi.stream_ptr(dev)))
     return cnt, offsets, nbr, ep, par, st_out, status
+
+
+@pytest.mark.parametrize("mode,window", [(-1, (0, 0)), (0, (10, 60)), (2, (0, 30))])
+@pytest.mark.parametrize("k", [1, 9, 40])
+def test_weighted_group_form_equals_the_column_form(mode, window, k):
+    """tg_ns_hop_weighted_groups (totals and draws flat over the 512-edge groups of all columns) == tg_ns_hop_weighted (a
+    wavefront / a workgroup per column): same counts, neighbours, edge pointers, parents, states; a hub graph so that
+    columns span many groups; too small a group bound raises status bit 1 and samples nothing."""
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    cabi, ptrs, idx, ts, g, n = _setup(dev)
+    rs = np.random.default_rng(31 + k)
+    ei = np.stack([rs.integers(0, n, 300000), rs.integers(0, n, 300000)])
+    ei[1, rs.integers(0, 300000, 120000)] = rs.integers(0, 6, 120000)       # six hub columns of ~20 K edges
+    ptrs, idx, _ = orc.to_csc(ei, n)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    w = rs.uniform(0.05, 4.0, len(idx))
+    w[rs.integers(0, len(idx), len(idx) // 20)] = 1e-300                     # some vanishing weights
+    tsv = rs.integers(0, 100, len(idx))
+    graph = cabi.graph_view(t(ptrs), t(idx), t(w), t(tsv))
+    verts = np.concatenate([np.arange(6), rs.integers(0, n, 1500), [-1, -1, 3]])
+    states, ids = rs.integers(20, 80, len(verts)), rs.integers(0, 1 << 40, len(verts))
+    V, S, IDS = t(verts), t(states), t(ids)
+    ref = _one(cabi, graph, V, S, k, mode, window, IDS, 0x31, True)
+
+    def groups(group_cap):
+        m = V.numel()
+        o = dict(dtype=torch.int64, device=dev)
+        cnt, offsets = torch.empty(m, **o), torch.empty(m + 1, **o)
+        nbr, ep, par, st_out = (torch.full((m * k,), -7, **o) for _ in range(4))
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        hin, hout, flt = cabi.TgHopIn(), cabi.TgHopOut(), cabi.TgHopFilter()
+        hin.vertices, hin.ids, hin.m, hin.fanout, hin.sampler, hin.rng_tag = V.data_ptr(), IDS.data_ptr(), m, k, 2, 0x31
+        hout.cnt, hout.offsets = cnt.data_ptr(), offsets.data_ptr()
+        hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
+        flt.filter_mode, flt.forward, flt.win_lo, flt.win_hi, flt.states = mode, 0, window[0], window[1], S.data_ptr()
+        nbytes = C.c_int64(0)
+        cabi.check(cabi.lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(k), C.c_int64(group_cap), C.byref(nbytes)))
+        ws = torch.empty(nbytes.value // 8 + 1, **o)
+        rng = cabi.TgRng(5, 9)
+        cabi.check(cabi.lib.tg_ns_hop_weighted_groups(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
+                                                      cabi.ptr(st_out), cabi.ptr(status), cabi.ptr(ws), C.c_int64(nbytes.value),
+                                                      C.c_int64(group_cap), cabi.stream_ptr(dev)))
+        return cnt, offsets, nbr, ep, par, st_out, status
+
+    got = groups(8192)
+    assert int(got[6].item()) == int(ref[6].item()) == 0
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    total = int(ref[1][-1].item())
+    assert total > 6 * min(k, 1) and int(ref[0][:6].min().item()) == k     # the hubs fill every slot
+    for a, b in zip(got[2:5], ref[2:5]):
+        assert torch.equal(a[:total], b[:total])
+    if mode != -1:
+        assert torch.equal(got[5][:total], ref[5][:total])
+    low = groups(1024)                                                       # ~1 750 groups needed: the bound is reached
+    assert int(low[6].item()) & 1 and int(low[0].sum().item()) == 0 and int(low[1][-1].item()) == 0
