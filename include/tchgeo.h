@@ -254,7 +254,9 @@ TG_API int tg_ns_hop_weighted(const tg_graph *csc, const tg_hop_in *in, const tg
  * them -- a hub column no longer occupies one wavefront or one workgroup while the device idles (RMAT-24, 64 batches of
  * 1 024 seeds: 39.7 -> 15.3 ms).  Same draws, same sums, same result.  group_cap >= 1024 bounds the frontier's groups as in
  * tg_ns_hop_scan (reached: status[0] |= 1, all counts 0 -- retry with more); workspace:
- * tg_ns_hop_scan_workspace_bytes(m, fanout, group_cap).  tg_ns_hop_segments takes this form under the same condition. */
+ * tg_ns_hop_weighted_workspace_bytes(m, fanout, group_cap) (64 bytes more per group than the filtered hop's).
+ * tg_ns_hop_segments with the weighted sampler takes this form under the same condition and needs the same workspace. */
+TG_API int tg_ns_hop_weighted_workspace_bytes(int64_t m, int32_t fanout, int64_t group_cap, int64_t *bytes);
 TG_API int tg_ns_hop_weighted_groups(const tg_graph *csc, const tg_hop_in *in, const tg_hop_filter *filter, const tg_rng *rng,
                                      const tg_hop_out *out, int64_t *states_out, int32_t *status, void *workspace,
                                      int64_t workspace_bytes, int64_t group_cap, void *stream);

@@ -875,10 +875,19 @@ extern "C" int tg_ns_hop_scan_workspace_bytes(int64_t m, int32_t fanout, int64_t
     *bytes = (int64_t)(hs_align(8 * (size_t)(m + 1)) + hs_align(4 * (size_t)group_cap) + hs_align(8 * (size_t)group_cap) +
                        hs_align(8 * (size_t)(group_cap + 1)) +
                        hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(hs_scan_temp(big)) + 512 +
-                       hs_align(12 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS) + // long columns of the weighted sampler
-                       // ... and its group form: chunk totals, ranks before the groups, slots, call keys
-                       hs_align(8 * (size_t)group_cap * HS_CHUNKS) + hs_align(4 * (size_t)group_cap) +
-                       hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(8 * (size_t)(m > 0 ? m : 1)));
+                       hs_align(12 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS)); // long columns of the weighted sampler
+    return TG_OK;
+}
+// the weighted sampler's group form needs 64 more bytes per group (chunk totals), ranks before the groups, slots and call
+// keys -- and no group prefix; sized apart so that the filtered hop's workspace stays at 20 bytes per group
+extern "C" int tg_ns_hop_weighted_workspace_bytes(int64_t m, int32_t fanout, int64_t group_cap, int64_t *bytes) {
+    TG_REQUIRE(m >= 0 && fanout >= 1 && group_cap >= 1 && bytes, "tg_ns_hop_weighted_workspace_bytes: bad arguments");
+    using namespace tg;
+    int64_t base = 0;
+    const int rc = tg_ns_hop_scan_workspace_bytes(m, fanout, group_cap, &base);
+    if (rc != TG_OK) return rc;
+    *bytes = base + (int64_t)(hs_align(8 * (size_t)group_cap * HS_CHUNKS) + hs_align(4 * (size_t)group_cap) +
+                              hs_align(8 * (size_t)(m > 0 ? m : 1) * fanout) + hs_align(8 * (size_t)(m > 0 ? m : 1)));
     return TG_OK;
 }
 
@@ -903,8 +912,13 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
         TG_HIP(hipMemsetAsync(out->offsets, 0, sizeof(int64_t), stream));
         return TG_OK;
     }
+    // the weighted sampler takes the GROUP FORM whenever the caller sized the workspace for the frontier's groups (the
+    // same bound as the filtered path's; reached: status |= 1, all counts 0, retry with more) -- with the historical
+    // group_cap = 1 it keeps the column-at-a-time kernels
+    const bool weighted_groups = c.weighted && group_cap >= HW_GROUP_FORM_MIN;
     int64_t need = 0;
-    int rc = tg_ns_hop_scan_workspace_bytes(in->m, c.kmax, group_cap, &need);
+    int rc = weighted_groups ? tg_ns_hop_weighted_workspace_bytes(in->m, c.kmax, group_cap, &need)
+                             : tg_ns_hop_scan_workspace_bytes(in->m, c.kmax, group_cap, &need);
     if (rc != TG_OK) return rc;
     TG_REQUIRE(workspace && workspace_bytes >= need, "%s: workspace too small", who);
     TG_REQUIRE(in->vertices && out->neighbors && out->edge_ptrs && out->parents, "%s: null buffers", who);
@@ -944,10 +958,12 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
         p.long_tot = reinterpret_cast<double *>(ls);
         p.long_cnt = reinterpret_cast<uint32_t *>(ls + 8 * (size_t)HW_LONG_BLOCKS * (size_t)HW_LONG_CHUNKS);
     }
-    p.gtot = reinterpret_cast<double *>(take(8 * (size_t)group_cap * HS_CHUNKS));
-    p.grank = reinterpret_cast<uint32_t *>(take(4 * (size_t)group_cap));
-    p.slot_best = reinterpret_cast<unsigned long long *>(take(8 * (size_t)p.m * p.k));
-    p.vck = reinterpret_cast<uint32_t *>(take(8 * (size_t)p.m));
+    if (weighted_groups) {
+        p.gtot = reinterpret_cast<double *>(take(8 * (size_t)group_cap * HS_CHUNKS));
+        p.grank = reinterpret_cast<uint32_t *>(take(4 * (size_t)group_cap));
+        p.slot_best = reinterpret_cast<unsigned long long *>(take(8 * (size_t)p.m * p.k));
+        p.vck = reinterpret_cast<uint32_t *>(take(8 * (size_t)p.m));
+    }
     void *temp = base + off;
     size_t temp_bytes = (size_t)workspace_bytes - off;
     p.status = status;
@@ -970,10 +986,6 @@ static int hs_run(const char *who, const HsCall &c, const tg_hop_in *in, const t
                "%s: a device-side layout needs a frontier bound <= %lld and a group bound <= %lld", who, (long long)SCAN1_MAX,
                (long long)SCAN1_GROUPS_MAX);
     size_t st = temp_bytes;
-    // the weighted sampler takes the GROUP FORM whenever the caller sized the workspace for the frontier's groups (the
-    // same bound as the filtered path's; reached: status |= 1, all counts 0, retry with more) -- with the historical
-    // group_cap = 1 it keeps the column-at-a-time kernels
-    const bool weighted_groups = c.weighted && group_cap >= HW_GROUP_FORM_MIN;
     if (weighted_groups) {
         if (short_m) {
             hipLaunchKernelGGL(hs_groups1_kernel, dim3(1), dim3(SCAN1_THREADS), 0, stream, p);

@@ -92,6 +92,11 @@ struct NsResult {
     std::vector<std::tuple<int64_t, int64_t, int64_t>> layer_offsets;
     int64_t n_samples = 0, n_edges = 0;
 };
+// workspace of one whole-device hop under a filter / with weights (the weighted sampler's group form needs more per group)
+static inline int hop_workspace_bytes(bool weighted, int64_t m, int32_t k, int64_t group_cap, int64_t *bytes) {
+    return weighted ? tg_ns_hop_weighted_workspace_bytes(m, k, group_cap, bytes) : tg_ns_hop_scan_workspace_bytes(m, k, group_cap, bytes);
+}
+
 // The same operator with NO read-back between hops: sample list, frontier slice and edge count stay on the device
 // (csrc/het_steps.hip with one node type and one relation: tg_het_hop_begin_all packs the frontier, tg_ns_hop_segments
 // samples it with the homogeneous draw tag, tg_het_hop_end_all appends), one array read when the call ends.  Worst-case
@@ -155,7 +160,7 @@ bool run_ns_filtered_device(NsResult &r, const c10::Device &dev, const tg_graph 
         int64_t ws_max = 0;
         for (int h = 0; h < H; ++h) {
             int64_t b = 0;
-            check_rc(tg_ns_hop_scan_workspace_bytes(cap_f[(size_t)h], (int32_t)fanout[(size_t)h], groups(h), &b));
+            check_rc(hop_workspace_bytes(weighted, cap_f[(size_t)h], (int32_t)fanout[(size_t)h], groups(h), &b));
             ws_max = std::max(ws_max, b);
         }
         Tensor ws = at::empty({ws_max / 8 + 1}, i64(dev));
@@ -187,7 +192,7 @@ bool run_ns_filtered_device(NsResult &r, const c10::Device &dev, const tg_graph 
             in.fanout = sg.fanout;
             in.sampler = s.kind;
             int64_t ws_bytes = 0;
-            check_rc(tg_ns_hop_scan_workspace_bytes(e.cap, sg.fanout, groups(h), &ws_bytes));
+            check_rc(hop_workspace_bytes(weighted, e.cap, sg.fanout, groups(h), &ws_bytes));
             check_rc(tg_ns_hop_segments(&sg, 1, &in, lay, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
                                         status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes, groups(h),
                                         stream_of(dev)));
@@ -280,7 +285,7 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
             for (;;) {
                 Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
                 int64_t ws_bytes = 0;
-                check_rc(tg_ns_hop_scan_workspace_bytes(m, (int32_t)k, group_cap, &ws_bytes));
+                check_rc(hop_workspace_bytes(weighted, m, (int32_t)k, group_cap, &ws_bytes));
                 Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
                 check_rc(tg_ns_hop_weighted_groups(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(),
                                                    status.data_ptr<int32_t>(), ws.data_ptr<int64_t>(), ws_bytes, group_cap,
@@ -296,7 +301,7 @@ NsResult run_ns_filtered_flat(const c10::Device &dev, const Tensor &ptrs, const 
         for (;;) { // the frontier's columns need sum(ceil(deg/512)) groups; grow the workspace if the guess was low
             Tensor status = at::zeros({1}, at::TensorOptions().dtype(at::kInt).device(dev));
             int64_t ws_bytes = 0;
-            check_rc(tg_ns_hop_scan_workspace_bytes(m, (int32_t)k, group_cap, &ws_bytes));
+            check_rc(hop_workspace_bytes(weighted, m, (int32_t)k, group_cap, &ws_bytes));
             Tensor ws = at::empty({ws_bytes / 8 + 1}, i64(dev));
             check_rc(tg_ns_hop_scan(&g, &in, &flt, &rng, &out, st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
                                     ws.data_ptr<int64_t>(), ws_bytes, group_cap, stream_of(dev)));
@@ -816,7 +821,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                     if (all_at_once) {
                         int64_t b = 0;
                         if (hop_m[(size_t)h])
-                            check_rc(tg_ns_hop_scan_workspace_bytes(hop_m[(size_t)h], (int32_t)hop_k[(size_t)h], groups_of_hop(h), &b));
+                            check_rc(hop_workspace_bytes(weighted, hop_m[(size_t)h], (int32_t)hop_k[(size_t)h], groups_of_hop(h), &b));
                         ws_max = std::max(ws_max, b);
                         continue;
                     }
@@ -856,7 +861,7 @@ py::tuple neighbor_sampling_heterogenous(const std::vector<std::string> &node_ty
                                 in.fanout = (int32_t)hop_k[(size_t)h];
                                 in.sampler = s.kind;
                                 int64_t ws_bytes = 0;
-                                check_rc(tg_ns_hop_scan_workspace_bytes(m_round, (int32_t)hop_k[(size_t)h], groups_of_hop(h), &ws_bytes));
+                                check_rc(hop_workspace_bytes(weighted, m_round, (int32_t)hop_k[(size_t)h], groups_of_hop(h), &ws_bytes));
                                 check_rc(tg_ns_hop_segments(segs.data(), (int32_t)segs.size(), &in, lay, &flt, &rng, &out,
                                                             st_out.data_ptr<int64_t>(), status.data_ptr<int32_t>(),
                                                             ws.data_ptr<int64_t>(), ws_bytes, groups_of_hop(h), stream_of(dev)));

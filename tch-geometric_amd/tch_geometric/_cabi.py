@@ -23,7 +23,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_tempo_random_walk", "tg_rmat_edges", "tg_seed_batches", "tg_ind2ptr", "tg_probe_random_gather",
            "tg_neg_workspace_bytes", "tg_neg_sample", "tg_hgt_workspace_bytes", "tg_hgt_sample", "tg_ns_hop_workspace_bytes", "tg_ns_hop", "tg_rmat_edges_rect",
            "tg_coo_to_csx_workspace_bytes", "tg_coo_to_csx", "tg_budget_layer", "tg_check_range",
-           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_ns_hop_weighted_groups", "tg_gather_rows",
+           "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_ns_hop_weighted_groups", "tg_ns_hop_weighted_workspace_bytes", "tg_gather_rows",
            "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
            "tg_ns_hetero_batched", "tg_ns_homo_compact", "tg_part_workspace_bytes", "tg_part_begin",
            "tg_sanitize_range", "tg_ns_hop_segments", "tg_het_hop_begin_all", "tg_het_hop_end_all", "tg_part_requests", "tg_part_count", "tg_part_scan_workspace_bytes", "tg_part_sample", "tg_part_emit", "tg_part_unpack", "tg_part_pack", "tg_compact_rows", "tg_budget_capacity",
@@ -539,7 +539,8 @@ def ns_hop_segments(segments, vertices, states, seed, filter_mode=FILTER_NONE, w
     flt.win_lo, flt.win_hi = window
     flt.states = states.data_ptr() if (m and states is not None) else None
     nbytes = C.c_int64(0)
-    check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(kmax), C.c_int64(group_cap), C.byref(nbytes)))
+    size_of = lib.tg_ns_hop_weighted_workspace_bytes if sampler == SAMPLER_WEIGHTED else lib.tg_ns_hop_scan_workspace_bytes
+    check(size_of(C.c_int64(m), C.c_int32(kmax), C.c_int64(group_cap), C.byref(nbytes)))
     ws = torch.empty(nbytes.value // 8 + 1, **o)
     rng = TgRng(seed, call_id)
     check(lib.tg_ns_hop_segments(segs, C.c_int32(len(segments)), C.byref(hin), ptr(layout) if layout is not None else None,

@@ -256,7 +256,8 @@ class PartitionedSampler:
         # guess was too low raises status bit 1 and samples nothing -- sample() sees it in the call's ONE read-back,
         # enlarges the guess (kept for later calls) and runs the call again: no read-back per hop
         group_cap = max(1, int(self._group_mult * max(1024, graph.n_edges // 512 + 2 * m_cap + 2)))
-        _cabi.check(lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m_cap), C.c_int32(k), C.c_int64(group_cap),
+        size_of = lib.tg_ns_hop_weighted_workspace_bytes if weighted else lib.tg_ns_hop_scan_workspace_bytes
+        _cabi.check(size_of(C.c_int64(m_cap), C.c_int32(k), C.c_int64(group_cap),
                                                        C.byref(nbytes)))
         ws = self._buf("g_ws", nbytes.value // 8 + 1, i64)
         status.zero_()

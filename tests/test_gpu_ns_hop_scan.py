@@ -194,7 +194,7 @@ def test_weighted_group_form_equals_the_column_form(mode, window, k):
         hout.neighbors, hout.edge_ptrs, hout.parents = nbr.data_ptr(), ep.data_ptr(), par.data_ptr()
         flt.filter_mode, flt.forward, flt.win_lo, flt.win_hi, flt.states = mode, 0, window[0], window[1], S.data_ptr()
         nbytes = C.c_int64(0)
-        cabi.check(cabi.lib.tg_ns_hop_scan_workspace_bytes(C.c_int64(m), C.c_int32(k), C.c_int64(group_cap), C.byref(nbytes)))
+        cabi.check(cabi.lib.tg_ns_hop_weighted_workspace_bytes(C.c_int64(m), C.c_int32(k), C.c_int64(group_cap), C.byref(nbytes)))
         ws = torch.empty(nbytes.value // 8 + 1, **o)
         rng = cabi.TgRng(5, 9)
         cabi.check(cabi.lib.tg_ns_hop_weighted_groups(C.byref(graph), C.byref(hin), C.byref(flt), C.byref(rng), C.byref(hout),
