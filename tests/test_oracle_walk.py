@@ -87,3 +87,28 @@ def test_tempo_walk_k1_reservoir_quirk():
             w, _ = orc.tempo_random_walk(ptrs, idx, z, np.full(3, -1), [0], [-1], 2, (0, 1), rng)
             seen.add(int(w[0, 1]))
         assert seen == {2, 3}
+
+
+def test_tempo_walk_chunked_reservoir_law():
+    """philox-mode's one-slot reservoir draws once per chunk of 64 row positions (orc_reservoir_one_chunked); its law is the
+    literal loop's: with n admissible neighbours never candidate 0, every other one with probability 1/(n-1).  A row of 150
+    neighbours (three chunks), every second one outside the window, 40 000 walkers; ref-mode (the literal loop on the
+    reference's stream) measured the same way."""
+    n_nb = 150
+    ptrs = np.zeros(n_nb + 2, dtype=np.int64)
+    ptrs[1:] = n_nb                                     # vertex 0 -> 1..150, everyone else has no out-edges
+    idx = np.arange(1, n_nb + 1, dtype=np.int64)
+    edge_ts = np.where(np.arange(n_nb) % 2 == 0, 5, 50).astype(np.int64)     # even positions admissible (window [0, 10))
+    node_ts = np.full(n_nb + 1, -1, dtype=np.int64)
+    walkers = 40000
+    start, start_ts = np.zeros(walkers, dtype=np.int64), np.zeros(walkers, dtype=np.int64)
+    n_cand = n_nb // 2
+    for rng in (orc.rng_philox(123), orc.rng_ref()):
+        w, _ = orc.tempo_random_walk(ptrs, idx, node_ts, edge_ts, start, start_ts, 2, (0, 10), rng)
+        picks = w[:, 1]
+        assert np.all((picks - 1) % 2 == 0)                                  # admissible neighbours only
+        counts = np.bincount((picks - 1) // 2, minlength=n_cand)
+        assert counts[0] == 0                                                # candidate 0 never survives (sampling.rs:19)
+        expect = walkers / (n_cand - 1)
+        chi2 = float(((counts[1:] - expect) ** 2 / expect).sum())
+        assert chi2 < 130, chi2                                              # 73 degrees of freedom: mean 73, sd 12
