@@ -420,21 +420,23 @@ def coo_to_csx(row, col, size0, size1, csc):
     return ptrs, indices, perm
 
 
-def ns_homo_compact(out, n_batches, counts_host):
+def ns_homo_compact(out, n_batches, counts_host, stacked=False):
     """Flat batch-major (samples, rows, cols, edge_index) of the first n_batches of an NsBatchedOut; counts_host: the
-    [n_batches, 2] counts already read back (sizes the flat arrays)."""
+    [n_batches, 2] counts already read back (sizes the flat arrays).  stacked: rows and cols are the two rows of ONE
+    [2, E] tensor (what a loader hands out as edge_index) -> (samples, [rows; cols], edge_index)."""
     dev = out.samples.device
     total_n, total_e = int(counts_host[:, 0].sum()), int(counts_host[:, 1].sum())
     c = out.counts[:n_batches]
     off = torch.zeros((2, n_batches + 1), dtype=torch.int64, device=dev)
     off[:, 1:] = torch.cumsum(c.t(), dim=1)
     o = dict(dtype=torch.int64, device=dev)
-    fs, fr = torch.empty(total_n, **o), torch.empty(total_e, **o)
-    fc, fe = torch.empty(total_e, **o), torch.empty(total_e, **o)
+    fs, fe = torch.empty(total_n, **o), torch.empty(total_e, **o)
+    rc = torch.empty((2, total_e), **o)
+    fr, fc = rc[0], rc[1]
     so = out.struct()
     check(lib.tg_ns_homo_compact(C.byref(so), C.c_int64(n_batches), ptr(off[0]), ptr(off[1]), ptr(fs), ptr(fr), ptr(fc),
                                  ptr(fe), stream_ptr(dev)))
-    return fs, fr, fc, fe
+    return (fs, rc, fe) if stacked else (fs, fr, fc, fe)
 
 
 def compact_rows(slab, lens, total):

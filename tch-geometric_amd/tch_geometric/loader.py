@@ -35,18 +35,26 @@ class SuperBatch:
     (python lists, length G + 1), `layer_offsets` [G][hops] triples, `call_id0`.  Iterating (or indexing) yields the
     mini-batches as `MiniBatch` views; a consumer that can take the whole super-batch (a model over a batch of
     sub-graphs with `ptr` offsets) pays no per-mini-batch host work at all."""
-    __slots__ = ("n_id", "edge_index", "e_id", "node_attrs", "edge_attrs", "node_ptr", "edge_ptr", "layer_offsets",
-                 "batch_size", "call_id0", "n_hops", "_views", "_index")
+    __slots__ = ("n_id", "edge_index", "_e_id", "_e_ptr", "_perm", "node_attrs", "edge_attrs", "node_ptr", "edge_ptr",
+                 "layer_offsets", "batch_size", "call_id0", "n_hops", "_views", "_index")
+
+    @property
+    def e_id(self):
+        """COO edge ids of the sampled edges: a gather through the ingest permutation (one random 8-byte read per edge),
+        made when first asked for -- a consumer that only needs n_id / edge_index / x does not pay for it"""
+        if self._e_id is None:
+            self._e_id = _cabi.gather_rows(self._perm, self._e_ptr)[0]
+        return self._e_id
 
     def views_of(self, j):
-        """every tensor view of mini-batch j, cut by the host module in one call (BatchViews): (n_id, e_id, edge_index,
-        node attributes..., edge attributes...)"""
+        """every tensor view of mini-batch j, cut by the host module in one call (BatchViews): (n_id, edge_index, node
+        attributes..., edge attributes...); e_id is cut apart, when asked for"""
         v = getattr(self, "_views", None)
         if v is None:
-            names = ["n_id", "e_id", "edge_index"] + list(self.node_attrs) + list(self.edge_attrs)
-            bases = [self.n_id, self.e_id, self.edge_index] + list(self.node_attrs.values()) + list(self.edge_attrs.values())
-            dims = [0, 0, 1] + [0] * (len(bases) - 3)
-            kinds = [0, 1, 1] + [0] * len(self.node_attrs) + [1] * len(self.edge_attrs)
+            names = ["n_id", "edge_index"] + list(self.node_attrs) + list(self.edge_attrs)
+            bases = [self.n_id, self.edge_index] + list(self.node_attrs.values()) + list(self.edge_attrs.values())
+            dims = [0, 1] + [0] * (len(bases) - 2)
+            kinds = [0, 1] + [0] * len(self.node_attrs) + [1] * len(self.edge_attrs)
             self._index = {k: i for i, k in enumerate(names)}
             v = self._views = _host.BatchViews(bases, dims, kinds, self.node_ptr, self.edge_ptr)
         return v.at(j)
@@ -96,8 +104,13 @@ class MiniBatch:
         return c
 
     n_id = property(lambda self: self._all()[0])
-    e_id = property(lambda self: self._all()[1])
-    edge_index = property(lambda self: self._all()[2])
+    edge_index = property(lambda self: self._all()[1])
+
+    @property
+    def e_id(self):
+        sb, j = self._sb, self._j
+        a = sb.edge_ptr[j]
+        return sb.e_id.narrow(0, a, sb.edge_ptr[j + 1] - a)
 
     def __getattr__(self, name):  # node / edge attributes of the source graph (x, y, edge_attr, ...)
         sb = object.__getattribute__(self, "_sb")
@@ -108,7 +121,7 @@ class MiniBatch:
 
     def tensor_items(self):
         views = self._all()
-        return [(k, views[i]) for k, i in self._sb._index.items()]
+        return [(k, views[i]) for k, i in self._sb._index.items()] + [("e_id", self.e_id)]
 
 
 class NeighborLoader:
@@ -194,13 +207,14 @@ class NeighborLoader:
         cur.wait_event(done)
         counts = slab["counts"][:G]
         n_nodes, n_edges = counts[:, 0].tolist(), counts[:, 1].tolist()
-        n_id, rows, cols, e_ptr = _cabi.ns_homo_compact(out, G, counts)   # copies: the slabs go back to the sampler
+        n_id, edge_index, e_ptr = _cabi.ns_homo_compact(out, G, counts, stacked=True)   # copies: the slabs go back to the sampler
         free = torch.cuda.Event()
         free.record(cur)
         slab["free"] = free
         rows_of = lambda table, index: _cabi.gather_rows(table, index)[0]   # ids come from the sampler: no range read-back
         sb = SuperBatch()
-        sb.n_id, sb.edge_index, sb.e_id = n_id, torch.stack([rows, cols]), rows_of(self.perm, e_ptr)
+        sb.n_id, sb.edge_index = n_id, edge_index
+        sb._e_id, sb._e_ptr, sb._perm = None, e_ptr, self.perm
         sb.node_attrs = {k: rows_of(v, n_id) for k, v in self._node_attrs}
         sb.edge_attrs = {k: rows_of(v, sb.e_id) for k, v in self._edge_attrs}
         ptr_n, ptr_e, a, e = [0], [0], 0, 0
