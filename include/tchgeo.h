@@ -55,6 +55,10 @@ typedef struct {
                                   gathered line; NULL = not provided.  Outputs stay int64 either way. */
     const uint32_t *ptrs32;    /* optional u32 shadow of `ptrs` (n_edges < 2^32): 4 B per offset, so the whole
                                   offset table of RMAT-24 (67 MB) stays in the Infinity Cache; NULL = not provided */
+    int64_t max_degree;        /* optional: the longest column (row) of the graph, 0 = unknown (n_edges is assumed).  The
+                                  window-ordered launch packs sampled positions into max_degree's bits; a
+                                  value SMALLER than the truth is a contract violation like an out-of-range id.
+                                  tg_graph_max_degree computes it on the device. */
 } tg_graph;
 
 typedef struct {
@@ -107,6 +111,9 @@ typedef struct {
     int64_t cap_edges;
 } tg_ns_out;
 
+/* *max_degree_dev (device int64) = the longest column of `g` (reads ptrs32 when given, else ptrs).  Stream-ordered. */
+TG_API int tg_graph_max_degree(const tg_graph *g, int64_t *max_degree_dev, void *stream);
+
 TG_API const char *tg_version(void);
 TG_API const char *tg_last_error(void);
 
@@ -141,6 +148,11 @@ TG_API int tg_ns_homo_batched(const tg_graph *csc, const int64_t *seeds, int64_t
  * a launch whose workspace lacks them takes the push form) */
 TG_API int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
                                int64_t *n_bytes);
+/* The same for a given graph: the staged pipeline's stage slots are then sized by the graph's bit widths (vertex ids and
+ * tg_graph.max_degree: one 64-byte chunk per frontier vertex where the pairs {neighbour, position} fit, else two); without
+ * a graph the larger size is assumed. */
+TG_API int tg_ns_homo_workspace_bytes_for(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                   int32_t n_hops, int64_t *n_bytes);
 TG_API int tg_ns_homo_batched_ws(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
                           const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                           const tg_ns_out *out, void *workspace, int64_t workspace_bytes, int32_t mode, void *stream);
@@ -181,7 +193,10 @@ typedef struct {
                                      a side stream beside part p + 1's sort and gather (default 1 = one stream: measured, the overlap
                                      buys nothing -- both kernels are bound by vector-ALU work -- and every part costs 0.2 ms) */
     int32_t stage_part_min_batches; /* ... as long as every part keeps at least this many batches (default 1024) */
-    int32_t stage_sort_blocks;      /* staged form: workgroups of the item sort = rows of its histogram (default 512, the most) */
+    int32_t stage_sort_blocks;      /* staged form: workgroups of the item sort = rows of its histogram = persistent workgroups
+                                       of the first kernel (default 768, at most 1024) */
+    int32_t stage_fine;             /* staged form: second sort level (tiles of the coarse-sorted items ordered by vertex in LDS,
+                                       so that a gather workgroup's slice lies in a few columns; default 1; < 0 in _set keeps) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

@@ -123,6 +123,31 @@ def philox_named_draw(seed, call_id, tag, id_, d0, d1):
     return list(out)
 
 
+def bounded_word(w, range_):
+    """Lemire's bounded integer from one 32-bit word -> (value, accepted)."""
+    ok = C.c_int(0)
+    f = lib().orc_test_bounded_word
+    f.restype = C.c_uint32
+    v = f(C.c_uint32(w), C.c_uint32(range_), C.byref(ok))
+    return int(v), bool(ok.value)
+
+
+def slot_draw(rng, tag, id_, d1, s, range_):
+    """philox-mode's bounded draw of slot s -> (value, fell back to the 64-bit draw)."""
+    fb = C.c_int(0)
+    f = lib().orc_test_slot_draw
+    f.restype = C.c_uint64
+    v = f(C.byref(rng), C.c_uint32(tag), C.c_uint64(id_), C.c_uint32(d1), C.c_int64(s), C.c_uint64(range_), C.byref(fb))
+    return int(v), bool(fb.value)
+
+
+def slot_fallback_count(reset=False):
+    """64-bit fallback draws the philox-mode slot draw has taken so far (a rejected 32-bit word each)."""
+    f = lib().orc_slot_fallback_count
+    f.restype = C.c_uint64
+    return int(f(C.c_int(int(reset))))
+
+
 def reservoir_positions(rng, n, k, algo=RES_TICKETS, tag=TAG_NS_HOMO, id_=0):
     dst = np.zeros(max(k, 1), dtype=np.int64)
     cnt = lib().orc_reservoir_positions(C.byref(rng), tag, id_, n, k, algo, _p(dst))

@@ -197,6 +197,21 @@ static inline orc_draw orc_philox_draw(orc_callkey ck, uint64_t id, uint32_t d0,
 static inline uint64_t orc_bounded(uint64_t x, uint64_t range) {
     return (uint64_t)(((unsigned __int128)x * range) >> 64);
 }
+/* Bounded integer from ONE 32-bit word: Lemire's multiply-shift with its exact rejection test ("Fast Random Integer
+ * Generation in an Interval", 2019).  *ok = 0 when the word must be rejected (probability < range / 2^32); an accepted
+ * word gives an exactly uniform value in [0, range).  0 < range < 2^32. */
+static inline uint32_t orc_bounded_word(uint32_t w, uint32_t range, int *ok) {
+    uint64_t m = (uint64_t)w * range;
+    uint32_t lo = (uint32_t)m;
+    *ok = 1;
+    if (lo < range) {
+        uint32_t t = (uint32_t)(0u - range) % range; /* 2^32 mod range */
+        if (lo < t) *ok = 0;
+    }
+    return (uint32_t)(m >> 32);
+}
+#define ORC_D1_FALLBACK 0x46u /* 'F': or-ed into d1 for the 64-bit draw that replaces a rejected word */
+
 static inline float orc_u32_to_f32_01(uint32_t w) {
     uint32_t bits = 0x3F800000u | (w >> 9);
     float v;

@@ -40,6 +40,27 @@ static inline orc_draw orc_ctx_draw(orc_ctx *c, uint64_t id, uint32_t d0, uint32
     return orc_philox_draw(c->ck, id, d0, d1);
 }
 
+/* Bounded draw of SLOT s of a reservoir / replacement sample (philox-mode's definition since round 4; the kernels'
+ * tg::slot_draw): slot s owns ONE 32-bit word -- word (s & 3) of the Philox block (id, d0_base + (s >> 2), d1) -- bounded
+ * by Lemire's multiply-shift with its exact rejection test; a rejected word (probability < range / 2^32) is replaced by
+ * the 64-bit multiply-shift draw of a block of the slot's own, (id, d0_base + s, d1 | ORC_D1_FALLBACK).  Exactly uniform
+ * up to the 2^-64 * range bias every 64-bit draw of this file has.  Before round 4 a slot took half a block (64 bits):
+ * five blocks per vertex at k = 10 where three do now -- the ticket draws are what bounds the sampling kernels
+ * (DESIGN.md 4.1).  Ranges of 2^32 and more take the 64-bit draw directly.  *blk caches the current block. */
+static uint64_t orc_slot_fallbacks = 0; /* statistics for the tests (single-threaded use): 64-bit fallback draws taken */
+static inline uint64_t orc_slot_draw(orc_ctx *c, uint64_t id, uint32_t d0_base, uint32_t d1, int64_t s, orc_draw *blk,
+                                     uint64_t range) {
+    if ((s & 3) == 0) *blk = orc_ctx_draw(c, id, d0_base + (uint32_t)(s >> 2), d1); /* slots are drawn in order from 0 */
+    if (range < ((uint64_t)1 << 32)) {
+        int ok;
+        uint32_t r = orc_bounded_word(blk->w[s & 3], (uint32_t)range, &ok);
+        if (ok) return r;
+    }
+    orc_slot_fallbacks++;
+    orc_draw f = orc_ctx_draw(c, id, d0_base + (uint32_t)s, d1 | ORC_D1_FALLBACK);
+    return orc_bounded(f.a, range);
+}
+
 /* Reservoir by tickets (philox mode). n > k >= 1.
  * The reference loop of sampling.rs:17-24 (item i >= k draws j from 0..i and
  * overwrites slot j when j < k) leaves in slot s the LAST item that hit it.
@@ -51,7 +72,7 @@ static inline orc_draw orc_ctx_draw(orc_ctx *c, uint64_t id, uint32_t d0, uint32
  * check: tests/test_reservoir_equivalence.py).  A blank leaves item s in
  * slot s.  The ordered draw is a partial Fisher-Yates over ticket indices
  * [0, n-1): ticket tau < n-k is position k+tau, the rest are blanks.
- * One bounded draw per slot; slots 2q and 2q+1 share one Philox block.
+ * One bounded draw per slot (orc_slot_draw: one 32-bit Philox word each).
  * `scratch` holds 2k int64 (the displaced-entry list of the shuffle). */
 static inline void orc_reservoir_tickets(orc_ctx *c, uint64_t id, uint32_t d0_base, int64_t n, int64_t k,
                                          int64_t *dst, int64_t *scratch) {
@@ -59,9 +80,7 @@ static inline void orc_reservoir_tickets(orc_ctx *c, uint64_t id, uint32_t d0_ba
     orc_draw d = {0};
     for (int64_t s = 0; s < k; s++) {
         int64_t m = (n - 1) - s; /* tickets left in the urn */
-        if ((s & 1) == 0) d = orc_ctx_draw(c, id, d0_base + (uint32_t)(s >> 1), 0);
-        uint64_t x = (s & 1) ? d.b : d.a;
-        int64_t r = (int64_t)orc_bounded(x, (uint64_t)m), last = m - 1;
+        int64_t r = (int64_t)orc_slot_draw(c, id, d0_base, 0, s, &d, (uint64_t)m), last = m - 1;
         int64_t tr = r, tl = last;
         for (int64_t j = 0; j < s; j++) { /* latest entry for an index wins */
             if (keys[j] == r) tr = vals[j];
@@ -126,14 +145,12 @@ static inline int64_t orc_reservoir_one_chunked(orc_ctx *c, uint64_t id, int64_t
 
 /* src/utils/sampling.rs:57-69 replacement_sampling: k draws from [0,n), n>0 */
 static inline int64_t orc_replacement(orc_ctx *c, uint64_t id, int64_t n, int64_t k, int64_t *dst) {
+    orc_draw d = {0};
     for (int64_t s = 0; s < k; s++) {
         if (c->rng->mode == ORC_RNG_REF)
             dst[s] = (int64_t)orc_ref_gen_range_u64(c->rng, (uint64_t)n);
         else
-        {
-            orc_draw d = orc_ctx_draw(c, id, (uint32_t)(s >> 1), 0x52455000u);
-            dst[s] = (int64_t)orc_bounded((s & 1) ? d.b : d.a, (uint64_t)n);
-        }
+            dst[s] = (int64_t)orc_slot_draw(c, id, 0, 0x52455000u, s, &d, (uint64_t)n);
     }
     return k;
 }

@@ -66,6 +66,27 @@ ORC_API void orc_philox_named_draw(uint64_t seed, uint64_t call_id, uint32_t tag
     memcpy(out4, d.w, 16);
 }
 
+/* the slot draw's primitives exposed for tests/test_oracle_rng.py: the bounded word with its rejection flag, and the whole
+ * slot draw (a fresh context per call, so `s` need not start at 0 here: the block is recomputed) */
+ORC_API uint32_t orc_test_bounded_word(uint32_t w, uint32_t range, int *ok) { return orc_bounded_word(w, range, ok); }
+ORC_API uint64_t orc_test_slot_draw(orc_rng *rng, uint32_t tag, uint64_t id, uint32_t d1, int64_t s, uint64_t range,
+                                    int *fell_back) {
+    orc_ctx c;
+    orc_ctx_init(&c, rng, tag);
+    orc_draw blk = orc_philox_draw(c.ck, id, (uint32_t)(s >> 2), d1);
+    int ok = 0;
+    if (range < ((uint64_t)1 << 32)) (void)orc_bounded_word(blk.w[s & 3], (uint32_t)range, &ok);
+    *fell_back = !ok;
+    orc_draw cache = blk; /* orc_slot_draw recomputes it only when s is a multiple of 4: hand it the right block */
+    return orc_slot_draw(&c, id, 0, d1, s, &cache, range);
+}
+
+ORC_API uint64_t orc_slot_fallback_count(int reset) {
+    uint64_t v = orc_slot_fallbacks;
+    if (reset) orc_slot_fallbacks = 0;
+    return v;
+}
+
 /* reservoir primitive exposed for the equivalence tests */
 ORC_API int64_t orc_reservoir_positions(orc_rng *rng, uint32_t tag, uint64_t id, int64_t n, int64_t k, int algo,
                                         int64_t *dst) {

@@ -80,8 +80,8 @@ __global__ void budget_layer_kernel(const BudParams p) {
             const uint64_t id = (uint64_t)(p.id_base + j);
             for (int s = 0; s < k; ++s) {
                 const uint32_t m = (n - 1u) - (uint32_t)s;
-                if ((s & 1) == 0) d = draw(ck, id, (uint32_t)(s >> 1), 0u);
-                const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                if ((s & 3) == 0) d = draw(ck, id, (uint32_t)(s >> 2), 0u);
+                const uint32_t r = slot_draw_from(d, ck, id, (uint32_t)s, 0u, m), last = m - 1u;
                 const uint64_t mr = __ballot(lane < s && myK == r);
                 const uint64_t ml = __ballot(lane < s && myK == last);
                 const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);
@@ -203,8 +203,8 @@ __global__ void budf_select_kernel(const BudFused f) {
             const uint64_t id = (uint64_t)(begin + j); // slot of the node in its type's list
             for (int s = 0; s < k; ++s) {
                 const uint32_t m = (n - 1u) - (uint32_t)s;
-                if ((s & 1) == 0) d = draw(ck, id, (uint32_t)(s >> 1), 0u);
-                const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                if ((s & 3) == 0) d = draw(ck, id, (uint32_t)(s >> 2), 0u);
+                const uint32_t r = slot_draw_from(d, ck, id, (uint32_t)s, 0u, m), last = m - 1u;
                 const uint64_t mr = __ballot(lane < s && myK == r);
                 const uint64_t ml = __ballot(lane < s && myK == last);
                 const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);

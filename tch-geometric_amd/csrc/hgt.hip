@@ -806,8 +806,8 @@ __device__ __forceinline__ void hgt_edge_candidates_body(const HgtType &dst, con
             Draw d;
             for (int s = 0; s < HGT_MAX_NB; ++s) {
                 const uint32_t m = (n - 1u) - (uint32_t)s;
-                if ((s & 1) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 1), 0u);
-                const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                if ((s & 3) == 0) d = draw(ck, (uint64_t)i, (uint32_t)(s >> 2), 0u);
+                const uint32_t r = slot_draw_from(d, ck, (uint64_t)i, (uint32_t)s, 0u, m), last = m - 1u;
                 const uint64_t mr = __ballot(lane < s && myK == r);     // the latest displaced entry wins
                 const uint64_t ml = __ballot(lane < s && myK == last);
                 const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);

@@ -41,6 +41,28 @@ __global__ void csx_ptrs_kernel(const int64_t *__restrict__ sorted_keys, int64_t
         ptrs[j] = lo;
     }
 }
+// largest column (row) length of a CSC (CSR): one 8-byte atomic max per workgroup
+__global__ void max_degree_kernel(const int64_t *__restrict__ ptrs, const uint32_t *__restrict__ ptrs32, int64_t m,
+                                  unsigned long long *out) {
+    __shared__ unsigned long long part[4];
+    unsigned long long best = 0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long d = ptrs32 ? (unsigned long long)(ptrs32[j + 1] - ptrs32[j])
+                                            : (unsigned long long)(ptrs[j + 1] - ptrs[j]);
+        best = d > best ? d : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) best = part[w] > best ? part[w] : best;
+        atomicMax(out, best);
+    }
+}
 static inline unsigned csx_grid(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -96,6 +118,19 @@ extern "C" int tg_coo_to_csx(const int64_t *row, const int64_t *col, int64_t nnz
     TG_HIP(rocprim::radix_sort_pairs(temp, st, keys, skeys, vals, perm, (size_t)nnz, 0, bits, stream, false));
     hipLaunchKernelGGL(csx_indices_kernel, dim3(csx_grid(nnz)), dim3(256), 0, stream, skeys, nnz, size_minor, indices);
     hipLaunchKernelGGL(csx_ptrs_kernel, dim3(csx_grid(m + 1)), dim3(256), 0, stream, skeys, nnz, size_minor, m, ptrs);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+/* tg_graph.max_degree for a caller that does not know it: *max_degree_dev (device int64) = the longest column. */
+extern "C" int tg_graph_max_degree(const tg_graph *g, int64_t *max_degree_dev, void *stream_) {
+    using namespace tg;
+    TG_REQUIRE(g && max_degree_dev && (g->ptrs || g->ptrs32) && g->n_major >= 0, "tg_graph_max_degree: bad arguments");
+    hipStream_t stream = (hipStream_t)stream_;
+    TG_HIP(hipMemsetAsync(max_degree_dev, 0, sizeof(int64_t), stream));
+    if (g->n_major == 0) return TG_OK;
+    hipLaunchKernelGGL(max_degree_kernel, dim3(csx_grid(g->n_major)), dim3(256), 0, stream, g->ptrs, g->ptrs32, g->n_major,
+                       reinterpret_cast<unsigned long long *>(max_degree_dev));
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

@@ -140,12 +140,7 @@ __global__ void ns_hetero_kernel(const NsHetParams p) {
                     if (cnt > 0) {
                         const uint32_t n = (uint32_t)deg;
                         if (REPLACE) { // sampling.rs:57-69
-                            Draw d;
-                            for (int s = 0; s < k; ++s) {
-                                if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                                spos[excl + s] = bounded32(d.half(s & 1), n);
-                                slane[excl + s] = (uint8_t)lane;
-                            }
+                            sample_replace_any(ck, did, n, k, spos, slane, excl, lane);
                         } else if (deg <= k) { // sampling.rs:12-15
                             for (uint32_t s = 0; s < cnt; ++s) {
                                 spos[excl + s] = s;

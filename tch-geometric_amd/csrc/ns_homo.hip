@@ -216,12 +216,7 @@ __global__ void ns_homo_uniform_kernel(const NsHomoParams p) {
                 if (cnt > 0) {
                     const uint32_t n = (uint32_t)deg;
                     if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
-                        Draw d;
-                        for (int s = 0; s < k; ++s) {
-                            if ((s & 1) == 0) d = draw(ckl, did, (uint32_t)(s >> 1), D1_REPLACE);
-                            spos[excl + s] = bounded32(d.half(s & 1), n);
-                            slane[excl + s] = (uint8_t)lane;
-                        }
+                        sample_replace_any(ckl, did, n, k, spos, slane, excl, lane);
                     } else if (deg <= k) { // sampling.rs:12-15: the reservoir is just filled
                         for (uint32_t s = 0; s < cnt; ++s) {
                             spos[excl + s] = s;

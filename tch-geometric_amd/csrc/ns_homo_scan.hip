@@ -224,16 +224,15 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
                 const uint64_t did = (uint64_t)(p.id_base + i);
                 if (p.sampler == TG_SAMPLER_UNIFORM_REPL) {
                     if (n > 0 && lane < k) {
-                        const Draw d = draw(ck, did, (uint32_t)(lane >> 1), D1_REPLACE);
-                        myrank = bounded32(d.half(lane & 1), n);
+                        myrank = slot_draw(ck, did, (uint32_t)lane, D1_REPLACE, n);
                     }
                 } else if (n > (uint32_t)k) {
                     uint32_t myK = 0xffffffffu, myV = 0;
                     Draw d;
                     for (int s = 0; s < k; ++s) {
                         const uint32_t m = (n - 1u) - (uint32_t)s;
-                        if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
-                        const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                        if ((s & 3) == 0) d = draw(ck, did, (uint32_t)(s >> 2), 0u);
+                        const uint32_t r = slot_draw_from(d, ck, did, (uint32_t)s, 0u, m), last = m - 1u;
                         const uint64_t mr = __ballot(lane < s && myK == r);
                         const uint64_t ml = __ballot(lane < s && myK == last);
                         const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);

@@ -25,9 +25,22 @@ struct WinItem8 {
 };
 static_assert(sizeof(WinItem8) == 8, "item layout");
 
-// window of a vertex's column start from the vertex id alone: vtab[i] = first vertex whose column starts at or beyond
-// window i (ptrs is monotone), so window(v) = largest i with vtab[i] <= v; then the XCD-major bucket as win_bucket
-__device__ __forceinline__ uint32_t win_vertex_bucket(const uint32_t *vtab, int n_windows, int n_buckets, uint32_t v) {
+// ---------------------------------------------------------------- the sort key of an item (round 4: two levels)
+// vtab[i] = first vertex whose column starts at or beyond window i (ptrs is monotone; vtab[n_windows] = n_major), so the
+// window of a vertex's column start is the largest i with vtab[i] <= v -- a binary search over a table the workgroup holds
+// in LDS, no column look-up.  Windows map to WINDOW BUCKETS XCD-major (as win_bucket); the sort key has two levels:
+//   coarse = window bucket / 8      (<= 1 024 coarse buckets: one counting-sort pass whose open destination lines -- rows x
+//            coarse buckets -- stay in the L2s, so the 8-byte items leave as whole chunks; the round-3 sort scattered them
+//            over rows x 2 048 buckets = 134 MB of open lines and paid a partial-chunk write per item)
+//   fine   = (window bucket % 8) * 16 + sub-bucket of the vertex inside its window's vertex range (16 by a shift)
+//            (a pass of its own INSIDE each coarse bucket, whose ~1 MB segment is L2-resident).
+// Items of one vertex end up adjacent and the vertices of a window in ascending order: a gather workgroup's slice then
+// lies in one or two columns, which its L1 holds (760 G gathers/s against 260 from L2: profiles/r04/probe_gather_small.json).
+struct StageKey {
+    uint32_t coarse, fine;
+};
+constexpr int WIN_FINE_PER_COARSE = 128;
+__device__ __forceinline__ StageKey win_stage_key(const uint32_t *vtab, int n_windows, int n_wbuckets, uint32_t v) {
     int lo = 0, hi = n_windows;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -36,12 +49,20 @@ __device__ __forceinline__ uint32_t win_vertex_bucket(const uint32_t *vtab, int 
         else
             hi = mid;
     }
-    return ((uint32_t)lo & 7u) * (uint32_t)(n_buckets >> 3) + ((uint32_t)lo >> 3);
+    const uint32_t wb = ((uint32_t)lo & 7u) * (uint32_t)(n_wbuckets >> 3) + ((uint32_t)lo >> 3);
+    const uint32_t v0 = vtab[lo], range = vtab[lo + 1] - v0; // >= 1 for a vertex of the graph
+    const int sh = max(0, 28 - (int)__clz((int)((range - 1u) | 1u))); // (range - 1) >> sh < 16
+    const uint32_t sub = min(15u, (v - v0) >> sh);
+    return StageKey{wb >> 3, ((wb & 7u) << 4) | sub};
 }
 
 __global__ void win_vtab_kernel(const WinParams p, int64_t n_major) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n_windows) return;
+    if (i > p.n_windows) return;
+    if (i == p.n_windows) {
+        p.vtab[i] = (uint32_t)n_major;
+        return;
+    }
     const uint64_t target = (uint64_t)i << p.shift;
     int64_t lo = 0, hi = n_major; // first v in [0, n_major] with ptrs[v] >= target (ptrs[n_major] = n_edges >= target)
     while (lo < hi) {
@@ -55,57 +76,38 @@ __global__ void win_vtab_kernel(const WinParams p, int64_t n_major) {
     p.vtab[i] = (uint32_t)lo;
 }
 
+// LDS tables of the sort kernels and of the folded first kernel: counters [n_buckets] | vertex table [n_windows + 1]
+__host__ __device__ inline size_t win_stage_tables_bytes(int n_buckets, int n_windows) {
+    return ((size_t)n_buckets + (size_t)n_windows + 1) * sizeof(uint32_t);
+}
+
 // ---------------------------------------------------------------- E0: seeds, hop 0 (direct) + the items of hop 1
+// Persistent: workgroup r walks batches b0 + r, b0 + r + gridDim.x, ... and keeps the COARSE histogram of the items it hands
+// over in LDS (row r of `hist`): the counting sort needs no pass of its own over the items to count them (hop 0 is bound
+// by its random line requests; the binary search per new item hides beneath them).
 template <int KMAX, bool REPLACE>
 __global__ void win_stage_first_kernel(const WinParams p, const int k0) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int64_t b = p.b0 + blockIdx.x;
-    int64_t *samples = p.samples + b * p.cap_nodes;
-    for (int64_t i = threadIdx.x; i < p.n_seeds; i += blockDim.x) samples[i] = p.seeds[b * p.n_seeds + i]; // :184
-    const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
-    if (threadIdx.x == 0) p.call_keys[b] = ck;
-    __syncthreads();
-    const WinState st =
-        win_emit_hop<WinItemN, KMAX, REPLACE, true, false, true>(p, smem, b, 0, k0, WinState{0, p.n_seeds, 0, 0}, ck);
-    win_store_state(p, b, 0, st);
-}
-
-// ---------------------------------------------------------------- sort: window histogram of the 8-byte items
-// workgroup r counts the items of batches r, r + gridDim.x, ... (the batches win_scatter8_kernel's workgroup r moves)
-__global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinParams p) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *lvtab = h + p.n_buckets;
-    const int nb = p.n_buckets;
-    const WinItem8 *items = static_cast<const WinItem8 *>(p.items_in);
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) h[i] = 0;
-    for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
-    __syncthreads();
-    constexpr int U = 4;
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + win_emit_lds_bytes(p.kmax, blockDim.x >> 6));
+    uint32_t *lvtab = lhist + p.n_buckets;
+    for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) lhist[i] = 0;
+    for (int i = threadIdx.x; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
     for (int64_t b = p.b0 + blockIdx.x; b < p.b0 + p.n_batches; b += gridDim.x) {
-        const WinState st = p.state[b];
-        const int64_t n = st.end - st.begin;
-        const WinItem8 *src = items + b * p.item_pitch;
-        for (int64_t t0 = 0; t0 < n; t0 += (int64_t)U * WIN_PART_THREADS) {
-            uint32_t v[U];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t j = t0 + (int64_t)u * WIN_PART_THREADS + threadIdx.x;
-                ok[u] = j < n;
-                if (ok[u]) v[u] = src[j].v;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (ok[u]) atomicAdd(&h[win_vertex_bucket(lvtab, p.n_windows, nb, v[u])], 1u);
-        }
+        int64_t *samples = p.samples + b * p.cap_nodes;
+        for (int64_t i = threadIdx.x; i < p.n_seeds; i += blockDim.x) samples[i] = p.seeds[b * p.n_seeds + i]; // :184
+        const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
+        if (threadIdx.x == 0) p.call_keys[b] = ck;
+        __syncthreads();
+        const WinState st = win_emit_hop<WinItemN, KMAX, REPLACE, true, false, true>(p, smem, b, 0, k0,
+                                                                                    WinState{0, p.n_seeds, 0, 0}, ck, lhist);
+        win_store_state(p, b, 0, st);
+        __syncthreads(); // the LDS staging of this batch is done before the next batch reuses it
     }
-    __syncthreads();
-    uint32_t *row = p.hist + (size_t)blockIdx.x * nb;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) row[i] = h[i];
+    uint32_t *row = p.hist + (size_t)blockIdx.x * p.n_buckets;
+    for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) row[i] = lhist[i];
 }
 
-// ---------------------------------------------------------------- sort: scatter of the 8-byte items (rows = emit workgroups)
+// ---------------------------------------------------------------- sort, level 1: scatter by coarse bucket (rows = first-kernel workgroups)
 __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_kernel(const WinParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint32_t *cur = reinterpret_cast<uint32_t *>(smem);
@@ -115,66 +117,236 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_kernel(const Wi
     WinItem8 *sorted = static_cast<WinItem8 *>(p.items_sorted);
     const uint32_t *row = p.hist + (size_t)blockIdx.x * nb;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) cur[i] = p.base[i] + row[i];
-    for (int i = threadIdx.x; i < p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
+    for (int i = threadIdx.x; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
     __syncthreads();
     constexpr int U = 4;
     for (int64_t b = p.b0 + blockIdx.x; b < p.b0 + p.n_batches; b += gridDim.x) {
         const WinState st = p.state[b];
         const int64_t n = st.end - st.begin; // the frontier of the hop about to be gathered
         const WinItem8 *src = items + b * p.item_pitch;
-        for (int64_t t0 = 0; t0 < n; t0 += (int64_t)U * WIN_PART_THREADS) {
+        for (int64_t t0 = 0; t0 < n; t0 += (int64_t)U * blockDim.x) {
             WinItem8 it[U];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t j = t0 + (int64_t)u * WIN_PART_THREADS + threadIdx.x;
+                const int64_t j = t0 + (int64_t)u * blockDim.x + threadIdx.x;
                 ok[u] = j < n;
                 if (ok[u]) it[u] = src[j];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) sorted[atomicAdd(&cur[win_vertex_bucket(lvtab, p.n_windows, nb, it[u].v)], 1u)] = it[u];
+                if (ok[u])
+                    sorted[atomicAdd(&cur[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v).coarse], 1u)] = it[u];
         }
     }
 }
 
-// the ticket sampler with its positions left in registers (G: lane = item, nothing is staged)
-template <int KMAX>
-__device__ __forceinline__ void sample_tickets_reg(CallKey ck, uint64_t id, uint32_t n, int k, uint32_t (&pos)[KMAX]) {
-    uint32_t keys[KMAX], vals[KMAX];
-    Draw d;
+// the histogram as a pass of its own (hops beyond the first: their items come from the emit kernel, which is not persistent)
+__global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *lvtab = h + p.n_buckets;
+    const int nb = p.n_buckets;
+    const WinItem8 *items = static_cast<const WinItem8 *>(p.items_in);
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) h[i] = 0;
+    for (int i = threadIdx.x; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
+    __syncthreads();
+    constexpr int U = 4;
+    for (int64_t b = p.b0 + blockIdx.x; b < p.b0 + p.n_batches; b += gridDim.x) {
+        const WinState st = p.state[b];
+        const int64_t n = st.end - st.begin;
+        const WinItem8 *src = items + b * p.item_pitch;
+        for (int64_t t0 = 0; t0 < n; t0 += (int64_t)U * blockDim.x) {
+            uint32_t v[U];
+            bool ok[U];
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-        if (s < k) {
-            const uint32_t m = (n - 1u) - (uint32_t)s;
-            if ((s & 1) == 0) d = draw(ck, id, (uint32_t)(s >> 1), 0u);
-            const uint32_t r = bounded32(d.half(s & 1), m);
-            const uint32_t last = m - 1u;
-            uint32_t tr = r, tl = last;
-#pragma unroll
-            for (int j = 0; j < s; ++j) {
-                tr = (keys[j] == r) ? vals[j] : tr;
-                tl = (keys[j] == last) ? vals[j] : tl;
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = t0 + (int64_t)u * blockDim.x + threadIdx.x;
+                ok[u] = j < n;
+                if (ok[u]) v[u] = src[j].v;
             }
-            keys[s] = r;
-            vals[s] = tl;
-            pos[s] = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) atomicAdd(&h[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u]).coarse], 1u);
         }
     }
+    __syncthreads();
+    uint32_t *row = p.hist + (size_t)blockIdx.x * nb;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) row[i] = h[i];
 }
+
+// ---------------------------------------------------------------- sort, level 2: inside each coarse bucket, by fine key
+// The level-1 output is cut into TILES of WIN_FINE_TILE consecutive items (a tile lies in one or two coarse buckets: they
+// hold ~170 K items each).  COUNT: a tile counts its items per (coarse bucket, fine key) in LDS and reserves, with one
+// returning atomic per non-empty bin, its own range inside that key's run (`fine_tot`, one counter per absolute key).
+// STARTS: the runs' starts = the coarse bucket's start + the prefix of its keys' totals.  PLACE: the tile reads its items
+// again (L2), ranks them per bin in LDS and writes each to start + reserved offset + rank -- scattered 8-byte writes, but
+// inside the few coarse segments (~1 MB each) the resident tiles work on, so they merge in the L2s.  The order inside a
+// key's run depends on which tile's atomic came first; it does not matter (outputs are addressed by the item's own slot).
+// Bins beyond the tile's first two coarse buckets are clamped into the last bin of the second (possible only when coarse
+// buckets hold fewer items than a tile): the order only matters for speed, and COUNT and PLACE clamp alike.
+constexpr int WIN_FINE_TILE = 4096, WIN_FINE_THREADS = 512, WIN_FINE_BINS = 2 * WIN_FINE_PER_COARSE;
+template <bool PLACE>
+__global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t h[WIN_FINE_BINS];
+    __shared__ uint32_t c0_s;
+    uint32_t *lvtab = reinterpret_cast<uint32_t *>(smem);
+    const WinItem8 *src = static_cast<const WinItem8 *>(p.items_sorted);
+    WinItem8 *dst = static_cast<WinItem8 *>(p.items_fine);
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
+    const uint32_t n = p.base[p.n_buckets];
+    constexpr int U = WIN_FINE_TILE / WIN_FINE_THREADS;
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * WIN_FINE_TILE < n; tile += gridDim.x) {
+        const uint32_t t0 = tile * WIN_FINE_TILE;
+        uint32_t *tile_off = p.fine_tile_off + (size_t)tile * WIN_FINE_BINS;
+        WinItem8 it[U];
+        uint32_t key[U], rank[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = t0 + (uint32_t)u * WIN_FINE_THREADS + tid;
+            ok[u] = j < n;
+            if (ok[u]) it[u] = src[j];
+        }
+        if (tid < WIN_FINE_BINS) h[tid] = PLACE ? tile_off[tid] : 0u; // PLACE: the tile's reserved offsets, then cursors
+        __syncthreads(); // also: the vertex table is loaded
+        StageKey sk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ok[u]) sk[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v);
+        if (tid == 0) c0_s = sk[0].coarse; // the tile's first item lies in its smallest coarse bucket
+        __syncthreads();
+        const uint32_t c0 = c0_s;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (ok[u]) {
+                key[u] = min((uint32_t)WIN_FINE_BINS - 1u, (sk[u].coarse - c0) * WIN_FINE_PER_COARSE + sk[u].fine);
+                rank[u] = atomicAdd(&h[key[u]], 1u);
+            }
+        if (PLACE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) dst[p.fine_start[(size_t)c0 * WIN_FINE_PER_COARSE + key[u]] + rank[u]] = it[u];
+        } else {
+            __syncthreads();
+            if (tid < WIN_FINE_BINS) {
+                const uint32_t cnt = h[tid];
+                tile_off[tid] = cnt ? atomicAdd(&p.fine_tot[(size_t)c0 * WIN_FINE_PER_COARSE + tid], cnt) : 0u;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fine_start = the exclusive prefix of fine_tot over ALL absolute keys in key order ((n_buckets + 1) * 128 of them: the last
+// row takes bins clamped out of the last bucket).  A global prefix, not "coarse start + prefix inside the bucket": clamped
+// bins count under a neighbouring key, and only a prefix over everything keeps the runs disjoint whatever was counted
+// where.  One workgroup: a wavefront sums a bucket's 128 keys, the bucket totals are scanned in LDS, then the same
+// wavefronts write their bucket's starts.
+__global__ void __launch_bounds__(1024) win_fine_starts_kernel(const WinParams p) {
+    __shared__ uint32_t tot[WIN_MAX_BUCKETS / 8 + 8], wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = p.n_buckets + 1;
+    for (int c = wave; c < rows; c += 16) {
+        const uint32_t a = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane];
+        const uint32_t b = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane + 1];
+        const uint32_t t = wave_sum(a + b);
+        if (lane == 0) tot[c] = t;
+    }
+    __syncthreads();
+    uint32_t carry = 0;
+    for (int c0 = 0; c0 < rows; c0 += 1024) { // exclusive scan of the bucket totals, 1 024 at a time
+        const int c = c0 + tid;
+        const uint32_t v = c < rows ? tot[c] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (c < rows) tot[c] = off + incl - v;
+        uint32_t all = 0;
+        for (int w = 0; w < 16; ++w) all += wave_tot[w];
+        carry += all;
+        __syncthreads();
+    }
+    for (int c = wave; c < rows; c += 16) {
+        const uint32_t a = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane];
+        const uint32_t b = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane + 1];
+        const uint32_t incl = wave_inclusive_scan(a + b);
+        p.fine_start[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane] = tot[c] + incl - (a + b);
+        p.fine_start[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane + 1] = tot[c] + incl - b;
+    }
+}
+
+// ---------------------------------------------------------------- the stage slot (round 4: positions travel with the neighbours)
+// One slot per frontier vertex, W = 16 or 32 words (one or two whole 64-byte chunks), a bit stream:
+//   bits  0..31  column start (edge pointer of the column's first edge; the narrow form has 32-bit edge pointers)
+//   bits 32..39  number of samples cnt (0 .. fan-out <= 255)
+//   then cnt pairs {neighbour id: bv bits, position inside the column: bp bits}, slot order (s = 0 .. cnt - 1)
+// bv = bits of the largest vertex id, bp = bits of the largest column length (tg_graph.max_degree; the edge count when the
+// caller gave none) -- per LAUNCH, uniform, passed as kernel arguments; the host picks W so that 40 + k (bv + bp) bits fit.
+// RMAT-24, k = 10: 40 + 10 * (24 + 19) = 470 bits: one chunk.  Because the chosen POSITIONS travel with the gathered
+// neighbours, the emit pass computes no draws: it is a pure stream (the round-3 form recomputed them, and the two passes
+// then both hung on the vector ALUs).
+struct StageBits {
+    int32_t bv, bp;
+};
+__host__ __device__ inline int stage_bits_of(uint64_t max_value) { // bits that hold 0 .. max_value
+    int b = 1;
+    while (b < 64 && (max_value >> b) != 0) ++b;
+    return b;
+}
+__host__ __device__ inline int stage_slot_bits(int k, StageBits sb) { return 40 + k * (sb.bv + sb.bp); }
+
+// LDS bit-stream writer / reader over a lane's row of the tile (uniform control flow: bv, bp and the unrolled slot index
+// are the same for every lane, so `fill` and the word index are scalars)
+struct BitWriter {
+    uint32_t *row;
+    uint64_t acc;
+    int fill, w;
+    __device__ __forceinline__ void push(uint32_t v, int bits) { // bits <= 32, v < 2^bits
+        acc |= (uint64_t)v << fill;
+        fill += bits;
+        if (fill >= 32) {
+            row[w++] = (uint32_t)acc;
+            acc >>= 32;
+            fill -= 32;
+        }
+    }
+    __device__ __forceinline__ void finish(int n_words) {
+        if (fill > 0) row[w++] = (uint32_t)acc;
+        for (; w < n_words; ++w) row[w] = 0u;
+    }
+};
+struct BitReader {
+    const uint32_t *row;
+    uint64_t acc;
+    int fill, w;
+    __device__ __forceinline__ uint32_t pop(int bits) { // bits <= 32
+        if (fill < bits) {
+            acc |= (uint64_t)row[w++] << fill;
+            fill += 32;
+        }
+        const uint32_t v = (uint32_t)acc & (bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u));
+        acc >>= bits;
+        fill -= bits;
+        return v;
+    }
+};
 
 // ---------------------------------------------------------------- G: window-ordered gather into the stage slots
-// W = words per stage slot (16: one 64-byte chunk, fan-outs <= 14; 32: two chunks, fan-outs <= 30); KMAX = W - 2.
-template <int W, bool REPLACE>
-__global__ void win_stage_gather_kernel(const WinParams p) {
-    constexpr int KMAX = W - 2;
+// W = words per stage slot; KMAX = unroll bound of the slot loops (>= the hop's fan-out).
+template <int W, int KMAX, bool REPLACE>
+__global__ void win_stage_gather_kernel(const WinParams p, const StageBits sb) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned long long slice_lo[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // per wave: tile [64][W + 1] u32 (the odd pitch keeps lane-per-row accesses off each other's banks), slot index [64]
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * (64 * (W + 1) + 64);
     uint32_t *jrow = tile + 64 * (W + 1);
-    const WinItem8 *items = static_cast<const WinItem8 *>(p.items_sorted);
+    const WinItem8 *items = static_cast<const WinItem8 *>(p.items_fine);
     const int k = p.k;
     WinQueues::Q *Q = &p.queues->q[blockIdx.x & 7];
     const unsigned long long qend = Q->end;
@@ -190,10 +362,10 @@ __global__ void win_stage_gather_kernel(const WinParams p) {
         if (tid == 0) nxt = atomicAdd(&Q->head, slice);
         const unsigned long long j = lo + (unsigned long long)wave * 64 + lane;
         const bool live = j < qend;
-        uint32_t row[W];
+        uint32_t slot_index = 0xffffffffu, e0w = 0, cnt = 0;
+        uint32_t pos[KMAX], nbr[KMAX];
 #pragma unroll
-        for (int w = 0; w < W; ++w) row[w] = 0u;
-        uint32_t slot_index = 0xffffffffu;
+        for (int s = 0; s < KMAX; ++s) pos[s] = nbr[s] = 0u;
         if (live) {
             WinItem8 it = items[j];
             TG_CHECK_VERTEX(p, it.v);
@@ -207,24 +379,16 @@ __global__ void win_stage_gather_kernel(const WinParams p) {
                 e1 = (uint64_t)p.ptrs[(int64_t)it.v + 1];
             }
             const uint32_t n = (uint32_t)(e1 - e0);
-            const uint32_t cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
+            cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
             slot_index = (uint32_t)((int64_t)b * p.item_pitch + idx);
-            row[0] = (uint32_t)e0;
-            row[1] = n;
+            e0w = (uint32_t)e0;
             if (cnt > 0) {
-                uint32_t pos[KMAX];
                 if (REPLACE || n > (uint32_t)k) {
                     const CallKey ck = p.call_keys[b];
                     const uint64_t did = (uint64_t)(p.id_base + p.state[b].begin + (int64_t)idx);
-                    if (REPLACE) { // sampling.rs:57-69
-                        Draw d;
-#pragma unroll
-                        for (int s = 0; s < KMAX; ++s)
-                            if (s < k) {
-                                if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                                pos[s] = bounded32(d.half(s & 1), n);
-                            }
-                    } else
+                    if (REPLACE) // sampling.rs:57-69
+                        slot_draws<KMAX, true>(ck, did, n, k, pos);
+                    else
                         sample_tickets_reg<KMAX>(ck, did, n, k, pos);
                 } else {
 #pragma unroll
@@ -233,16 +397,28 @@ __global__ void win_stage_gather_kernel(const WinParams p) {
                 if (p.indices32) {
 #pragma unroll
                     for (int s = 0; s < KMAX; ++s)
-                        if ((uint32_t)s < cnt) row[2 + s] = p.indices32[e0 + pos[s]];
+                        if ((uint32_t)s < cnt) nbr[s] = p.indices32[e0 + pos[s]];
                 } else {
 #pragma unroll
                     for (int s = 0; s < KMAX; ++s)
-                        if ((uint32_t)s < cnt) row[2 + s] = (uint32_t)p.indices[e0 + pos[s]];
+                        if ((uint32_t)s < cnt) nbr[s] = (uint32_t)p.indices[e0 + pos[s]];
                 }
             }
         }
+        { // the slot as a bit stream into this lane's row of the tile
+            BitWriter bw{tile + lane * (W + 1), (uint64_t)e0w | ((uint64_t)cnt << 32), 8, 1};
+            tile[lane * (W + 1)] = e0w;
+            bw.acc >>= 32;
 #pragma unroll
-        for (int w = 0; w < W; ++w) tile[lane * (W + 1) + w] = row[w];
+            for (int s = 0; s < KMAX; ++s) {
+                if (s < k) {
+                    const bool on = (uint32_t)s < cnt;
+                    bw.push(on ? nbr[s] : 0u, sb.bv);
+                    bw.push(on ? pos[s] : 0u, sb.bp);
+                }
+            }
+            bw.finish(W);
+        }
         jrow[lane] = slot_index;
         wave_lds_handoff();
         // W lanes write one item's slot: whole aligned 64-byte chunks, 64 / W items per store instruction
@@ -261,19 +437,19 @@ __global__ void win_stage_gather_kernel(const WinParams p) {
 // ---------------------------------------------------------------- E(h): per batch, slot order: stage -> the four streams
 constexpr int WIN_STAGE_ROUND_CHUNKS_MAX = 16;
 
-// LDS of E: chunk offsets | tile [round chunks * 64][W + 1] u32 | per wave: positions [64*k] u32, lanes [64*k] u8,
-// first output of each lane [64] u32
+// LDS of E: chunk offsets | tile [round chunks * 64][W + 1] u32 | per wave: neighbours [64*k] u32, edge pointers [64*k] u32,
+// lanes [64*k] u8
 __host__ __device__ inline size_t win_stage_emit_wave_bytes(int k) {
-    return (size_t)64 * k * sizeof(uint32_t) + (((size_t)64 * k + 15) & ~(size_t)15) + 64 * sizeof(uint32_t);
+    return (size_t)2 * 64 * k * sizeof(uint32_t) + (((size_t)64 * k + 15) & ~(size_t)15);
 }
 __host__ __device__ inline size_t win_stage_emit_lds_bytes(int W, int k, int n_waves, int round_chunks) {
     return (((size_t)(round_chunks + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) +
            (size_t)round_chunks * 64 * (W + 1) * sizeof(uint32_t) + (size_t)n_waves * win_stage_emit_wave_bytes(k);
 }
 
-template <int W, int KMAX, bool REPLACE, bool NEXT>
-__device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigned char *smem, const int64_t b,
-                                                     const int round_chunks) {
+template <int W, int KMAX, bool NEXT>
+__device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const StageBits sb, unsigned char *smem,
+                                                     const int64_t b, const int round_chunks) {
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
@@ -283,9 +459,9 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem + off_bytes);
     unsigned char *wbase = smem + off_bytes + (size_t)round_chunks * 64 * (W + 1) * sizeof(uint32_t) +
                            (size_t)wave * win_stage_emit_wave_bytes(k);
-    uint32_t *spos = reinterpret_cast<uint32_t *>(wbase);
-    uint8_t *slane = wbase + (size_t)64 * k * sizeof(uint32_t);
-    uint32_t *lfirst = reinterpret_cast<uint32_t *>(wbase + (size_t)64 * k * sizeof(uint32_t) + (((size_t)64 * k + 15) & ~(size_t)15));
+    uint32_t *sval = reinterpret_cast<uint32_t *>(wbase);
+    uint32_t *sptr = sval + (size_t)64 * k;
+    uint8_t *slane = reinterpret_cast<uint8_t *>(sptr + (size_t)64 * k);
 
     int64_t *samples = p.samples + b * p.cap_nodes;
     int64_t *rows = p.rows + b * p.cap_edges;
@@ -295,7 +471,6 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
     const WinState st = p.state[b];
     const int64_t begin = st.begin, end = st.end;
     int64_t ne = st.ne;
-    const CallKey ck = p.call_keys[b];
     const uint32_t *stage = p.stage + (size_t)(b * p.item_pitch) * W;
     WinItem8 *next_items = static_cast<WinItem8 *>(p.items_in) + b * p.next_pitch;
 
@@ -334,8 +509,7 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
                 dst[3] = x[r].w;
             }
             wave_lds_handoff();
-            const uint32_t n = t[lane * (W + 1) + 1];
-            const uint32_t cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
+            const uint32_t cnt = t[lane * (W + 1) + 1] & 0xffu; // rows past `live` were zero-filled
             const uint32_t tot = wave_sum(cnt);
             if (lane == 0) chunk_off[c] = tot;
         }
@@ -347,41 +521,32 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
             if (lane == 63) chunk_off[nc] = incl;
         }
         __syncthreads();
-        for (int c = wave; c < nc; c += n_waves) { // pass B: draws, the four streams (and the next hop's items)
+        for (int c = wave; c < nc; c += n_waves) { // pass B: unpack, the four streams (and the next hop's items)
             const uint32_t *t = tile + (size_t)c * 64 * (W + 1);
             const int64_t i0 = round_begin + (int64_t)c * 64;
-            const int64_t i = i0 + lane;
-            const uint32_t n = t[lane * (W + 1) + 1];
-            const uint32_t cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
-            const uint64_t did = (uint64_t)(p.id_base + i);
+            const uint32_t e0 = t[lane * (W + 1)];
+            const uint32_t hdr = t[lane * (W + 1) + 1];
+            const uint32_t cnt = hdr & 0xffu;
             const uint32_t incl = wave_inclusive_scan(cnt);
             const uint32_t excl = incl - cnt;
             const uint32_t total = __shfl(incl, 63, 64);
             const int64_t ea = ne + (int64_t)chunk_off[c];
-            lfirst[lane] = excl;
-            if (cnt > 0) {
-                if (REPLACE) { // sampling.rs:57-69
-                    Draw d;
-                    for (int s = 0; s < k; ++s) {
-                        if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                        spos[excl + s] = bounded32(d.half(s & 1), n);
-                        slane[excl + s] = (uint8_t)lane;
+            { // lane = slot: its pairs out of the bit stream into output order
+                BitReader br{t + lane * (W + 1), (uint64_t)(hdr >> 8), 24, 2};
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s) {
+                    if (s < k) {
+                        const uint32_t v = br.pop(sb.bv);
+                        const uint32_t ps = br.pop(sb.bp);
+                        if ((uint32_t)s < cnt) {
+                            sval[excl + s] = v;
+                            sptr[excl + s] = e0 + ps; // the CSC edge pointer (narrow form: < 2^32)
+                            slane[excl + s] = (uint8_t)lane;
+                        }
                     }
-                } else if (n <= (uint32_t)k) { // sampling.rs:12-15
-                    for (uint32_t s = 0; s < cnt; ++s) {
-                        spos[excl + s] = s;
-                        slane[excl + s] = (uint8_t)lane;
-                    }
-                } else {
-                    sample_tickets<KMAX>(ck, did, n, k, spos, slane, excl, lane);
                 }
             }
             wave_lds_handoff();
-            // the gathered neighbour of output q of this chunk: slot `l`'s (q - first output of l)-th value
-            auto value_of = [&](uint32_t q) -> int64_t {
-                const int l = slane[q];
-                return (int64_t)t[l * (W + 1) + 2 + (q - lfirst[l])];
-            };
             // rows / cols / edge_index share the parity of their addresses (equal pitch, 16-byte aligned bases); samples
             // (offset by n_seeds, pitch cap_nodes) has its own.  An element at an address that is not 16-byte aligned is
             // stored alone, the rest as 16-byte pairs, one stream after the other (the emit kernel's store shape).
@@ -391,17 +556,17 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
                 if (head) {
                     __builtin_nontemporal_store(n_seeds + ea, &rows[ea]);
                     __builtin_nontemporal_store(i0 + (int64_t)slane[0], &cols[ea]);
-                    __builtin_nontemporal_store((int64_t)t[slane[0] * (W + 1)] + (int64_t)spos[0], &eidx[ea]);
+                    __builtin_nontemporal_store((int64_t)sptr[0], &eidx[ea]);
                 }
-                if (head_s) __builtin_nontemporal_store(value_of(0u), &samples[n_seeds + ea]);
+                if (head_s) __builtin_nontemporal_store((int64_t)sval[0], &samples[n_seeds + ea]);
             }
             for (uint32_t q = head_s + 2u * lane; q < total; q += 128) { // :215
                 const int64_t e = ea + q;
                 if (q + 1 < total) {
-                    i64x2 s2 = {value_of(q), value_of(q + 1)};
+                    i64x2 s2 = {(int64_t)sval[q], (int64_t)sval[q + 1]};
                     __builtin_nontemporal_store(s2, reinterpret_cast<i64x2 *>(&samples[n_seeds + e]));
                 } else
-                    __builtin_nontemporal_store(value_of(q), &samples[n_seeds + e]);
+                    __builtin_nontemporal_store((int64_t)sval[q], &samples[n_seeds + e]);
             }
             for (uint32_t q = head + 2u * lane; q < total; q += 128) { // :217
                 const int64_t e = ea + q;
@@ -421,19 +586,16 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
             }
             for (uint32_t q = head + 2u * lane; q < total; q += 128) {
                 const int64_t e = ea + q;
-                const int l0 = slane[q];
                 if (q + 1 < total) {
-                    const int l1 = slane[q + 1];
-                    i64x2 x = {(int64_t)t[l0 * (W + 1)] + (int64_t)spos[q], (int64_t)t[l1 * (W + 1)] + (int64_t)spos[q + 1]};
+                    i64x2 x = {(int64_t)sptr[q], (int64_t)sptr[q + 1]};
                     __builtin_nontemporal_store(x, reinterpret_cast<i64x2 *>(&eidx[e]));
                 } else
-                    __builtin_nontemporal_store((int64_t)t[l0 * (W + 1)] + (int64_t)spos[q], &eidx[e]);
+                    __builtin_nontemporal_store((int64_t)sptr[q], &eidx[e]);
             }
             if (NEXT) { // the new samples are the next hop's frontier: hand them over as items while they are in LDS
                 for (uint32_t q = lane; q < total; q += 64) {
-                    const uint32_t v = (uint32_t)value_of(q);
                     const uint32_t rel = (uint32_t)(n_seeds + ea + q - end); // index in the next frontier (it begins at `end`)
-                    next_items[rel] = WinItem8{v, ((uint32_t)b << p.next_idx_bits) | rel};
+                    next_items[rel] = WinItem8{sval[q], ((uint32_t)b << p.next_idx_bits) | rel};
                 }
             }
             wave_lds_handoff();
@@ -445,8 +607,8 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, unsigne
     win_store_state(p, b, hop, WinState{end, n_seeds + ne, ne, begin}); // :221-222
 }
 
-template <int W, int KMAX, bool REPLACE, bool NEXT>
-__global__ void win_stage_emit_kernel(const WinParams p, const int round_chunks) {
+template <int W, int KMAX, bool NEXT>
+__global__ void win_stage_emit_kernel(const WinParams p, const StageBits sb, const int round_chunks) {
     extern __shared__ __align__(16) unsigned char smem[];
-    win_stage_emit_batch<W, KMAX, REPLACE, NEXT>(p, smem, p.b0 + blockIdx.x, round_chunks);
+    win_stage_emit_batch<W, KMAX, NEXT>(p, sb, smem, p.b0 + blockIdx.x, round_chunks);
 }

@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "ns_tickets.h"
 #include "tg_device.h"
@@ -82,6 +83,10 @@ struct WinParams {
     uint32_t *vtab;  // [n_windows] first vertex whose column starts in window i or later
     uint32_t *stage; // [max_items][stage_words] {column start, degree, neighbours}
     int32_t n_windows, idx_bits, next_idx_bits;
+    int32_t n_wbuckets; // window buckets (multiple of 64); the staged form sorts by n_buckets = n_wbuckets / 8 COARSE buckets first
+    void *items_fine;   // staged form: the items after the second sort level (what the gather kernel reads)
+    uint32_t *fine_tot, *fine_start; // [(n_buckets + 1) * 128] items per absolute fine key / start of each key's run
+    uint32_t *fine_tile_off;         // [tiles][256] offset of a tile's items inside each key's run
     int64_t next_pitch;
     int64_t b0; // staged form in parts: the kernels of a part walk batches [b0, b0 + n_batches)
     TG_BOUNDS_FIELDS
@@ -145,31 +150,6 @@ __host__ __device__ inline size_t win_emit_wave_lds_bytes(int kmax) { // ... + t
     return (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15) + 64;
 }
 
-// The ticket chain of sample_tickets with the slot's bounded draws r[s] already in registers (they were computed by
-// OTHER lanes, below): same positions, same order.
-template <int KMAX>
-__device__ __forceinline__ void sample_tickets_given(const uint32_t (&r_in)[KMAX], uint32_t n, int k, uint32_t *spos,
-                                                     uint8_t *slane, uint32_t out_base, int lane) {
-    uint32_t keys[KMAX], vals[KMAX];
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-        if (s < k) {
-            const uint32_t m = (n - 1u) - (uint32_t)s;
-            const uint32_t r = r_in[s];
-            const uint32_t last = m - 1u;
-            uint32_t tr = r, tl = last;
-#pragma unroll
-            for (int j = 0; j < s; ++j) {
-                tr = (keys[j] == r) ? vals[j] : tr;
-                tl = (keys[j] == last) ? vals[j] : tl;
-            }
-            keys[s] = r;
-            vals[s] = tl;
-            spos[out_base + s] = (tr < n - (uint32_t)k) ? (uint32_t)k + tr : (uint32_t)s;
-            slane[out_base + s] = (uint8_t)lane;
-        }
-    }
-}
 __host__ __device__ inline size_t win_emit_head_bytes() {
     return (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
            (size_t)WIN_ROUND_SLOTS * (sizeof(int64_t) + sizeof(uint32_t));
@@ -185,7 +165,7 @@ __host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
 // buys nothing; deeper frontiers are drawn by degree, repeat the hubs and touch every line ~13 times.
 // One hop of one batch by one workgroup; returns the batch's state after the hop.  `hop` / `k` are arguments (not
 // p.hop / p.k) so that one kernel can run consecutive hops of its batch back to back.
-__device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v); // staged form
+__device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v, uint32_t *lhist); // staged form
 
 // NEXT (DIRECT only; staged form): every new sample is also handed to the next hop as an 8-byte item.
 template <typename Item, int KMAX, bool REPLACE, bool DIRECT, bool FOLD = false, bool NEXT = false>
@@ -284,16 +264,19 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
                 const int my_rank = __popcll(dmask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
                 if (draws) dl[my_rank] = (uint8_t)lane;
                 wave_lds_handoff();
-                const int nb = (k + 1) >> 1;
+                const int nb = (k + 3) >> 2; // Philox blocks per drawing slot: four 32-bit words each
                 for (int t = lane; t < n_draw * nb; t += 64) {
                     const int rank = t / nb, blk = t - rank * nb;
                     const int src = dl[rank];
                     const uint32_t ns = cdeg[c * 64 + src];
-                    const Draw d = draw(ck, (uint64_t)(p.id_base + i0 + src), (uint32_t)blk, REPLACE ? D1_REPLACE : 0u);
+                    const uint64_t sid = (uint64_t)(p.id_base + i0 + src);
+                    const Draw d = draw(ck, sid, (uint32_t)blk, REPLACE ? D1_REPLACE : 0u);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int sl = 2 * blk + h;
-                        if (sl < k) spos[rank * k + sl] = bounded32(d.half(h), REPLACE ? ns : (ns - 1u) - (uint32_t)sl);
+                    for (int h = 0; h < 4; ++h) {
+                        const int sl = 4 * blk + h;
+                        if (sl < k)
+                            spos[rank * k + sl] = slot_draw_from(d, ck, sid, (uint32_t)sl, REPLACE ? D1_REPLACE : 0u,
+                                                                 REPLACE ? ns : (ns - 1u) - (uint32_t)sl);
                     }
                 }
                 wave_lds_handoff();
@@ -323,12 +306,7 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
                 }
             } else if (cnt > 0) {
                 if (REPLACE) { // sampling.rs:57-69
-                    Draw d;
-                    for (int s = 0; s < k; ++s) {
-                        if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                        spos[excl + s] = bounded32(d.half(s & 1), n);
-                        slane[excl + s] = (uint8_t)lane;
-                    }
+                    sample_replace_any(ck, did, n, k, spos, slane, excl, lane);
                 } else if (n <= (uint32_t)k) { // sampling.rs:12-15
                     for (uint32_t s = 0; s < cnt; ++s) {
                         spos[excl + s] = s;
@@ -366,7 +344,7 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
                             __builtin_nontemporal_store(n_seeds + e, &rows[e]);
                             __builtin_nontemporal_store(i0 + (int64_t)l4[u], &cols[e]);
                             __builtin_nontemporal_store(ep[u], &eidx[e]);
-                            if (NEXT) win_next_item(p, b, (uint32_t)(n_seeds + e - end), (uint32_t)v[u]);
+                            if (NEXT) win_next_item(p, b, (uint32_t)(n_seeds + e - end), (uint32_t)v[u], lhist);
                         }
                     }
                 }
@@ -744,12 +722,7 @@ __global__ void win_gather_kernel(const WinParams p) {
             ebase[lane] = (int64_t)it.col();
             obase[lane] = (int64_t)b * p.cap_nodes + p.n_seeds + (int64_t)it.e - (int64_t)excl;
             if (REPLACE) { // sampling.rs:57-69, k draws of U[0,n)
-                Draw d;
-                for (int s = 0; s < k; ++s) {
-                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                    spos[excl + s] = bounded32(d.half(s & 1), n);
-                    slane[excl + s] = (uint8_t)lane;
-                }
+                sample_replace_any(ck, did, n, k, spos, slane, excl, lane);
             } else if (n <= (uint32_t)k) { // sampling.rs:12-15: the reservoir is just filled
                 for (uint32_t s = 0; s < cnt; ++s) {
                     spos[excl + s] = s;
@@ -771,8 +744,10 @@ __global__ void win_gather_kernel(const WinParams p) {
 
 #include "ns_homo_stage.inl"
 
-__device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v) {
+// lhist (first kernel): the workgroup's coarse histogram in LDS, its vertex table right behind it
+__device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v, uint32_t *lhist) {
     static_cast<WinItem8 *>(p.items_in)[b * p.next_pitch + rel] = WinItem8{v, ((uint32_t)b << p.next_idx_bits) | rel};
+    if (lhist) atomicAdd(&lhist[win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v).coarse], 1u);
 }
 
 static int win_env_int(const char *name, int dflt) {
@@ -786,6 +761,7 @@ struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
     int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches, stage_sort_blocks;
+    int32_t stage_fine;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -804,7 +780,8 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_EMIT_THREADS", 256),
         win_env_int("TG_WIN_STAGE_PARTS", 1),
         win_env_int("TG_WIN_STAGE_PART_MIN_BATCHES", 1024),
-        win_env_int("TG_WIN_STAGE_SORT_BLOCKS", 512),
+        win_env_int("TG_WIN_STAGE_SORT_BLOCKS", 768),
+        win_env_int("TG_WIN_STAGE_FINE", 1),
     };
     return t;
 }
@@ -837,19 +814,35 @@ static WinStageClock &win_clock() {
 }
 
 struct WinLayout {
-    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, stage, total, total_push;
+    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, fine_tot, fine_start, fine_tile_off, stage, total, total_push;
     int64_t max_items;
     int stage_words; // 16 / 32: words per stage slot of the staged form; 0: fan-outs beyond it (push form only)
 };
 
-// words per stage slot: {column start, degree} + the largest fan-out of an ORDERED hop (hop 0 is direct)
-static int win_stage_words(const int64_t *fanout, int32_t n_hops) {
+// bit widths of a stage slot's pairs for this graph (ns_homo_stage.inl): vertex ids, positions inside a column
+static StageBits win_stage_bits(const tg_graph *csc) {
+    StageBits sb;
+    if (!csc) {
+        sb.bv = sb.bp = 32;
+        return sb;
+    }
+    sb.bv = stage_bits_of((uint64_t)std::max<int64_t>(csc->n_major, 1) - 1);
+    const int64_t longest = csc->max_degree > 0 ? csc->max_degree : csc->n_edges;
+    sb.bp = stage_bits_of((uint64_t)std::max<int64_t>(longest, 1) - 1);
+    return sb;
+}
+// words per stage slot for the largest fan-out of an ORDERED hop (hop 0 is direct): 16 (one 64-byte chunk), 32 (two), or 0
+// when the pairs do not fit two chunks (the launch then takes the push form).  csc == NULL: 32-bit fields assumed.
+static int win_stage_words(const tg_graph *csc, const int64_t *fanout, int32_t n_hops) {
     int64_t k = 0;
     for (int h = 1; h < n_hops; ++h) k = std::max(k, fanout[h]);
-    return n_hops < 2 ? 0 : (k <= 14 ? 16 : (k <= 30 ? 32 : 0));
+    if (n_hops < 2 || k > 32) return 0;
+    if (!csc) return 32; // sizing without a graph: the most a launch can ask for
+    const int bits = stage_slot_bits((int)k, win_stage_bits(csc));
+    return (bits <= 512 && k <= 16) ? 16 : (bits <= 1024 ? 32 : 0);
 }
 
-static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops) {
+static WinLayout win_layout(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops) {
     WinLayout L;
     int64_t layer = n_seeds, widest = n_seeds;
     for (int h = 0; h + 1 < n_hops; ++h) {
@@ -871,9 +864,12 @@ static WinLayout win_layout(int64_t n_batches, int64_t n_seeds, const int64_t *f
     L.base = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS + 8) * sizeof(uint32_t));
     L.items_in = take((size_t)L.max_items * sizeof(WinItemW)); // sized for the wide form
     L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
-    L.vtab = take((size_t)WIN_MAX_BUCKETS * sizeof(uint32_t));
-    L.total_push = at; // what the push form needs; the staged form's slots come after it
-    L.stage_words = win_stage_words(fanout, n_hops);
+    L.vtab = take((size_t)(WIN_MAX_BUCKETS + 8) * sizeof(uint32_t));
+    L.total_push = at; // what the push form needs; the staged form's tables and slots come after it
+    L.fine_tot = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * 128 * sizeof(uint32_t));
+    L.fine_start = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * 128 * sizeof(uint32_t));
+    L.fine_tile_off = take(((size_t)L.max_items / 4096 + WIN_MAX_PARTS + 1) * 256 * sizeof(uint32_t));
+    L.stage_words = win_stage_words(csc, fanout, n_hops);
     L.stage = take((size_t)L.max_items * L.stage_words * sizeof(uint32_t));
     L.total = at;
     return L;
@@ -988,15 +984,24 @@ static bool win_staged_applicable(const WinParams &p, const WinTuning &t, const 
     return true;
 }
 
-// The side stream and events of the staged form (one set per process; launches that share them serialise on the events,
-// which keeps them correct).  Part p's emit pass runs on the side stream while part p + 1 is sorted and gathered on the
-// caller's: the gather is bound by vector-ALU work (ticket draws), the emit pass by its streams, so they overlap.
+// The side stream and events of the staged form (one set per process).  Part p's emit pass runs on the side stream while
+// part p + 1's first hop, sort and gather run on the caller's: since round 4 the emit pass is a pure stream (no draws), so
+// it overlaps with the gather, which hangs on the vector ALUs.  `mu` is held over the whole enqueue sequence of a launch
+// in parts: two host threads launching at once would otherwise re-record an event between the other's record and wait.
 struct WinSide {
     hipStream_t stream = nullptr;
     hipEvent_t gathered[WIN_MAX_PARTS] = {}, done = nullptr;
+    std::mutex mu;
     int ensure() {
         if (stream) return TG_OK;
-        TG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // the emit pass gets the higher dispatch priority (TG_WIN_SIDE_PRIO=0: plain): beside it run the NEXT part's first
+        // hop and sort, whose thousands of short workgroups would otherwise take every free slot first
+        int least = 0, greatest = 0;
+        if (win_env_int("TG_WIN_SIDE_PRIO", 1) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+            greatest < least)
+            TG_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest));
+        else
+            TG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto &e : gathered) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         TG_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
         return TG_OK;
@@ -1007,11 +1012,14 @@ static WinSide &win_side() {
     return s;
 }
 
-template <int W, int KMAX, bool REPLACE>
+// KFIRST: unroll bound of hop 0's direct kernel (any fan-out up to TG_MAX_FANOUT); the ordered hops' bound follows W
+template <int W, int KFIRST, bool REPLACE>
 static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, const int64_t *fanout, int32_t n_hops,
                           hipStream_t stream) {
+    constexpr int KMAX = W == 16 ? 16 : 32;
     const WinTuning t = win_tuning();
     WinStageClock &clk = win_clock();
+    const StageBits sb = win_stage_bits(csc);
     p.n_windows = (int32_t)((csc->n_edges >> p.shift) + 1);
     auto pitch_of = [&](int h) {
         int64_t f = p.n_seeds;
@@ -1023,69 +1031,102 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         while (((int64_t)1 << bits) < pitch) ++bits;
         return bits;
     };
-    const size_t tables = ((size_t)p.n_buckets + p.n_windows) * sizeof(uint32_t); // counters + vertex table in LDS
+    // two sort levels (ns_homo_stage.inl): window buckets in groups of 8 = coarse buckets, 8 queues of coarse buckets
+    p.n_wbuckets = (p.n_buckets + 63) & ~63;
+    p.n_buckets = p.n_wbuckets >> 3;
+    const size_t tables = win_stage_tables_bytes(p.n_buckets, p.n_windows); // counters + vertex table in LDS
     // parts: only worth it when every part still revisits the lines of a window often (>= 1 024 batches each)
     int parts = std::min(std::max(t.stage_parts, 1), WIN_MAX_PARTS);
     while (parts > 1 && n_batches / parts < std::max(t.stage_part_min_batches, 1)) --parts;
     if (clk.enabled) parts = 1; // stage timing: one stream, one part, so that the events bracket single kernels
     WinSide &side = win_side();
+    std::unique_lock<std::mutex> side_lock(side.mu, std::defer_lock);
     if (parts > 1) {
+        side_lock.lock();
         const int rc = side.ensure();
         if (rc != TG_OK) return rc;
     }
     uint32_t *const hist0 = p.hist, *const base0 = p.base;
     WinQueues *const queues0 = p.queues;
-    void *const sorted0 = p.items_sorted;
+    void *const sorted0 = p.items_sorted, *const in0 = p.items_in;
+    uint32_t *const fine_tot0 = p.fine_tot, *const fine_start0 = p.fine_start, *const fine_tile_off0 = p.fine_tile_off;
+    // two hops: the whole chain of a part -- first hop, sort, gather -- runs beside the previous part's emit pass; deeper
+    // launches run their earlier hops whole and only the LAST hop in parts
+    const bool first_in_parts = parts > 1 && n_hops == 2;
 
-    clk.begin(stream);
-    hipLaunchKernelGGL(win_vtab_kernel, dim3((p.n_windows + 255) / 256), dim3(256), 0, stream, p, csc->n_major);
-    TG_LAUNCH_CHECK();
-    { // E0: seeds, hop 0 direct, the items of hop 1 -- all batches
-        int threads = t.emit_threads;
-        while (threads > 64 && win_emit_lds_bytes(p.kmax, threads / 64) > 64 * 1024) threads = ((threads >> 1) + 63) & ~63;
-        p.b0 = 0;
-        p.n_batches = n_batches;
+    int fthreads = t.emit_threads;
+    while (fthreads > 64 && win_emit_lds_bytes(p.kmax, fthreads / 64) + tables > 64 * 1024)
+        fthreads = ((fthreads >> 1) + 63) & ~63;
+    auto rows_of = [&](int64_t nb) { // sort workgroups = rows of the histogram = persistent workgroups of the first kernel
+        return (int32_t)std::min<int64_t>(std::min(std::max(t.stage_sort_blocks, 1), WIN_MAX_ROWS), nb);
+    };
+    auto part_tables = [&](int part) {
+        p.hist = hist0 + (size_t)part * WIN_MAX_ROWS * (WIN_MAX_BUCKETS / 8);
+        p.base = base0 + (size_t)part * (WIN_MAX_BUCKETS + 8);
+        p.queues = queues0 + part;
+    };
+    auto launch_first = [&](int part, int64_t b0, int64_t nb) { // E0: seeds, hop 0 direct, the items of hop 1 + their histogram
+        part_tables(part);
+        p.b0 = b0;
+        p.n_batches = nb;
+        p.n_rows = rows_of(nb);
         p.next_pitch = pitch_of(1);
         p.next_idx_bits = bits_of(p.next_pitch);
-        hipLaunchKernelGGL((win_stage_first_kernel<KMAX, REPLACE>), dim3((unsigned)n_batches), dim3(threads),
-                           win_emit_lds_bytes(p.kmax, threads / 64), stream, p, (int)fanout[0]);
+        hipLaunchKernelGGL((win_stage_first_kernel<KFIRST, REPLACE>), dim3((unsigned)p.n_rows), dim3(fthreads),
+                           win_emit_lds_bytes(p.kmax, fthreads / 64) + tables, stream, p, (int)fanout[0]);
+    };
+
+    clk.begin(stream);
+    hipLaunchKernelGGL(win_vtab_kernel, dim3((p.n_windows + 256) / 256), dim3(256), 0, stream, p, csc->n_major);
+    TG_LAUNCH_CHECK();
+    if (!first_in_parts) {
+        launch_first(0, 0, n_batches);
         TG_LAUNCH_CHECK();
         clk.mark("first", 0, stream);
     }
     for (int h = 1; h < n_hops; ++h) {
-        p.hop = h;
-        p.k = (int32_t)fanout[h];
-        p.item_pitch = pitch_of(h);
-        p.idx_bits = bits_of(p.item_pitch);
         const bool next = h + 1 < n_hops;
-        p.next_pitch = next ? pitch_of(h + 1) : 0;
-        p.next_idx_bits = next ? bits_of(p.next_pitch) : 0;
-        int ethreads = t.stage_emit_threads;
-        int rc = std::min(std::max(t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
-        while (win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc) > 64 * 1024) {
-            if (rc > 1)
-                rc >>= 1;
-            else if (ethreads > 64)
-                ethreads = ((ethreads >> 1) + 63) & ~63;
-            else
-                return tg::fail(TG_ERR_INVALID, "tg_ns_homo_batched_ws: the staged emit kernel does not fit the LDS");
-        }
-        const size_t elds = win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc);
-        int gthreads = t.stage_gather_threads;
-        const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
-        while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
-        const int gblocks = (std::max(t.stage_gather_blocks, 8) + 7) & ~7;
-        for (int part = 0; part < parts; ++part) {
-            p.b0 = n_batches * part / parts;
-            p.n_batches = n_batches * (part + 1) / parts - p.b0;
-            p.n_rows = (int32_t)std::min<int64_t>(std::min(std::max(t.stage_sort_blocks, 1), WIN_PART_BLOCKS), p.n_batches); // rows of the histogram = sort workgroups
-            p.hist = hist0 + (size_t)part * WIN_PART_BLOCKS * WIN_MAX_BUCKETS;
-            p.base = base0 + (size_t)part * (WIN_MAX_BUCKETS + 8);
-            p.queues = queues0 + part;
-            p.items_sorted = static_cast<WinItem8 *>(sorted0) + p.b0 * p.item_pitch; // the part's own range of the sorted array
-            hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
-            TG_LAUNCH_CHECK();
-            clk.mark("hist", h, stream);
+        const int hparts = next ? 1 : parts; // a hop with a successor keeps one stream: its items feed the next hop's sort
+        for (int part = 0; part < hparts; ++part) {
+            const int64_t b0 = n_batches * part / hparts, nb = n_batches * (part + 1) / hparts - b0;
+            const bool counted = h == 1 && (first_in_parts || hparts == 1); // the first kernel left this part's histogram
+            if (first_in_parts) {
+                launch_first(part, b0, nb);
+                TG_LAUNCH_CHECK();
+            }
+            p.hop = h;
+            p.k = (int32_t)fanout[h];
+            p.item_pitch = pitch_of(h);
+            p.idx_bits = bits_of(p.item_pitch);
+            p.next_pitch = next ? pitch_of(h + 1) : 0;
+            p.next_idx_bits = next ? bits_of(p.next_pitch) : 0;
+            int ethreads = t.stage_emit_threads;
+            int rc = std::min(std::max(t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
+            while (win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc) > 64 * 1024) {
+                if (rc > 1)
+                    rc >>= 1;
+                else if (ethreads > 64)
+                    ethreads = ((ethreads >> 1) + 63) & ~63;
+                else
+                    return tg::fail(TG_ERR_INVALID, "tg_ns_homo_batched_ws: the staged emit kernel does not fit the LDS");
+            }
+            const size_t elds = win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc);
+            int gthreads = t.stage_gather_threads;
+            const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
+            while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
+            const int gblocks = (std::max(t.stage_gather_blocks, 8) + 7) & ~7;
+            part_tables(part);
+            p.b0 = b0;
+            p.n_batches = nb;
+            p.n_rows = rows_of(nb);
+            p.items_in = in0;
+            p.items_sorted = static_cast<WinItem8 *>(sorted0) + p.b0 * p.item_pitch; // the part's own range of the two flat arrays
+            p.items_fine = static_cast<WinItem8 *>(in0) + p.b0 * p.item_pitch; // (the strided items are dead after level 1)
+            if (!counted) {
+                hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+                TG_LAUNCH_CHECK();
+                clk.mark("hist", h, stream);
+            }
             hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
                                p.n_rows);
             TG_LAUNCH_CHECK();
@@ -1095,29 +1136,46 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
             TG_LAUNCH_CHECK();
             clk.mark("scatter", h, stream);
-            hipLaunchKernelGGL((win_stage_gather_kernel<W, REPLACE>), dim3(gblocks), dim3(gthreads),
-                               (size_t)(gthreads / 64) * per_wave, stream, p);
+            if (t.stage_fine) {
+                const int64_t worst = p.n_batches * p.item_pitch; // the item count itself lives on the device
+                const size_t vt = (size_t)(p.n_windows + 1) * sizeof(uint32_t);
+                const size_t keys = (size_t)(p.n_buckets + 1) * WIN_FINE_PER_COARSE;
+                p.fine_tot = fine_tot0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE;
+                p.fine_start = fine_start0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE;
+                p.fine_tile_off = fine_tile_off0 + ((size_t)(p.b0 * p.item_pitch) / WIN_FINE_TILE + (size_t)part) * WIN_FINE_BINS;
+                const unsigned tiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>((worst + WIN_FINE_TILE - 1) / WIN_FINE_TILE, 2048));
+                TG_HIP(hipMemsetAsync(p.fine_tot, 0, keys * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(win_sort_fine_kernel<false>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, stream, p);
+                TG_LAUNCH_CHECK();
+                hipLaunchKernelGGL(win_fine_starts_kernel, dim3(1), dim3(1024), 0, stream, p);
+                TG_LAUNCH_CHECK();
+                hipLaunchKernelGGL(win_sort_fine_kernel<true>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, stream, p);
+                TG_LAUNCH_CHECK();
+                clk.mark("fine", h, stream);
+            } else
+                p.items_fine = p.items_sorted; // the gather kernel reads the coarse-sorted items
+            hipLaunchKernelGGL((win_stage_gather_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
+                               (size_t)(gthreads / 64) * per_wave, stream, p, sb);
             TG_LAUNCH_CHECK();
             clk.mark("gather", h, stream);
             // the emit pass of the last hop has nothing after it to wait for: it goes to the side stream, behind this
-            // part's gather, and the next part's sort + gather start beside it.  (A hop with a successor keeps one
-            // stream: its items feed the next hop's sort.)
+            // part's gather, and the next part's chain starts beside it
             hipStream_t es = stream;
-            if (parts > 1 && !next) {
+            if (hparts > 1) {
                 TG_HIP(hipEventRecord(side.gathered[part], stream));
                 TG_HIP(hipStreamWaitEvent(side.stream, side.gathered[part], 0));
                 es = side.stream;
             }
             if (next)
-                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, true>), dim3((unsigned)p.n_batches),
-                                   dim3(ethreads), elds, es, p, rc);
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, true>), dim3((unsigned)p.n_batches), dim3(ethreads), elds,
+                                   es, p, sb, rc);
             else
-                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, REPLACE, false>), dim3((unsigned)p.n_batches),
-                                   dim3(ethreads), elds, es, p, rc);
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, false>), dim3((unsigned)p.n_batches), dim3(ethreads), elds,
+                                   es, p, sb, rc);
             TG_LAUNCH_CHECK();
             clk.mark("emit", h, stream);
         }
-        if (parts > 1 && !next) { // join: the caller's stream continues after the last emit pass
+        if (hparts > 1) { // join: the caller's stream continues after the last emit pass
             TG_HIP(hipEventRecord(side.done, side.stream));
             TG_HIP(hipStreamWaitEvent(stream, side.done, 0));
         }
@@ -1129,9 +1187,10 @@ template <bool REPLACE>
 static int win_dispatch_staged(const WinParams &p, const tg_graph *csc, int stage_words, int64_t n_batches,
                                const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
     if (stage_words == 16)
-        return p.kmax <= 16 ? win_run_staged<16, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
-                            : win_run_staged<16, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
-    return win_run_staged<32, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
+        return fanout[0] <= 16 ? win_run_staged<16, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
+                               : win_run_staged<16, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
+    return fanout[0] <= 16 ? win_run_staged<32, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
+                           : win_run_staged<32, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
 }
 
 // window size: a few hundred KB of the gathered array, at most WIN_MAX_BUCKETS windows
@@ -1158,8 +1217,8 @@ static int win_dispatch(const WinParams &p, bool repl, int64_t n_batches, const 
 
 } // namespace tg
 
-extern "C" int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
-                                          int64_t *n_bytes) {
+extern "C" int tg_ns_homo_workspace_bytes_for(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
+                                              int32_t n_hops, int64_t *n_bytes) {
     TG_REQUIRE(n_batches >= 0 && n_seeds >= 0 && n_hops >= 0 && n_hops <= TG_MAX_HOPS && (fanout || n_hops == 0) &&
                    n_bytes,
                "tg_ns_homo_workspace_bytes: bad arguments");
@@ -1167,9 +1226,13 @@ extern "C" int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, co
         TG_REQUIRE(fanout[h] >= 1 && fanout[h] <= 255, "tg_ns_homo_workspace_bytes: fanout[%d] outside [1, 255]", h);
     // the staged pipeline's stage slots (16 GB for the 16 384-batch bench launch) only when that pipeline is switched on
     // (tg_ns_win_tuning.staged) at the time of the query; a launch whose workspace lacks them takes the push form
-    const tg::WinLayout L = tg::win_layout(n_batches, n_seeds, fanout, n_hops);
+    const tg::WinLayout L = tg::win_layout(csc, n_batches, n_seeds, fanout, n_hops);
     *n_bytes = (int64_t)(tg::win_tuning().staged ? L.total : L.total_push);
     return TG_OK;
+}
+extern "C" int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
+                                          int64_t *n_bytes) {
+    return tg_ns_homo_workspace_bytes_for(nullptr, n_batches, n_seeds, fanout, n_hops, n_bytes);
 }
 
 // Is the window-ordered form applicable / worth it for this launch?  (Same outputs either way.)
@@ -1184,7 +1247,7 @@ int tg_ns_homo_windowed_applicable(const tg_graph *csc, int64_t n_batches, int64
     int kmax = 1;
     for (int h = 0; h < n_hops; ++h) kmax = fanout[h] > kmax ? (int)fanout[h] : kmax;
     if (kmax > TG_MAX_FANOUT) return 0;
-    const tg::WinLayout L = tg::win_layout(n_batches, n_seeds, fanout, n_hops);
+    const tg::WinLayout L = tg::win_layout(csc, n_batches, n_seeds, fanout, n_hops);
     if (L.max_items >= ((int64_t)1 << 32) || out->cap_nodes >= ((int64_t)1 << 32) || n_batches >= ((int64_t)1 << 32))
         return 0;
     if (mode == TG_NS_FORM_WINDOWED || mode == TG_NS_FORM_WINDOWED_WIDE) return 1;
@@ -1197,7 +1260,7 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
                                const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                                const tg_ns_out *out, void *ws, int64_t ws_bytes, int32_t mode, hipStream_t stream) {
     using namespace tg;
-    const WinLayout L = win_layout(n_batches, n_seeds, fanout, n_hops);
+    const WinLayout L = win_layout(csc, n_batches, n_seeds, fanout, n_hops);
     TG_REQUIRE(ws && ws_bytes >= (int64_t)L.total_push, "tg_ns_homo_batched_ws: workspace too small (%lld < %lld bytes)",
                (long long)ws_bytes, (long long)L.total_push);
     TG_REQUIRE(((uintptr_t)ws & 255) == 0, "tg_ns_homo_batched_ws: workspace must be 256-byte aligned");
@@ -1245,6 +1308,9 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     p.slot_bits = slot_bits;
     const bool repl = (cfg ? cfg->sampler : TG_SAMPLER_UNIFORM) == TG_SAMPLER_UNIFORM_REPL;
     p.vtab = reinterpret_cast<uint32_t *>(w + L.vtab);
+    p.fine_tot = reinterpret_cast<uint32_t *>(w + L.fine_tot);
+    p.fine_start = reinterpret_cast<uint32_t *>(w + L.fine_start);
+    p.fine_tile_off = reinterpret_cast<uint32_t *>(w + L.fine_tile_off);
     p.stage = reinterpret_cast<uint32_t *>(w + L.stage);
     if (narrow && !force_wide && ws_bytes >= (int64_t)L.total &&
         win_staged_applicable(p, win_tuning(), csc, n_batches, fanout, n_hops, L.stage_words))
@@ -1273,6 +1339,7 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_parts = w.stage_parts;
     t->stage_part_min_batches = w.stage_part_min_batches;
     t->stage_sort_blocks = w.stage_sort_blocks;
+    t->stage_fine = w.stage_fine;
     return TG_OK;
 }
 
@@ -1302,6 +1369,7 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_parts > 0) w.stage_parts = t->stage_parts;
     if (t->stage_part_min_batches > 0) w.stage_part_min_batches = t->stage_part_min_batches;
     if (t->stage_sort_blocks > 0) w.stage_sort_blocks = t->stage_sort_blocks;
+    if (t->stage_fine >= 0) w.stage_fine = t->stage_fine != 0;
     return TG_OK;
 }
 
@@ -1335,7 +1403,7 @@ extern "C" int tg_ns_homo_batched_form(const tg_graph *csc, int64_t n_batches, i
     if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE) return TG_OK; // the scanning kernels: neither form
     if (workspace_bytes <= 0 || !tg_ns_homo_windowed_applicable(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, mode))
         return TG_OK;
-    if ((int64_t)tg::win_layout(n_batches, n_seeds, fanout, n_hops).total_push > workspace_bytes) return TG_OK; // the launch would refuse
+    if ((int64_t)tg::win_layout(csc, n_batches, n_seeds, fanout, n_hops).total_push > workspace_bytes) return TG_OK; // the launch would refuse
     int32_t shift = 0, nb = 0;
     tg::win_window_geometry(csc, &shift, &nb);
     int slot_bits = 1;
@@ -1355,7 +1423,7 @@ extern "C" int tg_ns_homo_batched_pipeline(const tg_graph *csc, int64_t n_batche
     int32_t form = 0, n_win = 0;
     const int rc = tg_ns_homo_batched_form(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, workspace_bytes, mode, &form, &n_win);
     if (rc != TG_OK || form != TG_NS_FORM_WINDOWED) return rc;
-    const tg::WinLayout L = tg::win_layout(n_batches, n_seeds, fanout, n_hops);
+    const tg::WinLayout L = tg::win_layout(csc, n_batches, n_seeds, fanout, n_hops);
     tg::WinParams p{};
     p.n_seeds = n_seeds;
     *staged = workspace_bytes >= (int64_t)L.total &&

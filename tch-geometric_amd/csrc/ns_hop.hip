@@ -108,12 +108,7 @@ __global__ void hop_emit_kernel(const HopParams p) {
             const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[i], p.tag) : ck0;
             const uint32_t n = (uint32_t)deg;
             if (p.replace) { // sampling.rs:57-69
-                Draw d;
-                for (int s = 0; s < k; ++s) {
-                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                    spos[excl + s] = bounded32(d.half(s & 1), n);
-                    slane[excl + s] = (uint8_t)lane;
-                }
+                sample_replace_any(ck, did, n, k, spos, slane, excl, lane);
             } else if (deg <= k) { // sampling.rs:12-15
                 for (uint32_t s = 0; s < cnt; ++s) {
                     spos[excl + s] = s;
@@ -165,15 +160,15 @@ __global__ void hop_emit_bigk_kernel(const HopParams p) {
         const uint64_t did = p.ids ? (uint64_t)p.ids[i] : (uint64_t)(p.id_base + i);
         const CallKey ck = p.call_ids ? call_key(p.seed, (uint64_t)p.call_ids[i], p.tag) : ck0;
         if (p.replace) { // sampling.rs:57-69: slot s draws its own position
-            for (uint32_t s = lane; s < cnt; s += 64) pos[s] = bounded32(draw(ck, did, s >> 1, D1_REPLACE).half(s & 1), n);
+            for (uint32_t s = lane; s < cnt; s += 64) pos[s] = slot_draw(ck, did, s, D1_REPLACE, n);
         } else if (deg <= k) { // sampling.rs:12-15
             for (uint32_t s = lane; s < cnt; s += 64) pos[s] = s;
         } else {
             Draw d;
             for (int s = 0; s < k; ++s) {
                 const uint32_t m = (n - 1u) - (uint32_t)s;
-                if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
-                const uint32_t r = bounded32(d.half(s & 1), m), last = m - 1u;
+                if ((s & 3) == 0) d = draw(ck, did, (uint32_t)(s >> 2), 0u);
+                const uint32_t r = slot_draw_from(d, ck, did, (uint32_t)s, 0u, m), last = m - 1u;
                 int jr = -1, jl = -1; // latest displaced entry of r / of last
                 for (int j = lane; j < s; j += 64) {
                     const uint32_t key = keys[j];

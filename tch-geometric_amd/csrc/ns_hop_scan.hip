@@ -245,7 +245,7 @@ __global__ void hs_select_kernel(const HopScanParams p) {
             const CallKey ck = call_key(p.seed, p.call_ids ? (uint64_t)p.call_ids[v] : p.call_id, sg.tag);
             if (p.replace) { // sampling.rs:57-69
                 for (uint32_t s = lane; s < (uint32_t)k; s += 64)
-                    ranks[s] = bounded32(draw(ck, did, s >> 1, D1_REPLACE).half(s & 1), n);
+                    ranks[s] = slot_draw(ck, did, s, D1_REPLACE, n);
             } else if (n <= (uint32_t)k) { // every candidate, in order
                 for (uint32_t s = lane; s < cnt_sel; s += 64) ranks[s] = s;
             } else if (k <= 64) { // reservoir by tickets, lane s owns slot s
@@ -253,8 +253,8 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                 Draw d;
                 for (int s = 0; s < k; ++s) {
                     const uint32_t mm = (n - 1u) - (uint32_t)s;
-                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
-                    const uint32_t r = bounded32(d.half(s & 1), mm), last = mm - 1u;
+                    if ((s & 3) == 0) d = draw(ck, did, (uint32_t)(s >> 2), 0u);
+                    const uint32_t r = slot_draw_from(d, ck, did, (uint32_t)s, 0u, mm), last = mm - 1u;
                     const uint64_t mr = __ballot(lane < s && myK == r);
                     const uint64_t ml = __ballot(lane < s && myK == last);
                     const uint32_t vr = __shfl(myV, mr ? 63 - __clzll((long long)mr) : 0, 64);
@@ -271,8 +271,8 @@ __global__ void hs_select_kernel(const HopScanParams p) {
                 Draw d;
                 for (int s = 0; s < k; ++s) {
                     const uint32_t mm = (n - 1u) - (uint32_t)s;
-                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), 0u);
-                    const uint32_t r = bounded32(d.half(s & 1), mm), last = mm - 1u;
+                    if ((s & 3) == 0) d = draw(ck, did, (uint32_t)(s >> 2), 0u);
+                    const uint32_t r = slot_draw_from(d, ck, did, (uint32_t)s, 0u, mm), last = mm - 1u;
                     int jr = -1, jl = -1;
                     for (int j = lane; j < s; j += 64) {
                         const uint32_t key = keys[j];

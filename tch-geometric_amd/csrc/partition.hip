@@ -276,12 +276,7 @@ template <int KMAX> __global__ void part_sample_kernel(const PartOwnerParams p) 
         if (cnt > 0) {
             const CallKey ck = call_key(p.seed, call, TAG_NS_HOMO);
             if (p.replace) { // sampling.rs:57-69
-                Draw d;
-                for (int s = 0; s < k; ++s) {
-                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                    spos[excl + s] = bounded32(d.half(s & 1), n);
-                    slane[excl + s] = (uint8_t)lane;
-                }
+                sample_replace_any(ck, did, n, k, spos, slane, excl, lane);
             } else if (n <= (uint32_t)k) { // sampling.rs:12-15
                 for (uint32_t s = 0; s < cnt; ++s) {
                     spos[excl + s] = s;
@@ -488,12 +483,7 @@ template <int KMAX> __global__ void part_sample_sorted_kernel(const PartOwnerPar
         if (cnt > 0) {
             const CallKey ck = call_key(p.seed, call, TAG_NS_HOMO);
             if (p.replace) { // sampling.rs:57-69
-                Draw d;
-                for (int s = 0; s < k; ++s) {
-                    if ((s & 1) == 0) d = draw(ck, did, (uint32_t)(s >> 1), D1_REPLACE);
-                    spos[excl + s] = bounded32(d.half(s & 1), n);
-                    slane[excl + s] = (uint8_t)lane;
-                }
+                sample_replace_any(ck, did, n, k, spos, slane, excl, lane);
             } else if (n <= (uint32_t)k) { // sampling.rs:12-15
                 for (uint32_t s = 0; s < cnt; ++s) {
                     spos[excl + s] = s;

@@ -23,6 +23,7 @@ constexpr uint32_t D1_LITERAL = 0x4C495400u;  // "LIT"
 constexpr uint32_t D1_WEIGHTED = 0x57475400u; // "WGT"
 constexpr uint32_t D1_RESTART = 0x52535400u;  // "RST"
 constexpr uint32_t D1_CHUNK = 0x43484B00u;    // "CHK"
+constexpr uint32_t D1_FALLBACK = 0x46u;       // 'F', or-ed into d1: the 64-bit draw that replaces a rejected 32-bit word
 
 struct Draw {
     uint32_t w[4];
@@ -78,6 +79,42 @@ __device__ __forceinline__ uint32_t bounded32(uint64_t x, uint32_t range) {
     const uint64_t hi = (x >> 32) * range;
     return (uint32_t)((hi + (lo >> 32)) >> 32);
 }
+
+// ---- the bounded draw of SLOT s of a reservoir / replacement sample (philox-mode since round 4; the CPU checker's
+// orc_slot_draw) -----------------------------------------------------------------------------------------------------
+// Slot s owns ONE 32-bit word: word s & 3 of the block (id, s >> 2, d1).  It is bounded by Lemire's multiply-shift --
+// ONE 32 x 32 -> 64 multiply -- with the method's exact rejection test; a rejected word (probability < range / 2^32, so a
+// branch no wavefront usually takes) is replaced by the 64-bit multiply-shift draw of the slot's own block
+// (id, s, d1 | D1_FALLBACK).  Until round 3 a slot took half a block: five blocks and ten two-multiply draws per vertex at
+// k = 10, where three blocks and ten one-multiply draws do now -- the draws are what bounds the sampling kernels.
+__device__ __forceinline__ uint32_t bounded_word(uint32_t w, uint32_t range, bool &ok) {
+    const uint64_t m = (uint64_t)w * range;
+    const uint32_t lo = (uint32_t)m;
+    ok = true;
+    if (__builtin_expect(lo < range, 0)) ok = lo >= (0u - range) % range; // 2^32 mod range
+    return (uint32_t)(m >> 32);
+}
+__device__ __forceinline__ uint32_t slot_fallback(CallKey ck, uint64_t id, uint32_t s, uint32_t d1, uint32_t range) {
+    return bounded32(draw(ck, id, s, d1 | D1_FALLBACK).a(), range);
+}
+// word i of a block, i possibly different from lane to lane
+__device__ __forceinline__ uint32_t draw_word(const Draw &d, uint32_t i) {
+    const uint32_t lo = (i & 1u) ? d.w[1] : d.w[0], hi = (i & 1u) ? d.w[3] : d.w[2];
+    return (i & 2u) ? hi : lo;
+}
+// slot s from the block `d` = draw(ck, id, s >> 2, d1) the caller holds
+__device__ __forceinline__ uint32_t slot_draw_from(const Draw &d, CallKey ck, uint64_t id, uint32_t s, uint32_t d1,
+                                                   uint32_t range) {
+    bool ok;
+    uint32_t r = bounded_word(draw_word(d, s), range, ok);
+    if (__builtin_expect(!ok, 0)) r = slot_fallback(ck, id, s, d1, range);
+    return r;
+}
+// slot s, block computed here (a lane per slot)
+__device__ __forceinline__ uint32_t slot_draw(CallKey ck, uint64_t id, uint32_t s, uint32_t d1, uint32_t range) {
+    return slot_draw_from(draw(ck, id, s >> 2, d1), ck, id, s, d1, range);
+}
+
 __device__ __forceinline__ float u32_to_f32_01(uint32_t w) { return __uint_as_float(0x3F800000u | (w >> 9)) - 1.0f; }
 __device__ __forceinline__ double u64_to_f64_01(uint64_t x) {
     return __longlong_as_double((long long)(0x3FF0000000000000ull | (x >> 12))) - 1.0;

@@ -31,12 +31,14 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
            "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol",
            "tg_debug_bounds_set_flag", "tg_part_sample_workspace_bytes", "tg_part_sample_ws",
-           "tg_part_sample_order_thresholds", "tg_ns_homo_batched_pipeline"]
+           "tg_part_sample_order_thresholds", "tg_ns_homo_batched_pipeline", "tg_graph_max_degree",
+           "tg_ns_homo_workspace_bytes_for"]
 
 
 class TgGraph(C.Structure):
     _fields_ = [("ptrs", C.c_void_p), ("indices", C.c_void_p), ("weights", C.c_void_p), ("timestamps", C.c_void_p),
-                ("n_major", C.c_int64), ("n_edges", C.c_int64), ("indices32", C.c_void_p), ("ptrs32", C.c_void_p)]
+                ("n_major", C.c_int64), ("n_edges", C.c_int64), ("indices32", C.c_void_p), ("ptrs32", C.c_void_p),
+                ("max_degree", C.c_int64)]
 
 
 class TgRng(C.Structure):
@@ -100,7 +102,16 @@ def stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def graph_view(ptrs, indices, weights=None, timestamps=None, indices32=None, ptrs32=None):
+def graph_max_degree(g, device):
+    """The longest column (row) of a graph view, computed on the device (tg_graph_max_degree); one read-back."""
+    out = torch.zeros(1, dtype=torch.int64, device=device)
+    check(lib.tg_graph_max_degree(C.byref(g), ptr(out), stream_ptr(device)))
+    return int(out.item())
+
+
+def graph_view(ptrs, indices, weights=None, timestamps=None, indices32=None, ptrs32=None, max_degree=None):
+    """max_degree: None = unknown (0 in the struct: the window-ordered launch then assumes n_edges), "auto" = computed on the
+    device here (one read-back, once per view), or the caller's number."""
     g = TgGraph()
     g.ptrs, g.indices = ptrs.data_ptr(), indices.data_ptr()
     g.weights = weights.data_ptr() if weights is not None else None
@@ -109,6 +120,11 @@ def graph_view(ptrs, indices, weights=None, timestamps=None, indices32=None, ptr
     g.indices32 = indices32.data_ptr() if indices32 is not None else None
     g.ptrs32 = ptrs32.data_ptr() if ptrs32 is not None else None
     g._keep = (ptrs, indices, weights, timestamps, indices32, ptrs32)  # the struct only borrows the device memory
+    g.max_degree = 0
+    if max_degree == "auto":
+        g.max_degree = graph_max_degree(g, ptrs.device) if ptrs.is_cuda else int((ptrs[1:] - ptrs[:-1]).max()) if ptrs.numel() > 1 else 0
+    elif max_degree is not None:
+        g.max_degree = int(max_degree)
     return g
 
 
@@ -151,16 +167,16 @@ class NsBatchedOut:
         return self.samples[b, :ns], self.rows[b, :ne], self.cols[b, :ne], self.edge_index[b, :ne], lo
 
 
-def ns_homo_workspace(n_batches, n_seeds, fanout, device, staged=None):
+def ns_homo_workspace(n_batches, n_seeds, fanout, device, staged=None, graph=None):
     """Workspace of tg_ns_homo_batched_ws (the window-ordered gather of many-batch launches), as an int64 tensor.
     staged: True = sized for the staged pipeline too (its stage slots), False = push pipeline only, None = as the current
-    tuning says."""
+    tuning says.  graph: size the stage slots for this graph's bit widths (else the larger, graph-free size)."""
     nbytes = C.c_int64(0)
     fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
     prev = ns_win_tuning_set(staged=int(staged)) if staged is not None else None
     try:
-        check(lib.tg_ns_homo_workspace_bytes(C.c_int64(n_batches), C.c_int64(n_seeds), fan, C.c_int32(len(fanout)),
-                                             C.byref(nbytes)))
+        check(lib.tg_ns_homo_workspace_bytes_for(C.byref(graph) if graph is not None else None, C.c_int64(n_batches),
+                                                 C.c_int64(n_seeds), fan, C.c_int32(len(fanout)), C.byref(nbytes)))
     finally:
         if prev is not None:
             ns_win_tuning_set(staged=prev["staged"])
@@ -231,7 +247,7 @@ class TgNsWinTuning(C.Structure):
                 ("fold_hist", C.c_int32), ("emit_blocks", C.c_int32), ("staged", C.c_int32),
                 ("stage_round_chunks", C.c_int32), ("stage_gather_threads", C.c_int32), ("stage_gather_blocks", C.c_int32),
                 ("stage_emit_threads", C.c_int32), ("stage_parts", C.c_int32),
-                ("stage_part_min_batches", C.c_int32), ("stage_sort_blocks", C.c_int32)]
+                ("stage_part_min_batches", C.c_int32), ("stage_sort_blocks", C.c_int32), ("stage_fine", C.c_int32)]
 
 
 def ns_win_tuning():
@@ -243,7 +259,7 @@ def ns_win_tuning():
 def ns_win_tuning_set(**kw):
     """Process-wide tuning of the window-ordered launch (outputs never depend on it); -> the previous values."""
     before = ns_win_tuning()
-    t = TgNsWinTuning(0, 0, 0, 0, -1, -1, -1, 0, -1, 0, 0, 0, 0, 0, 0, 0)
+    t = TgNsWinTuning(0, 0, 0, 0, -1, -1, -1, 0, -1, 0, 0, 0, 0, 0, 0, 0, -1)
     for k, v in kw.items():
         assert k in before, k
         setattr(t, k, int(v))

@@ -146,3 +146,95 @@ def test_tempo_random_walk_step_law(cabi, karate):
         assert_same_law(dev_t[:, step] + 1, ref_t[:, step] + 1, "tempo walk timestamp %d" % step, n_bins=42)
     assert_same_law((dev_w[:, 1] + 1) * (n + 1) + dev_w[:, 2] + 1, (ref_w[:, 1] + 1) * (n + 1) + ref_w[:, 2] + 1,
                     "tempo walk steps (1,2)", n_bins=(n + 1) ** 2)
+
+
+# ---------------------------------------------------------------- round 4: operators whose philox-mode is not the literal
+# loop -- the device against the oracle's ref-mode (graphs and outcome codes shared with the CPU half of the check)
+@pytest.fixture(scope="module")
+def tg():
+    import tch_geometric
+    return tch_geometric
+
+
+def test_hgt_sample_from_law(tg):
+    """`BudgetDict::sample_from` (hgt_sampling.rs:104-135: weighted reservoir over score^2; blocked f64 sum on the device)
+    through the operator surface, one call per outcome."""
+    from test_oracle_law_philox_vs_ref import hgt_law_graph, hgt_outcomes
+    n_calls = 8000
+    nt, et, P, I = hgt_law_graph()
+    Pc = {k: _t(v) for k, v in P.items()}
+    Ic = {k: _t(v) for k, v in I.items()}
+    inputs = {"a": torch.zeros(1, dtype=torch.int64, device=DEV)}
+    tg.seed(77)
+    dev = np.empty(n_calls, dtype=np.int64)
+    got = []
+    for c in range(n_calls):                                                # every call draws with the next call id
+        s, _, _, _, _ = tg.hgt_sampling(nt, et, Pc, Ic, None, inputs, None, {"a": [2], "b": [2]}, 1)
+        got.append(s["b"])
+    got = torch.stack(got).cpu().numpy()
+    dev = got[:, 0] * 6 + got[:, 1]
+    parent = orc.rng_ref()
+    ref = hgt_outcomes(lambda c: orc.rng_ref_child(parent), n_calls)
+    assert_same_law(dev, ref, "hgt sample_from ordered pair", n_bins=36)
+    assert_same_law(dev // 6, ref // 6, "hgt sample_from slot 0", n_bins=6)
+    assert_same_law(dev % 6, ref % 6, "hgt sample_from slot 1", n_bins=6)
+    flat = hgt_outcomes(lambda c: orc.rng_ref_child(parent), n_calls, duplicates=False)
+    assert_different_law(dev, flat, "hgt scores 9:4:1:1:1:1 vs equal scores", n_bins=36)
+
+
+def test_biased_walk_first_step_law(cabi):
+    """biased_tempo_random_walk (random_walk.rs:258-271): one-slot weighted reservoir in f32 over the bias weights"""
+    from test_oracle_law_philox_vs_ref import biased_law_graph
+    ptrs, idx, node_ts, edge_ts = biased_law_graph()
+    g = cabi.graph_view(_t(ptrs), _t(idx))
+    start, start_ts = np.zeros(N, dtype=np.int64), np.full(N, 5, dtype=np.int64)
+    first = {}
+    for bias in ("uniform", "linear", "exponential"):
+        w, _, status = cabi.biased_tempo_random_walk(g, _t(node_ts), _t(edge_ts), _t(start), _t(start_ts), 2, bias, True, 1,
+                                                     61, 3, max_degree=12)
+        assert int(status.item()) == 0
+        ref, _ = orc.biased_tempo_random_walk(ptrs, idx, node_ts, edge_ts, start, start_ts, 2, bias, True, 1,
+                                              orc.rng_ref_child(orc.rng_ref()))
+        first[bias] = w[:, 1].cpu().numpy()
+        assert_same_law(first[bias], ref[:, 1], "biased walk (%s) step 1" % bias, n_bins=13)
+    assert_different_law(first["uniform"], first["linear"], "uniform vs linear bias", n_bins=13)
+    assert_different_law(first["uniform"], first["exponential"], "uniform vs exponential bias", n_bins=13)
+
+
+def test_negative_sampling_law(tg, karate):
+    """negative_sample_neighbors_homogenous (negative_sampling.rs:31-45): accepted nodes of one input vertex"""
+    n, _, _, rptrs, ridx = karate
+    inputs = np.zeros(N // 4, dtype=np.int64)
+    tg.seed(88)
+    s, r, c, _ = tg.negative_sample_neighbors_homogenous(_t(rptrs), _t(ridx), (n, n), _t(inputs), 4, 8)
+    dev = s[c].cpu().numpy()
+    rs, rr, rc, _ = orc.neg_homo(rptrs, ridx, (n, n), inputs, 4, 8, orc.rng_ref_child(orc.rng_ref()))
+    ref = rs[rc]
+    assert len(dev) > 0.95 * N and len(ref) > 0.95 * N
+    assert_same_law(dev, ref, "negatives of vertex 0", n_bins=n)
+    inputs[:] = 33
+    os_, or_, oc, _ = orc.neg_homo(rptrs, ridx, (n, n), inputs, 4, 8, orc.rng_ref_child(orc.rng_ref()))
+    assert_different_law(dev, os_[oc], "negatives of vertex 0 vs vertex 33", n_bins=n)
+
+
+def test_budget_sampling_law(tg, karate):
+    """budget_sampling's `Budget::sample` (budget_sampling.rs:137-151): reservoir over the node's candidate list"""
+    n, ptrs, idx, _, _ = karate
+    nt, et = ["a"], [("a", "r", "a")]
+    m = N // 2
+    inputs = np.zeros(m, dtype=np.int64)
+    tg.seed(99)
+    _, _, _, cols, eidx = tg.budget_sampling(nt, et, {"a__r__a": _t(ptrs)}, {"a__r__a": _t(idx)}, None, {"a": _t(inputs)},
+                                             None, {"a": [5]}, 1, None, False, False)
+    dev = eidx["a__r__a"].cpu().numpy()
+    assert len(dev) == m * 5 and np.array_equal(cols["a__r__a"].cpu().numpy(), np.repeat(np.arange(m), 5))
+    dev = dev.reshape(m, 5)
+    o = orc.budget(nt, et, {"a__r__a": ptrs}, {"a__r__a": idx}, None, {"a": inputs}, None, {"a": [5]}, 1,
+                   orc.rng_ref_child(orc.rng_ref()))
+    ref = o[4]["a__r__a"].reshape(m, 5)
+    for s in range(5):
+        assert_same_law(dev[:, s], ref[:, s], "budget slot %d" % s, n_bins=16)
+    assert_same_law(dev[:, 0] * 16 + dev[:, 3], ref[:, 0] * 16 + ref[:, 3], "budget slots (0,3)", n_bins=256)
+    o3 = orc.budget(nt, et, {"a__r__a": ptrs}, {"a__r__a": idx}, None, {"a": inputs}, None, {"a": [3]}, 1,
+                    orc.rng_ref_child(orc.rng_ref()))
+    assert_different_law(dev[:, 0], o3[4]["a__r__a"].reshape(m, 3)[:, 0], "k = 5 vs k = 3, slot 0", n_bins=16)

@@ -231,3 +231,96 @@ def test_stage_times(cabi):
         cabi.ns_win_tuning_set(**before)
     names = [s for s, _ in st]
     assert names[0] == "first.h0" and names[-1] == "emit.h1"                                         # the staged form
+
+
+# ---------------------------------------------------------------- round 4: packed stage slots carrying the positions
+@pytest.mark.parametrize("fan,hint", [([4, 20], None), ([3, 30], None), ([15, 10], "auto"), ([15, 10], 1 << 30),
+                                      ([6, 16], "auto"), ([2, 3, 4], "auto")])
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_staged_slot_formats(cabi, fan, hint, sampler):
+    """one-chunk and two-chunk slots (fan-outs 17..30 and wide bit fields take two), with and without the max-degree hint:
+    the same outputs as the fused kernel and the oracle"""
+    dev = torch.device(DEV)
+    n = 1 << 12
+    row, col = cabi.rmat_edges(12, n * 16, 0x5EED0000 + 12, dev)
+    ptrs, idx, _ = cabi.coo_to_csx(row, col, n, n, True)
+    g = cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32), max_degree=hint)
+    if hint == "auto":
+        assert g.max_degree == int((ptrs[1:] - ptrs[:-1]).max())
+    nb, B = 24, 48
+    seeds = cabi.seed_batches(0xBA7C4, 3, nb, B, n, dev)
+    seeds[:, 0] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))
+    before = cabi.ns_win_tuning_set(staged=1, window_bytes=2048)
+    try:
+        for parts in (1, 3):
+            cabi.ns_win_tuning_set(stage_parts=parts, stage_part_min_batches=4)
+            a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+            ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True, graph=g)
+            assert cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler)
+            cabi.ns_homo_batched(g, seeds, fan, 9, 40, a, ws=ws, form=WINDOWED, sampler=sampler)
+            cabi.ns_homo_batched(g, seeds, fan, 9, 40, b, form=FUSED, sampler=sampler)
+            torch.cuda.synchronize()
+            assert_equal_on_device(a, b)
+            assert_oracle(cabi, a, ptrs, idx, seeds, fan, 9, 40, (0, nb - 1), sampler=sampler)
+    finally:
+        cabi.ns_win_tuning_set(**before)
+
+
+def test_workspace_for_a_graph_is_smaller_when_the_pairs_fit_one_chunk(cabi):
+    n, ptrs, idx, g = _rmat(cabi, 12)
+    dev = torch.device(DEV)
+    nb, B, fan = 64, 64, [15, 10]
+    free_of_graph = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True)
+    for_graph = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True, graph=g)       # 12 + 16 bits per pair: one chunk
+    push_only = cabi.ns_homo_workspace(nb, B, fan, dev, staged=False)
+    assert push_only.numel() < for_graph.numel() < free_of_graph.numel()
+    # one 64-byte chunk per frontier slot of the widest ordered hop (nb * B * 15 slots) instead of two
+    assert abs((free_of_graph.numel() - for_graph.numel()) * 8 - nb * B * 15 * 64) <= 512
+
+
+def test_slot_draw_fallback_runs_on_the_device(cabi):
+    """A rejected 32-bit word (Lemire's test; probability (2^32 mod range) / 2^32) is replaced by the slot's 64-bit fallback
+    draw.  A hub column of 3 000 001 edges (2^32 mod 3 000 000 = 1 967 296) makes ~1 draw in 2 000 fall back: the fused
+    kernel, the window-ordered forms and the flat hop must take exactly the oracle's fallbacks."""
+    dev = torch.device(DEV)
+    n, hub = 512, 3_000_001
+    rs = np.random.default_rng(4)
+    deg = np.full(n, 4, dtype=np.int64)
+    deg[0] = hub
+    ptrs_h = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=ptrs_h[1:])
+    idx_h = rs.integers(0, n, int(ptrs_h[-1]))
+    idx_h[:hub:7] = 0                                                # the hub is its own frequent neighbour: hop 2 draws from it too
+    ptrs, idx = torch.from_numpy(ptrs_h).to(dev), torch.from_numpy(idx_h).to(dev)
+    g = cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32), max_degree="auto")
+    assert g.max_degree == hub
+    nb, B, fan = 16, 256, [15, 10]
+    seeds = torch.zeros((nb, B), dtype=torch.int64, device=dev)    # every seed is the hub
+    for sampler in (0, 1):
+        f = _poisoned(cabi, nb, B, fan)
+        cabi.ns_homo_batched(g, seeds, fan, 5, 100, f, form=FUSED, sampler=sampler)
+        torch.cuda.synchronize()
+        orc.slot_fallback_count(reset=True)
+        assert_oracle(cabi, f, ptrs, idx, seeds, fan, 5, 100, range(4), sampler=sampler)
+        assert orc.slot_fallback_count() >= 5, "the case does not reach the fallback"
+        for staged in (0, 1):
+            before = cabi.ns_win_tuning_set(staged=staged)
+            try:
+                w = _poisoned(cabi, nb, B, fan)
+                ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True, graph=g)
+                cabi.ns_homo_batched(g, seeds, fan, 5, 100, w, ws=ws, form=WINDOWED, sampler=sampler)
+                torch.cuda.synchronize()
+                assert bool(cabi.ns_homo_batched_staged(g, w, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler)) == bool(staged)
+                assert_equal_on_device(w, f)
+            finally:
+                cabi.ns_win_tuning_set(**before)
+    # the flat hop (lane-per-slot chains, any fan-out) on the same column
+    verts = torch.zeros(2048, dtype=torch.int64, device=dev)
+    for k, sampler in ((15, 0), (200, 0), (15, 1)):
+        cnt, offsets, nbr, ep, _ = cabi.ns_hop(g, verts, k, 5, call_id=7, sampler=sampler)
+        torch.cuda.synchronize()
+        orc.slot_fallback_count(reset=True)
+        o = orc.ns_homo(ptrs_h, idx_h, np.zeros(2048, dtype=np.int64), [k], orc.rng_philox(5, 7), sampler=sampler)
+        assert orc.slot_fallback_count() >= 3
+        m = int(offsets[-1])
+        assert m == len(o[3]) and np.array_equal(ep[:m].cpu().numpy(), o[3]) and np.array_equal(nbr[:m].cpu().numpy(), o[0][2048:])

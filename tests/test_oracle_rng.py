@@ -91,3 +91,59 @@ def test_named_draw_is_two_level_philox():
     ck = orc.philox_raw([call & 0xffffffff, call >> 32, tag, 0x74636867], [seed & 0xffffffff, seed >> 32])
     exp = orc.philox_raw([d0, d1, id_ & 0xffffffff, id_ >> 32], ck[:2])
     assert orc.philox_named_draw(seed, call, tag, id_, d0, d1) == exp
+
+
+def test_bounded_word_is_lemires_exact_method():
+    """philox-mode's slot draw (round 4): one 32-bit word, multiply-shift, exact rejection.  The accepted words of a range
+    map onto every value equally often: counted in closed form (accepted words with value v = words w with
+    (w * range) >> 32 == v and low half >= 2^32 mod range), and spot-checked against the C function."""
+    for rng_range in [1, 2, 3, 5, 6, 7, 10, 1000, 65537, 370000, 2**20 + 3, 2**31 - 1, 2**31 + 5, 2**32 - 1]:
+        t = (2**32) % rng_range
+        per_value = (2**32 - t) // rng_range            # what Lemire's proof promises: every value equally often
+        assert (2**32 - t) % rng_range == 0
+        # count the accepted words of three values exactly: words w with floor(w * range / 2^32) == v are
+        # ceil(v * 2^32 / range) .. ceil((v + 1) * 2^32 / range) - 1; the rejected ones are the first ones with low half < t
+        for v in {0, rng_range // 2, rng_range - 1}:
+            w_lo = -((-v * 2**32) // rng_range)
+            w_hi = -((-(v + 1) * 2**32) // rng_range)
+            rejected = 0
+            w = w_lo
+            while w < w_hi and ((w * rng_range) & 0xFFFFFFFF) < t:   # low halves rise by `range` per word: only a prefix can be < t
+                rejected += 1
+                w += 1
+            assert (w_hi - w_lo) - rejected == per_value
+            # the C function agrees on the boundary words
+            for ww in {w_lo, min(w_lo + rejected, w_hi - 1), w_hi - 1}:
+                val, ok = orc.bounded_word(ww, rng_range)
+                assert val == (ww * rng_range) >> 32 == v
+                assert ok == (((ww * rng_range) & 0xFFFFFFFF) >= t)
+    assert orc.bounded_word(0, 3) == (0, False)          # 2^32 mod 3 = 1: the word 0 is the one rejected word of value 0
+    assert orc.bounded_word(1, 3) == (0, True)
+
+
+def test_slot_draw_words_blocks_and_fallback():
+    """Slot s takes word s & 3 of block s >> 2; a rejected word is replaced by the 64-bit draw of block (s, d1 | 'F')."""
+    seed, call, tag, d1 = 7, 3, orc.TAG_NS_HOMO, 0
+    fell = 0
+    for id_ in range(40):
+        for s in range(12):
+            for rng_range in (9, 370001, 2**31 + 12345, 2**32 - 5):
+                r = orc.rng_philox(seed, call)
+                got, fb = orc.slot_draw(r, tag, id_, d1, s, rng_range)
+                w = orc.philox_named_draw(seed, call, tag, id_, s >> 2, d1)[s & 3]
+                m = w * rng_range
+                accept = (m & 0xFFFFFFFF) >= (2**32) % rng_range
+                assert fb == (not accept)
+                if accept:
+                    assert got == m >> 32
+                else:
+                    f = orc.philox_named_draw(seed, call, tag, id_, s, d1 | 0x46)
+                    assert got == ((f[0] | (f[1] << 32)) * rng_range) >> 64
+                    fell += 1
+                assert 0 <= got < rng_range
+    assert fell > 100        # the two large ranges reject about half / nearly all of their words
+    # ranges of 2^32 and more never look at the word
+    r = orc.rng_philox(seed, call)
+    got, fb = orc.slot_draw(r, tag, 5, d1, 2, 2**40 + 7)
+    f = orc.philox_named_draw(seed, call, tag, 5, 2, d1 | 0x46)
+    assert fb and got == ((f[0] | (f[1] << 32)) * (2**40 + 7)) >> 64

@@ -18,12 +18,12 @@ G, B, fan, scale = int(os.environ.get("G", 16384)), 1024, [15, 10], 24
 ROUNDS = int(os.environ.get("ROUNDS", 3))
 n = 1 << scale
 out = _cabi.NsBatchedOut(G, B, fan, dev)
-ws = _cabi.ns_homo_workspace(G, B, fan, dev, staged=True)   # sized for both pipelines
 out2 = _cabi.NsBatchedOut(G, B, fan, dev) if os.environ.get("SOL", "1") == "1" else None
 row, col = _cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
 ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, True)
 del row, col
-g = _cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32))
+g = _cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32), max_degree="auto")
+ws = _cabi.ns_homo_workspace(G, B, fan, dev, staged=True, graph=g)   # sized for both pipelines
 seeds = _cabi.seed_batches(0xBA7C4, 0, G, B, n, dev)
 
 variants = [("default", {})]
@@ -53,7 +53,7 @@ edges = int(out.counts[:, 1].sum())
 slots = int(out.layer_offsets[:, len(fan) - 1, 0].sum())
 alg = 24 * slots + 40 * edges + 16 * B * G
 print(json.dumps({"batches": G, "sampled_edges": edges, "frontier_slots": slots, "algorithmic_GB": alg / 1e9,
-                  "tuning": base}), flush=True)
+                  "max_degree": g.max_degree, "workspace_GB": ws.numel() * 8 / 1e9, "tuning": base}), flush=True)
 res = {}
 for rnd in range(ROUNDS):
     for name, kv in variants:

@@ -13,7 +13,8 @@ from tch_geometric import _cabi  # noqa: E402
 dev = torch.device("cuda:0")
 big = torch.arange(1 << 28, dtype=torch.int64, device=dev)
 res = {}
-for log2_bytes in (18, 20, 21, 22, 23, 24, 26, 27, 28, 30, 31):
+sizes = [int(x) for x in sys.argv[1:]] or [18, 20, 21, 22, 23, 24, 26, 27, 28, 30, 31]   # log2 of the table's bytes
+for log2_bytes in sizes:
     table = big[:1 << (log2_bytes - 3)]
     n_threads, per_thread = 256 * 16 * 64, 256
     _cabi.probe_random_gather(table, n_threads, per_thread)
@@ -27,5 +28,5 @@ for log2_bytes in (18, 20, 21, 22, 23, 24, 26, 27, 28, 30, 31):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     g = n_threads * per_thread
-    res["table_%d_KiB" % (1 << (log2_bytes - 10))] = {"gathers": g, "ms": ms, "Ggathers_per_s": g / ms / 1e6}
+    res["table_%g_KiB" % ((1 << log2_bytes) / 1024)] = {"gathers": g, "ms": ms, "Ggathers_per_s": g / ms / 1e6}
 print(json.dumps(res, indent=1))
