@@ -197,6 +197,12 @@ typedef struct {
                                        of the first kernel (default 768, at most 1024) */
     int32_t stage_fine;             /* staged form: second sort level (tiles of the coarse-sorted items ordered by vertex in LDS,
                                        so that a gather workgroup's slice lies in a few columns; default 1; < 0 in _set keeps) */
+    int32_t stage_concurrent;       /* staged form, two hops, several parts: the parts' whole chains alternate between the caller's
+                                       stream and the side stream (default 0; < 0 in _set keeps) */
+    int32_t stage_split;            /* staged form: rows / cols / edge_index of an ordered hop are written by a pass of their own on
+                                       the side stream, beside the hop's sort and gather; the emit pass writes `samples` only
+                                       (< 0 in _set keeps) */
+    int32_t stage_split_round_chunks; /* ... whose tiles hold this many 64-slot chunks (default 4; 0 in _set keeps) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

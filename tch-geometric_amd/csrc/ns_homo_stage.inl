@@ -86,9 +86,9 @@ __host__ __device__ inline size_t win_stage_tables_bytes(int n_buckets, int n_wi
 // over in LDS (row r of `hist`): the counting sort needs no pass of its own over the items to count them (hop 0 is bound
 // by its random line requests; the binary search per new item hides beneath them).
 template <int KMAX, bool REPLACE>
-__global__ void win_stage_first_kernel(const WinParams p, const int k0) {
+__global__ void __launch_bounds__(WIN_EMIT_MAX_THREADS) win_stage_first_kernel(const WinParams p, const int k0) {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + win_emit_lds_bytes(p.kmax, blockDim.x >> 6));
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(smem + win_emit_lds_bytes(p.kmax, blockDim.x >> 6, WIN_STAGE_FIRST_RC));
     uint32_t *lvtab = lhist + p.n_buckets;
     for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) lhist[i] = 0;
     for (int i = threadIdx.x; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
@@ -98,13 +98,26 @@ __global__ void win_stage_first_kernel(const WinParams p, const int k0) {
         const CallKey ck = call_key(p.seed, p.call_id + (uint64_t)b, p.tag);
         if (threadIdx.x == 0) p.call_keys[b] = ck;
         __syncthreads();
-        const WinState st = win_emit_hop<WinItemN, KMAX, REPLACE, true, false, true>(p, smem, b, 0, k0,
-                                                                                    WinState{0, p.n_seeds, 0, 0}, ck, lhist);
+        const WinState st = win_emit_hop<WinItemN, KMAX, REPLACE, true, false, true, true, WIN_STAGE_FIRST_RC>(
+            p, smem, b, 0, k0, WinState{0, p.n_seeds, 0, 0}, ck, lhist);
         win_store_state(p, b, 0, st);
         __syncthreads(); // the LDS staging of this batch is done before the next batch reuses it
     }
     uint32_t *row = p.hist + (size_t)blockIdx.x * p.n_buckets;
     for (int i = threadIdx.x; i < p.n_buckets; i += blockDim.x) row[i] = lhist[i];
+}
+
+// ---------------------------------------------------------------- S(h): the three streams that need no gather, on the side stream
+// rows / cols / edge_index of an ordered hop depend on the frontier's column bounds and draws only, not on the gathered
+// neighbours: this pass (the push form's emit pass without its items; workgroup per batch) writes them BESIDE the hop's
+// sort and gather -- those hang on LDS / L2 latency and leave the HBM write path idle -- and the emit pass behind the
+// gather is left with `samples` alone (tg_ns_win_tuning.stage_split).  It reads the per-batch state and writes none.
+template <int KMAX, bool REPLACE>
+__global__ void __launch_bounds__(WIN_EMIT_MAX_THREADS) win_stage_side_kernel(const WinParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t b = p.b0 + blockIdx.x;
+    (void)win_emit_hop<WinItemN, KMAX, REPLACE, false, false, false, false, WIN_STAGE_SIDE_RC>(p, smem, b, p.hop, p.k, p.state[b],
+                                                                                             p.call_keys[b]);
 }
 
 // ---------------------------------------------------------------- sort, level 1: scatter by coarse bucket (rows = first-kernel workgroups)
@@ -439,15 +452,18 @@ constexpr int WIN_STAGE_ROUND_CHUNKS_MAX = 16;
 
 // LDS of E: chunk offsets | tile [round chunks * 64][W + 1] u32 | per wave: neighbours [64*k] u32, edge pointers [64*k] u32,
 // lanes [64*k] u8
-__host__ __device__ inline size_t win_stage_emit_wave_bytes(int k) {
-    return (size_t)2 * 64 * k * sizeof(uint32_t) + (((size_t)64 * k + 15) & ~(size_t)15);
+// (split: the neighbours alone)
+__host__ __device__ inline size_t win_stage_emit_wave_bytes(int k, bool split) {
+    return split ? (size_t)64 * k * sizeof(uint32_t)
+                 : (size_t)2 * 64 * k * sizeof(uint32_t) + (((size_t)64 * k + 15) & ~(size_t)15);
 }
-__host__ __device__ inline size_t win_stage_emit_lds_bytes(int W, int k, int n_waves, int round_chunks) {
+__host__ __device__ inline size_t win_stage_emit_lds_bytes(int W, int k, int n_waves, int round_chunks, bool split) {
     return (((size_t)(round_chunks + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) +
-           (size_t)round_chunks * 64 * (W + 1) * sizeof(uint32_t) + (size_t)n_waves * win_stage_emit_wave_bytes(k);
+           (size_t)round_chunks * 64 * (W + 1) * sizeof(uint32_t) + (size_t)n_waves * win_stage_emit_wave_bytes(k, split);
 }
 
-template <int W, int KMAX, bool NEXT>
+// SPLIT: rows / cols / edge_index were written by the side pass; only `samples` (and the next hop's items) leave here.
+template <int W, int KMAX, bool NEXT, bool SPLIT>
 __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const StageBits sb, unsigned char *smem,
                                                      const int64_t b, const int round_chunks) {
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
@@ -458,7 +474,7 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
     const size_t off_bytes = (((size_t)(round_chunks + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem + off_bytes);
     unsigned char *wbase = smem + off_bytes + (size_t)round_chunks * 64 * (W + 1) * sizeof(uint32_t) +
-                           (size_t)wave * win_stage_emit_wave_bytes(k);
+                           (size_t)wave * win_stage_emit_wave_bytes(k, SPLIT);
     uint32_t *sval = reinterpret_cast<uint32_t *>(wbase);
     uint32_t *sptr = sval + (size_t)64 * k;
     uint8_t *slane = reinterpret_cast<uint8_t *>(sptr + (size_t)64 * k);
@@ -540,8 +556,10 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
                         const uint32_t ps = br.pop(sb.bp);
                         if ((uint32_t)s < cnt) {
                             sval[excl + s] = v;
-                            sptr[excl + s] = e0 + ps; // the CSC edge pointer (narrow form: < 2^32)
-                            slane[excl + s] = (uint8_t)lane;
+                            if (!SPLIT) {
+                                sptr[excl + s] = e0 + ps; // the CSC edge pointer (narrow form: < 2^32)
+                                slane[excl + s] = (uint8_t)lane;
+                            }
                         }
                     }
                 }
@@ -553,7 +571,7 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
             const uint32_t head = (uint32_t)(((uintptr_t)(rows + ea) >> 3) & 1);
             const uint32_t head_s = (uint32_t)(((uintptr_t)(samples + n_seeds + ea) >> 3) & 1);
             if (lane == 0 && total > 0) {
-                if (head) {
+                if (head && !SPLIT) {
                     __builtin_nontemporal_store(n_seeds + ea, &rows[ea]);
                     __builtin_nontemporal_store(i0 + (int64_t)slane[0], &cols[ea]);
                     __builtin_nontemporal_store((int64_t)sptr[0], &eidx[ea]);
@@ -568,6 +586,7 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
                 } else
                     __builtin_nontemporal_store((int64_t)sval[q], &samples[n_seeds + e]);
             }
+            if (!SPLIT)
             for (uint32_t q = head + 2u * lane; q < total; q += 128) { // :217
                 const int64_t e = ea + q;
                 if (q + 1 < total) {
@@ -576,6 +595,7 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
                 } else
                     __builtin_nontemporal_store(n_seeds + e, &rows[e]);
             }
+            if (!SPLIT)
             for (uint32_t q = head + 2u * lane; q < total; q += 128) {
                 const int64_t e = ea + q;
                 if (q + 1 < total) {
@@ -584,6 +604,7 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
                 } else
                     __builtin_nontemporal_store(i0 + (int64_t)slane[q], &cols[e]);
             }
+            if (!SPLIT)
             for (uint32_t q = head + 2u * lane; q < total; q += 128) {
                 const int64_t e = ea + q;
                 if (q + 1 < total) {
@@ -607,8 +628,8 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
     win_store_state(p, b, hop, WinState{end, n_seeds + ne, ne, begin}); // :221-222
 }
 
-template <int W, int KMAX, bool NEXT>
+template <int W, int KMAX, bool NEXT, bool SPLIT>
 __global__ void win_stage_emit_kernel(const WinParams p, const StageBits sb, const int round_chunks) {
     extern __shared__ __align__(16) unsigned char smem[];
-    win_stage_emit_batch<W, KMAX, NEXT>(p, sb, smem, p.b0 + blockIdx.x, round_chunks);
+    win_stage_emit_batch<W, KMAX, NEXT, SPLIT>(p, sb, smem, p.b0 + blockIdx.x, round_chunks);
 }

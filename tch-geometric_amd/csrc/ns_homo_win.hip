@@ -142,7 +142,12 @@ __global__ void win_init_kernel(const WinParams p, int64_t n_batches) {
 // K1 works through a batch's frontier in rounds of WIN_ROUND_CHUNKS 64-vertex chunks whose column bounds stay in LDS
 // between the counting pass and the emitting pass (one `ptrs` look-up per frontier vertex and hop).
 constexpr int WIN_ROUND_CHUNKS = 32;
-constexpr int WIN_ROUND_SLOTS = WIN_ROUND_CHUNKS * 64;
+constexpr int WIN_EMIT_MAX_THREADS = 512; // launch bound of the STAGED form's first and side kernels: without one the compiler
+// budgets registers for 1 024-thread workgroups (128 VGPRs) and the ticket chain spills (50-200 B per lane).  The push form's
+// emit kernels keep the 128-VGPR budget and their spills on purpose: bound to 512 threads they take 150-176 VGPRs, two
+// wavefronts per SIMD instead of four, and the three output streams need the wavefronts (first hops 3.7 -> 4.7 ms, measured)
+constexpr int WIN_STAGE_FIRST_RC = 16; // staged form: rounds of the first kernel (hop 0: usually <= 1 024 seeds) ...
+constexpr int WIN_STAGE_SIDE_RC = 8;   // ... and of the side pass, which shares the CUs with the gather kernel
 
 // K1's LDS: chunk offsets | fbase | column starts [slots] i64 | degrees [slots] u32 | per wave: staged positions
 // [64*k] u32, staged lanes [64*k] u8
@@ -150,12 +155,14 @@ __host__ __device__ inline size_t win_emit_wave_lds_bytes(int kmax) { // ... + t
     return (size_t)64 * kmax * sizeof(uint32_t) + (((size_t)64 * kmax + 15) & ~(size_t)15) + 64;
 }
 
-__host__ __device__ inline size_t win_emit_head_bytes() {
-    return (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
-           (size_t)WIN_ROUND_SLOTS * (sizeof(int64_t) + sizeof(uint32_t));
+// rc = chunks per round (WIN_ROUND_CHUNKS by default; the staged form's first and side kernels take fewer: less LDS, more
+// resident workgroups)
+__host__ __device__ inline size_t win_emit_head_bytes(int rc = WIN_ROUND_CHUNKS) {
+    return (((size_t)(rc + 1) * sizeof(uint32_t) + 15) & ~(size_t)15) + 16 +
+           (size_t)rc * 64 * (sizeof(int64_t) + sizeof(uint32_t));
 }
-__host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
-    return win_emit_head_bytes() + (size_t)n_waves * win_emit_wave_lds_bytes(kmax);
+__host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves, int rc = WIN_ROUND_CHUNKS) {
+    return win_emit_head_bytes(rc) + (size_t)n_waves * win_emit_wave_lds_bytes(kmax);
 }
 
 // ---------------------------------------------------------------- K1: counts, offsets, draws, the three streams, items
@@ -168,17 +175,20 @@ __host__ __device__ inline size_t win_emit_lds_bytes(int kmax, int n_waves) {
 __device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v, uint32_t *lhist); // staged form
 
 // NEXT (DIRECT only; staged form): every new sample is also handed to the next hop as an 8-byte item.
-template <typename Item, int KMAX, bool REPLACE, bool DIRECT, bool FOLD = false, bool NEXT = false>
+// ITEMS = false (staged form's side pass): only the three streams -- no items, no item-range atomics.
+template <typename Item, int KMAX, bool REPLACE, bool DIRECT, bool FOLD = false, bool NEXT = false, bool ITEMS = true,
+          int RC = WIN_ROUND_CHUNKS>
 __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned char *smem, const int64_t b, const int hop,
                                                  const int k, const WinState st, const CallKey ck,
                                                  uint32_t *lhist = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
-    const size_t off_bytes = (((size_t)(WIN_ROUND_CHUNKS + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    constexpr int64_t ROUND_SLOTS = (int64_t)RC * 64;
+    const size_t off_bytes = (((size_t)(RC + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
     int64_t *shared_fbase = reinterpret_cast<int64_t *>(smem + off_bytes);
     int64_t *col0 = reinterpret_cast<int64_t *>(smem + off_bytes + 16);
-    uint32_t *cdeg = reinterpret_cast<uint32_t *>(smem + off_bytes + 16 + (size_t)WIN_ROUND_SLOTS * sizeof(int64_t));
-    unsigned char *wbase = smem + win_emit_head_bytes() + (size_t)wave * win_emit_wave_lds_bytes(p.kmax);
+    uint32_t *cdeg = reinterpret_cast<uint32_t *>(smem + off_bytes + 16 + (size_t)ROUND_SLOTS * sizeof(int64_t));
+    unsigned char *wbase = smem + win_emit_head_bytes(RC) + (size_t)wave * win_emit_wave_lds_bytes(p.kmax);
     uint32_t *spos = reinterpret_cast<uint32_t *>(wbase);
     uint8_t *slane = wbase + (size_t)64 * p.kmax * sizeof(uint32_t);
     Item *items = static_cast<Item *>(p.items_in);
@@ -197,13 +207,13 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
         lo[1] = ne;
         lo[2] = n_seeds + ne;
         // this batch's range of the hop's flat item array (order between batches does not matter)
-        if (!FOLD) *shared_fbase = DIRECT ? 0 : (int64_t)atomicAdd(&p.n_items[hop], (unsigned long long)(end - begin));
+        if (!FOLD) *shared_fbase = (DIRECT || !ITEMS) ? 0 : (int64_t)atomicAdd(&p.n_items[hop], (unsigned long long)(end - begin));
     }
     if (!FOLD) __syncthreads();
     const int64_t fbase = FOLD ? b * p.item_pitch : *shared_fbase;
 
-    for (int64_t round_begin = begin; round_begin < end; round_begin += WIN_ROUND_SLOTS) {
-        const int64_t round_end = min(end, round_begin + (int64_t)WIN_ROUND_SLOTS);
+    for (int64_t round_begin = begin; round_begin < end; round_begin += ROUND_SLOTS) {
+        const int64_t round_end = min(end, round_begin + ROUND_SLOTS);
         const int nc = (int)((round_end - round_begin + 63) >> 6);
         for (int c = wave; c < nc; c += n_waves) { // pass A: column bounds -> LDS, per-chunk sample counts
             const int64_t i = round_begin + (int64_t)c * 64 + lane;
@@ -244,7 +254,7 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
             const uint32_t excl = incl - cnt;
             const uint32_t total = __shfl(incl, 63, 64);
             const int64_t e_chunk = ne + (int64_t)chunk_off[c];
-            if (!DIRECT && i < round_end) {
+            if (!DIRECT && ITEMS && i < round_end) {
                 items[fbase + (i - begin)] =
                     Item::make((uint64_t)e0, n, (uint32_t)b, (uint32_t)i, (uint32_t)(e_chunk + excl), p.slot_bits);
                 if (FOLD && n) atomicAdd(&lhist[win_bucket((uint64_t)e0, p.shift, p.n_buckets)], 1u);
@@ -761,7 +771,7 @@ struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
     int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches, stage_sort_blocks;
-    int32_t stage_fine;
+    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -782,6 +792,9 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_PART_MIN_BATCHES", 1024),
         win_env_int("TG_WIN_STAGE_SORT_BLOCKS", 768),
         win_env_int("TG_WIN_STAGE_FINE", 1),
+        win_env_int("TG_WIN_STAGE_CONCURRENT", 0),
+        win_env_int("TG_WIN_STAGE_SPLIT", 0),
+        win_env_int("TG_WIN_STAGE_SPLIT_ROUND_CHUNKS", 4),
     };
     return t;
 }
@@ -997,9 +1010,9 @@ struct WinSide {
         // the emit pass gets the higher dispatch priority (TG_WIN_SIDE_PRIO=0: plain): beside it run the NEXT part's first
         // hop and sort, whose thousands of short workgroups would otherwise take every free slot first
         int least = 0, greatest = 0;
-        if (win_env_int("TG_WIN_SIDE_PRIO", 1) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
-            greatest < least)
-            TG_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest));
+        const int prio = win_env_int("TG_WIN_SIDE_PRIO", 1); // 0 plain, 1 highest, 2 lowest
+        if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least)
+            TG_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio == 2 ? least : greatest));
         else
             TG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto &e : gathered) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1012,11 +1025,11 @@ static WinSide &win_side() {
     return s;
 }
 
-// KFIRST: unroll bound of hop 0's direct kernel (any fan-out up to TG_MAX_FANOUT); the ordered hops' bound follows W
-template <int W, int KFIRST, bool REPLACE>
+// KFIRST: unroll bound of hop 0's direct kernel (any fan-out up to TG_MAX_FANOUT); KMAX: that of the ordered hops' gather /
+// emit / side kernels (<= 16 with one-chunk slots; 12 where the fan-outs allow: ~20 VGPRs less in the gather kernel)
+template <int W, int KFIRST, int KMAX, bool REPLACE>
 static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, const int64_t *fanout, int32_t n_hops,
                           hipStream_t stream) {
-    constexpr int KMAX = W == 16 ? 16 : 32;
     const WinTuning t = win_tuning();
     WinStageClock &clk = win_clock();
     const StageBits sb = win_stage_bits(csc);
@@ -1039,9 +1052,13 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
     int parts = std::min(std::max(t.stage_parts, 1), WIN_MAX_PARTS);
     while (parts > 1 && n_batches / parts < std::max(t.stage_part_min_batches, 1)) --parts;
     if (clk.enabled) parts = 1; // stage timing: one stream, one part, so that the events bracket single kernels
+    // split: rows / cols / edge_index leave on the side stream beside the sort and the gather (one part: the emit pass that
+    // follows is short, and it must wait for the side pass, which reads the state it updates)
+    const bool split = t.stage_split && !clk.enabled;
+    if (split) parts = 1;
     WinSide &side = win_side();
     std::unique_lock<std::mutex> side_lock(side.mu, std::defer_lock);
-    if (parts > 1) {
+    if (parts > 1 || split) {
         side_lock.lock();
         const int rc = side.ensure();
         if (rc != TG_OK) return rc;
@@ -1054,8 +1071,8 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
     // launches run their earlier hops whole and only the LAST hop in parts
     const bool first_in_parts = parts > 1 && n_hops == 2;
 
-    int fthreads = t.emit_threads;
-    while (fthreads > 64 && win_emit_lds_bytes(p.kmax, fthreads / 64) + tables > 64 * 1024)
+    int fthreads = std::min(t.emit_threads, WIN_EMIT_MAX_THREADS);
+    while (fthreads > 64 && win_emit_lds_bytes(p.kmax, fthreads / 64, WIN_STAGE_FIRST_RC) + tables > 64 * 1024)
         fthreads = ((fthreads >> 1) + 63) & ~63;
     auto rows_of = [&](int64_t nb) { // sort workgroups = rows of the histogram = persistent workgroups of the first kernel
         return (int32_t)std::min<int64_t>(std::min(std::max(t.stage_sort_blocks, 1), WIN_MAX_ROWS), nb);
@@ -1065,7 +1082,7 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         p.base = base0 + (size_t)part * (WIN_MAX_BUCKETS + 8);
         p.queues = queues0 + part;
     };
-    auto launch_first = [&](int part, int64_t b0, int64_t nb) { // E0: seeds, hop 0 direct, the items of hop 1 + their histogram
+    auto launch_first = [&](int part, int64_t b0, int64_t nb, hipStream_t ps) { // E0: seeds, hop 0 direct, the items of hop 1 + their histogram
         part_tables(part);
         p.b0 = b0;
         p.n_batches = nb;
@@ -1073,16 +1090,23 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         p.next_pitch = pitch_of(1);
         p.next_idx_bits = bits_of(p.next_pitch);
         hipLaunchKernelGGL((win_stage_first_kernel<KFIRST, REPLACE>), dim3((unsigned)p.n_rows), dim3(fthreads),
-                           win_emit_lds_bytes(p.kmax, fthreads / 64) + tables, stream, p, (int)fanout[0]);
+                           win_emit_lds_bytes(p.kmax, fthreads / 64, WIN_STAGE_FIRST_RC) + tables, ps, p, (int)fanout[0]);
     };
+    // stage_concurrent (two hops, several parts): the parts' WHOLE chains alternate between the caller's stream and the side
+    // stream and run beside each other -- what two launches in flight give a caller, inside one launch
+    const bool concurrent = first_in_parts && t.stage_concurrent;
 
     clk.begin(stream);
     hipLaunchKernelGGL(win_vtab_kernel, dim3((p.n_windows + 256) / 256), dim3(256), 0, stream, p, csc->n_major);
     TG_LAUNCH_CHECK();
     if (!first_in_parts) {
-        launch_first(0, 0, n_batches);
+        launch_first(0, 0, n_batches, stream);
         TG_LAUNCH_CHECK();
         clk.mark("first", 0, stream);
+    }
+    if (concurrent) { // fork: the side stream starts behind the vertex table
+        TG_HIP(hipEventRecord(side.gathered[0], stream));
+        TG_HIP(hipStreamWaitEvent(side.stream, side.gathered[0], 0));
     }
     for (int h = 1; h < n_hops; ++h) {
         const bool next = h + 1 < n_hops;
@@ -1090,8 +1114,9 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
         for (int part = 0; part < hparts; ++part) {
             const int64_t b0 = n_batches * part / hparts, nb = n_batches * (part + 1) / hparts - b0;
             const bool counted = h == 1 && (first_in_parts || hparts == 1); // the first kernel left this part's histogram
+            hipStream_t ps = (concurrent && (part & 1)) ? side.stream : stream;
             if (first_in_parts) {
-                launch_first(part, b0, nb);
+                launch_first(part, b0, nb, ps);
                 TG_LAUNCH_CHECK();
             }
             p.hop = h;
@@ -1101,8 +1126,8 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             p.next_pitch = next ? pitch_of(h + 1) : 0;
             p.next_idx_bits = next ? bits_of(p.next_pitch) : 0;
             int ethreads = t.stage_emit_threads;
-            int rc = std::min(std::max(t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
-            while (win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc) > 64 * 1024) {
+            int rc = std::min(std::max(split ? t.stage_split_round_chunks : t.stage_round_chunks, 1), WIN_STAGE_ROUND_CHUNKS_MAX);
+            while (win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc, split) > 64 * 1024) {
                 if (rc > 1)
                     rc >>= 1;
                 else if (ethreads > 64)
@@ -1110,7 +1135,7 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
                 else
                     return tg::fail(TG_ERR_INVALID, "tg_ns_homo_batched_ws: the staged emit kernel does not fit the LDS");
             }
-            const size_t elds = win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc);
+            const size_t elds = win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc, split);
             int gthreads = t.stage_gather_threads;
             const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
             while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
@@ -1123,17 +1148,17 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             p.items_sorted = static_cast<WinItem8 *>(sorted0) + p.b0 * p.item_pitch; // the part's own range of the two flat arrays
             p.items_fine = static_cast<WinItem8 *>(in0) + p.b0 * p.item_pitch; // (the strided items are dead after level 1)
             if (!counted) {
-                hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+                hipLaunchKernelGGL(win_hist8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, ps, p);
                 TG_LAUNCH_CHECK();
                 clk.mark("hist", h, stream);
             }
-            hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, stream, p,
+            hipLaunchKernelGGL(win_colscan_kernel, dim3((p.n_buckets + 63) / 64), dim3(64 * WIN_SCAN_GROUPS), 0, ps, p,
                                p.n_rows);
             TG_LAUNCH_CHECK();
-            hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, stream, p);
+            hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, ps, p);
             TG_LAUNCH_CHECK();
             clk.mark("scans", h, stream);
-            hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, stream, p);
+            hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, ps, p);
             TG_LAUNCH_CHECK();
             clk.mark("scatter", h, stream);
             if (t.stage_fine) {
@@ -1144,34 +1169,53 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
                 p.fine_start = fine_start0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE;
                 p.fine_tile_off = fine_tile_off0 + ((size_t)(p.b0 * p.item_pitch) / WIN_FINE_TILE + (size_t)part) * WIN_FINE_BINS;
                 const unsigned tiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>((worst + WIN_FINE_TILE - 1) / WIN_FINE_TILE, 2048));
-                TG_HIP(hipMemsetAsync(p.fine_tot, 0, keys * sizeof(uint32_t), stream));
-                hipLaunchKernelGGL(win_sort_fine_kernel<false>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, stream, p);
+                TG_HIP(hipMemsetAsync(p.fine_tot, 0, keys * sizeof(uint32_t), ps));
+                hipLaunchKernelGGL(win_sort_fine_kernel<false>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, ps, p);
                 TG_LAUNCH_CHECK();
-                hipLaunchKernelGGL(win_fine_starts_kernel, dim3(1), dim3(1024), 0, stream, p);
+                hipLaunchKernelGGL(win_fine_starts_kernel, dim3(1), dim3(1024), 0, ps, p);
                 TG_LAUNCH_CHECK();
-                hipLaunchKernelGGL(win_sort_fine_kernel<true>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, stream, p);
+                hipLaunchKernelGGL(win_sort_fine_kernel<true>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, ps, p);
                 TG_LAUNCH_CHECK();
                 clk.mark("fine", h, stream);
             } else
                 p.items_fine = p.items_sorted; // the gather kernel reads the coarse-sorted items
+            if (split) TG_HIP(hipEventRecord(side.gathered[h & (WIN_MAX_PARTS - 1)], ps)); // fork point: before the gather
             hipLaunchKernelGGL((win_stage_gather_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
-                               (size_t)(gthreads / 64) * per_wave, stream, p, sb);
+                               (size_t)(gthreads / 64) * per_wave, ps, p, sb);
             TG_LAUNCH_CHECK();
+            if (split) { // fork: the side pass starts beside the GATHER (beside the sort it slowed the sort's passes 2.5x: they
+                         // hang on the latency of their few HBM accesses, which the side pass's streams stretch)
+                int sthreads = std::min(t.emit_threads, WIN_EMIT_MAX_THREADS);
+                while (sthreads > 64 && win_emit_lds_bytes(p.kmax, sthreads / 64, WIN_STAGE_SIDE_RC) > 64 * 1024) sthreads = ((sthreads >> 1) + 63) & ~63;
+                TG_HIP(hipStreamWaitEvent(side.stream, side.gathered[h & (WIN_MAX_PARTS - 1)], 0));
+                hipLaunchKernelGGL((win_stage_side_kernel<KMAX, REPLACE>), dim3((unsigned)p.n_batches), dim3(sthreads),
+                                   win_emit_lds_bytes(p.kmax, sthreads / 64, WIN_STAGE_SIDE_RC), side.stream, p);
+                TG_LAUNCH_CHECK();
+                TG_HIP(hipEventRecord(side.done, side.stream));
+            }
             clk.mark("gather", h, stream);
             // the emit pass of the last hop has nothing after it to wait for: it goes to the side stream, behind this
             // part's gather, and the next part's chain starts beside it
-            hipStream_t es = stream;
-            if (hparts > 1) {
+            hipStream_t es = ps;
+            if (split) TG_HIP(hipStreamWaitEvent(ps, side.done, 0)); // join: the emit pass updates the state the side pass reads
+            if (hparts > 1 && !concurrent) {
                 TG_HIP(hipEventRecord(side.gathered[part], stream));
                 TG_HIP(hipStreamWaitEvent(side.stream, side.gathered[part], 0));
                 es = side.stream;
             }
-            if (next)
-                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, true>), dim3((unsigned)p.n_batches), dim3(ethreads), elds,
-                                   es, p, sb, rc);
+            if (split) {
+                if (next)
+                    hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, true, true>), dim3((unsigned)p.n_batches),
+                                       dim3(ethreads), elds, es, p, sb, rc);
+                else
+                    hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, false, true>), dim3((unsigned)p.n_batches),
+                                       dim3(ethreads), elds, es, p, sb, rc);
+            } else if (next)
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, true, false>), dim3((unsigned)p.n_batches), dim3(ethreads),
+                                   elds, es, p, sb, rc);
             else
-                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, false>), dim3((unsigned)p.n_batches), dim3(ethreads), elds,
-                                   es, p, sb, rc);
+                hipLaunchKernelGGL((win_stage_emit_kernel<W, KMAX, false, false>), dim3((unsigned)p.n_batches), dim3(ethreads),
+                                   elds, es, p, sb, rc);
             TG_LAUNCH_CHECK();
             clk.mark("emit", h, stream);
         }
@@ -1186,11 +1230,16 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
 template <bool REPLACE>
 static int win_dispatch_staged(const WinParams &p, const tg_graph *csc, int stage_words, int64_t n_batches,
                                const int64_t *fanout, int32_t n_hops, hipStream_t stream) {
+    int64_t kord = 0; // the largest fan-out of an ordered hop
+    for (int h = 1; h < n_hops; ++h) kord = std::max(kord, fanout[h]);
+    if (stage_words == 16 && kord <= 12)
+        return fanout[0] <= 16 ? win_run_staged<16, 16, 12, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
+                               : win_run_staged<16, 32, 12, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
     if (stage_words == 16)
-        return fanout[0] <= 16 ? win_run_staged<16, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
-                               : win_run_staged<16, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
-    return fanout[0] <= 16 ? win_run_staged<32, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
-                           : win_run_staged<32, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
+        return fanout[0] <= 16 ? win_run_staged<16, 16, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
+                               : win_run_staged<16, 32, 16, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
+    return fanout[0] <= 16 ? win_run_staged<32, 16, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream)
+                           : win_run_staged<32, 32, 32, REPLACE>(p, csc, n_batches, fanout, n_hops, stream);
 }
 
 // window size: a few hundred KB of the gathered array, at most WIN_MAX_BUCKETS windows
@@ -1340,6 +1389,9 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_part_min_batches = w.stage_part_min_batches;
     t->stage_sort_blocks = w.stage_sort_blocks;
     t->stage_fine = w.stage_fine;
+    t->stage_concurrent = w.stage_concurrent;
+    t->stage_split = w.stage_split;
+    t->stage_split_round_chunks = w.stage_split_round_chunks;
     return TG_OK;
 }
 
@@ -1370,6 +1422,9 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_part_min_batches > 0) w.stage_part_min_batches = t->stage_part_min_batches;
     if (t->stage_sort_blocks > 0) w.stage_sort_blocks = t->stage_sort_blocks;
     if (t->stage_fine >= 0) w.stage_fine = t->stage_fine != 0;
+    if (t->stage_concurrent >= 0) w.stage_concurrent = t->stage_concurrent != 0;
+    if (t->stage_split >= 0) w.stage_split = t->stage_split != 0;
+    if (t->stage_split_round_chunks > 0) w.stage_split_round_chunks = t->stage_split_round_chunks;
     return TG_OK;
 }
 
