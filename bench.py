@@ -54,8 +54,9 @@ def parse_args(argv=None):
                          "its own HIP stream, host thread and process group (communicator), so that the exchange of one "
                          "super-batch overlaps the sampling of the next (SURVEY.md 8(e)).  Verified with ONE rank exchanging "
                          "with itself only; refused with more ranks")
-    ap.add_argument("--pipelines", choices=["auto", "push", "staged"], default="auto",
-                    help="pipeline of the window-ordered launch: auto = time both in the untimed set-up and keep the faster")
+    ap.add_argument("--pipelines", choices=["auto", "push", "staged", "staged2"], default="auto",
+                    help="pipeline of the window-ordered launch: auto = time all of them in the untimed set-up and keep the "
+                         "fastest (staged2 = the staged pipeline in two parts, the emit pass of one beside the chain of the next)")
     ap.add_argument("--form", choices=["auto", "windowed", "fused"], default="auto",
                     help="tg_ns_homo_batched_ws form: window-ordered gather of the launch, or the fused per-batch kernel")
     return ap.parse_args(argv)
@@ -152,12 +153,16 @@ def main(argv=None):
     form = {"auto": 0, "windowed": 1, "fused": 2}[args.form]
 
     ws_staged = form != 2 and args.pipelines != "push"   # the workspaces then hold the staged pipeline's stage slots too
+    # the arenas are allocated BEFORE the graph exists (placement), so the stage slots are sized for an
+    # ASSUMED bound on the longest column (edges / 256: one 64-byte chunk per frontier vertex on RMAT-24); a graph beyond
+    # the bound needs two chunks, finds the workspace too small for them and takes the push pipeline (reported as such)
+    ws_sizing = _cabi.graph_sizing(n_nodes, n_edges, max(n_edges >> 8, 1))
 
     def alloc_slabs(G):  # 16 384 batches per launch need ~100 GB of slabs + workspace: on a GPU with less free HBM, halve
         while True:
             try:
                 out = _cabi.NsBatchedOut(G, B, fanout, dev)
-                ws = _cabi.ns_homo_workspace(G, B, fanout, dev, staged=ws_staged) if form != 2 else None
+                ws = _cabi.ns_homo_workspace(G, B, fanout, dev, staged=ws_staged, graph=ws_sizing) if form != 2 else None
                 return out, ws, G
             except torch.OutOfMemoryError:
                 out = ws = None
@@ -180,7 +185,8 @@ def main(argv=None):
                 if free_b < need + (24 << 30):           # keep room for the graph, its build and the seeds
                     break
                 candidates.append((_cabi.NsBatchedOut(G, B, fanout, dev),
-                                   _cabi.ns_homo_workspace(G, B, fanout, dev, staged=ws_staged) if form != 2 else None))
+                                   _cabi.ns_homo_workspace(G, B, fanout, dev, staged=ws_staged, graph=ws_sizing)
+                                   if form != 2 else None))
             except torch.OutOfMemoryError:
                 torch.cuda.empty_cache()
                 break
@@ -196,7 +202,7 @@ def main(argv=None):
     # u32 shadows (int32 tensors carrying the u32 bit pattern): only while ids / offsets fit 32 bits
     idx32 = indices.to(torch.int32) if args.idx32 and n_nodes <= 2 ** 32 else None
     ptr32 = ptrs.to(torch.int32) if args.ptr32 and n_edges < 2 ** 32 else None
-    graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32)
+    graph = _cabi.graph_view(ptrs, indices, indices32=idx32, ptrs32=ptr32, max_degree="auto")
     if not slabs_first:
         out, ws, G = alloc_slabs(G)
         candidates = [(out, ws)]
@@ -209,14 +215,15 @@ def main(argv=None):
     seeds = _cabi.seed_batches(0xBA7C4, first, n_pool * G, B, n_nodes, dev)
     placement_ms = None
     in_flight = None
+    PIPELINE_KNOBS = {"push": dict(staged=0), "staged": dict(staged=1, stage_parts=1), "staged2": dict(staged=1, stage_parts=2)}
     pipelines = ["push"]
     if form != 2 and args.pipelines != "push":
         # the window-ordered launch has two pipelines with identical outputs (push: emit -> sort -> gather scattering its
-        # samples; staged: gather into 64-byte stage slots -> emit all four streams); which is faster depends on where
-        # the slabs landed, so the set-up times both, like a planner would
-        pipelines = ["push", "staged"] if args.pipelines == "auto" else [args.pipelines]
+        # samples; staged: two-level sort -> gather into 64-byte stage slots -> emit all four streams as pure streams);
+        # which is faster depends on where the slabs landed, so the set-up times them, like a planner would
+        pipelines = ["push", "staged", "staged2"] if args.pipelines == "auto" else [args.pipelines]
     pipeline = pipelines[0]
-    _cabi.ns_win_tuning_set(staged=int(pipeline == "staged"))
+    _cabi.ns_win_tuning_set(**PIPELINE_KNOBS[pipeline])
     if len(candidates) > 1 or len(pipelines) > 1:
         # untimed set-up: the launch is timed on every combination of {samples slab} x {rows / cols / edge_index slabs} x
         # {workspace} of the placements (the gather kernel's time follows the first, the emit kernel's the second), one
@@ -228,7 +235,7 @@ def main(argv=None):
         n_c = len(candidates)
         for (a, b_, c), pl in itertools.product(itertools.product(range(n_c), range(n_c), range(n_c) if form != 2 else [0]),
                                                 pipelines):
-            _cabi.ns_win_tuning_set(staged=int(pl == "staged"))
+            _cabi.ns_win_tuning_set(**PIPELINE_KNOBS[pl])
             mix = copy.copy(candidates[a][0])
             mix.samples = candidates[a][0].samples
             mix.rows, mix.cols, mix.edge_index = (candidates[b_][0].rows, candidates[b_][0].cols,
@@ -245,7 +252,7 @@ def main(argv=None):
             placement_ms["samples%d_streams%d_ws%d_%s" % (a, b_, c, pl)] = round(ms, 3)
             if best_ms is None or ms < best_ms:
                 best, best_ms, pipeline = (a, b_, c), ms, pl
-        _cabi.ns_win_tuning_set(staged=int(pipeline == "staged"))
+        _cabi.ns_win_tuning_set(**PIPELINE_KNOBS[pipeline])
         # beside the line (never part of `value`): the same launches with TWO in flight, one per placement on its own
         # stream -- what a caller that prefetches the next super-batch gets
         in_flight = None
@@ -320,14 +327,14 @@ def main(argv=None):
     bytes_per_launch = alg_bytes / my_launches
     achieved = bytes_per_launch / avg_kernel_s / 1e9
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % (pipeline if form != 2 else "fused"))
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % (pipeline.rstrip("2") if form != 2 else "fused"))
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))  # PMC passes of an identical launch, collected by tools/pmc_win.sh
             form_ran = "fused" if args.form == "fused" else "windowed"
             if (tj.get("batches_per_launch") == G and args.scale == 24 and B == 1024 and fanout == [15, 10]
                     and tj.get("idx32") == args.idx32 and tj.get("ptr32") == args.ptr32 and tj.get("form") == form_ran
-                    and (form_ran == "fused" or tj.get("pipeline", "push") == pipeline)):
+                    and (form_ran == "fused" or tj.get("pipeline", "push") == pipeline.rstrip("2"))):
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_source = ("profiles/%s (separate rocprofv3 --pmc passes of the same launch and pipeline; NOT this "
                                   "run)" % os.path.basename(tpath))
@@ -338,7 +345,9 @@ def main(argv=None):
     if ws is None or _cabi.ns_homo_batched_form(graph, out, G, B, fanout, ws=ws, form=form)[0] == 2:
         pipeline_taken = "fused"
     else:
-        pipeline_taken = "staged" if _cabi.ns_homo_batched_staged(graph, out, G, B, fanout, ws=ws, form=form) else "push"
+        pipeline_taken = "push"
+        if _cabi.ns_homo_batched_staged(graph, out, G, B, fanout, ws=ws, form=form):
+            pipeline_taken = "staged, %d part(s)" % _cabi.ns_win_tuning()["stage_parts"]
 
     result = {
         "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [%s] on RMAT-%d" % (args.fanout, args.scale),
@@ -368,7 +377,9 @@ def main(argv=None):
             "two_launches_in_flight": in_flight,
             "hbm_layout": "CSC int64 ptrs/indices%s%s" % (" + u32 shadow of indices for the gathers" if args.idx32 else "",
                                                           " + u32 shadow of ptrs" if args.ptr32 else ""),
-            "rng": "philox4x32-10 counter-addressed, seed 0, call_id = global batch id",
+            "rng": "philox4x32-10 counter-addressed (slot draws: one 32-bit word each, Lemire's exact rejection, 64-bit fallback), "
+                   "seed 0, call_id = global batch id",
+            "max_degree": graph.max_degree,
             "parallelism": "replicated CSC, %d x independent seed batches" % world,
             "sampled_edges_per_step": edges_all / (K * world),
             "sampled_edges_per_mini_batch": edges_all / (K * world * G),
@@ -386,8 +397,9 @@ def main(argv=None):
             "traffic": traffic,
             "traffic_source": traffic_source,
             "kernel": ("ns_homo_uniform_kernel (fused per-batch form)" if args.form == "fused" else
-                       "tg_ns_homo_batched_ws launch = per hop win_emit + counting sort of the frontier by window + "
-                       "win_gather (window-ordered form); duration = the whole launch"),
+                       "tg_ns_homo_batched_ws launch, window-ordered form, pipeline `%s` (push: first hops + emit -> counting "
+                       "sort of the frontier by window -> win_gather; staged: first hop -> two-level sort -> gather into stage "
+                       "slots -> emit); no kernel dominates: duration = the whole launch" % pipeline_taken),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": avg_kernel_s * 1e3,
             "launches": my_launches,
@@ -406,6 +418,10 @@ def main(argv=None):
         del out, ws
         torch.cuda.empty_cache()
         result["secondary"] = secondary_configs(torch, _cabi, dev, args.cpu_seconds)
+        try:  # the headline launch at the sizes a loader uses (same graph, same seeds rule)
+            result["secondary"]["batches_per_launch_sweep"] = launch_size_sweep(torch, _cabi, graph, dev, B, fanout, n_nodes, first)
+        except Exception as e:  # noqa: BLE001  (a secondary run must never cost the headline line)
+            result["secondary"]["batches_per_launch_sweep"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
     if rank == 0:
@@ -571,6 +587,61 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
         dist.destroy_process_group()
 
 
+def roofline_block(alg_bytes, ms, what):
+    """`roofline` of a secondary configuration: algorithmic bytes / HIP-event time against the HBM peak."""
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes": alg_bytes, "ms": ms, "bytes_rule": what}
+
+
+def launch_size_sweep(torch, _cabi, graph, dev, B, fanout, n_nodes, first, sizes=(256, 1024, 4096)):
+    """tg_ns_homo_batched_ws at the launch sizes a loader uses: per size the form AUTO takes and, beside it, the fused
+    per-batch kernel and the window-ordered form forced -- sampled edges/s and roofline fraction each (HIP events)."""
+    res = {}
+    base = _cabi.ns_win_tuning()
+    _cabi.ns_win_tuning_set(staged=0, stage_parts=1)   # "auto" = the library's own defaults, not the headline's pick
+    defaults = _cabi.ns_win_tuning()
+    for G in sizes:
+        out = _cabi.NsBatchedOut(G, B, fanout, dev)
+        ws = _cabi.ns_homo_workspace(G, B, fanout, dev, staged=True, graph=graph)
+        seeds = _cabi.seed_batches(0xBA7C4, first, G, B, n_nodes, dev)
+        _cabi.ns_homo_batched(graph, seeds, fanout, 0, first, out, form=2)
+        torch.cuda.synchronize()
+        edges = int(out.counts[:, 1].sum())
+        slots = int(out.layer_offsets[:, len(fanout) - 1, 0].sum()) if fanout else 0
+        alg = 24 * slots + 40 * edges + 16 * B * G
+        entry = {"sampled_edges": edges, "algorithmic_bytes": alg}
+        for name, form, knobs in (("auto", 0, {}), ("fused", 2, {}), ("windowed_push", 1, dict(staged=0)),
+                                  ("windowed_staged", 1, dict(staged=1, stage_parts=1))):
+            _cabi.ns_win_tuning_set(**knobs)
+            try:
+                reps = max(4, 8192 // G)
+                best = None
+                for _ in range(2):
+                    for _w in range(2):
+                        _cabi.ns_homo_batched(graph, seeds, fanout, 0, first, out, ws=ws, form=form)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _r in range(reps):
+                        _cabi.ns_homo_batched(graph, seeds, fanout, 0, first, out, ws=ws, form=form)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
+                    best = ms if best is None else min(best, ms)
+                taken = _cabi.ns_homo_batched_form(graph, out, G, B, fanout, ws=ws, form=form)[0]
+                staged = bool(_cabi.ns_homo_batched_staged(graph, out, G, B, fanout, ws=ws, form=form))
+            finally:
+                _cabi.ns_win_tuning_set(**defaults)
+            entry[name] = {"ms_per_launch": best, "edges_per_s": edges / best * 1e3,
+                           "roofline_frac": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "takes": "fused" if taken == 2 else ("windowed, staged" if staged else "windowed, push")}
+        res["%d_batches" % G] = entry
+        del out, ws, seeds
+        torch.cuda.empty_cache()
+    _cabi.ns_win_tuning_set(**base)
+    return res
+
+
 def gpu_state(index):
     """sclk / mclk / power of this rank's GPU from sysfs (so that box-to-box spread can be attributed); never fails."""
     st = {}
@@ -641,6 +712,10 @@ def secondary_configs(torch, _cabi, dev, cpu_seconds):
         ms, w = timed(lambda c: _cabi.random_walk(g, start, 80, 1.0, 1.0, 0, c))
         steps = int((w[:, 1:] >= 0).sum().item())
         entry = {"ms": ms, "executed_steps": steps, "steps_per_s": steps / ms * 1e3}
+        n_w, L = int(w.shape[0]), int(w.shape[1]) - 1
+        entry["roofline"] = roofline_block(32 * steps + 8 * n_w + 8 * (n_w * L - steps), ms,
+                                           "32 B per executed step (16 ptrs + 8 neighbour + 8 written) + 8 B per walker (start "
+                                           "read) + 8 B per unexecuted cell (the -1 fill)")
         hp, hi, hs = ptrs.cpu().numpy(), idx.cpu().numpy(), start.cpu().numpy()
         nw, t0 = 4096, time.perf_counter()
         ref = orc.random_walk(hp, hi, hs[:nw], 80, 1.0, 1.0, orc.rng_ref_child(orc.rng_ref()))
@@ -674,6 +749,13 @@ def secondary_configs(torch, _cabi, dev, cpu_seconds):
         ms, _ = timed(lambda c: hb.run(0, c * nb))
         ne = int(hb.counts[:, 3:].sum().item())
         entry = {"ms_per_launch": ms, "sampled_edges": ne, "edges_per_s": ne / ms * 1e3}
+        # frontier slots of relation r in hop h = samples of its dst type that arrived during the previous hop (the seeds in
+        # hop 0): layer_offsets[b, r, h] = (len(samples[src]), len(edges[r]), len(samples[dst])) when hop h starts
+        lo = hb.layer_offsets  # [nb, R, H, 3]
+        dst_before = torch.cat([torch.zeros_like(lo[:, :, :1, 2]), lo[:, :, :-1, 2]], dim=2)
+        slots = int((lo[:, :, :, 2] - dst_before).sum().item())
+        entry["roofline"] = roofline_block(24 * slots + 40 * ne + 16 * nb * 1024, ms,
+                                           "per relation and hop 24 B per frontier slot + 40 B per sampled edge; 16 B per seed")
         hP = {k: v.cpu().numpy() for k, v in P.items()}
         hI = {k: v.cpu().numpy() for k, v in I.items()}
         hs = sd.cpu().numpy()
@@ -702,6 +784,20 @@ def secondary_configs(torch, _cabi, dev, cpu_seconds):
         edges = sum(int(v.numel()) for v in out[2].values())
         entry = {"ms_per_call": ms, "sampled_nodes": nodes, "sampled_edges": edges,
                  "nodes_plus_edges_per_s": (nodes + edges) / ms * 1e3}
+        # per budget update of a node, per relation INTO its type: 16 B (ptrs) + 8 B x min(deg, 50); the edge
+        # rebuild reads the same per output node again (hash-map traffic excluded).  Every sampled node is updated once
+        # except those of the last layer; every output node is rebuilt.
+        hgt_bytes = 0
+        n_last = {t: ns[t][-1] for t in node_types}
+        for (s_, r_, d_) in edge_types:
+            p_ = P["%s__%s__%s" % (s_, r_, d_)]
+            w_ = out[0][d_]
+            deg = (p_[w_ + 1] - p_[w_]).clamp(max=50)
+            upd = w_.numel() - min(n_last[d_], max(w_.numel() - int(seeds.numel() if d_ == "A" else 0), 0))
+            hgt_bytes += int((16 * upd + 8 * deg[:upd].sum()).item()) + int((16 * w_.numel() + 8 * deg.sum()).item())
+        entry["roofline"] = roofline_block(hgt_bytes, ms, "16 B + 8 B x min(deg, 50) per (node, relation into its type) per budget "
+                                           "update and again per output node for the edge rebuild; hash maps excluded -- the "
+                                           "call is bound by its chain of ~48 small launches, not by bytes")
         t0, done = time.perf_counter(), 0
         while done < 64 and time.perf_counter() - t0 < budget:
             orc.hgt(node_types, edge_types, hP, hI, None, {"A": hs[done]}, None, ns, 2, orc.rng_ref_child(parent))

@@ -128,6 +128,13 @@ def graph_view(ptrs, indices, weights=None, timestamps=None, indices32=None, ptr
     return g
 
 
+def graph_sizing(n_major, n_edges, max_degree=0):
+    """A tg_graph that carries only sizes (no arrays): enough for ns_homo_workspace(graph=...) before the graph exists."""
+    g = TgGraph()
+    g.n_major, g.n_edges, g.max_degree = int(n_major), int(n_edges), int(max_degree)
+    return g
+
+
 def ns_homo_capacity(n_seeds, fanout):
     cn, ce = C.c_int64(0), C.c_int64(0)
     fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
