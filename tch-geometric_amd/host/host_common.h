@@ -7,6 +7,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstring>
 #include <mutex>
 #include <random>
 #include <sstream>
@@ -101,6 +102,31 @@ inline Tensor on(const Tensor &t, const c10::Device &dev, at::ScalarType want) {
 // a weak reference to the storage so that the entry of a freed tensor is dropped and its address can be reused safely.
 // RMAT-24's CSC is 2.3 GB = 40 ms per upload; per call that was the whole cost of a "CPU graph" (DESIGN.md 5).
 // Bounded by TG_GRAPH_CACHE_GB (default 64) of device memory, least recently used first; graph_cache_clear() drops all.
+// Version counter of a tensor for the identity memos below, or false where there is none to trust: inference tensors do not
+// track versions (`_version()` throws on them -- an eval loop under torch.inference_mode() hands such tensors in), so they are
+// never memoised: their checks / uploads are simply done again.
+inline bool memo_version(const Tensor &t, uint32_t *version) {
+    if (t.is_inference()) return false;
+    *version = (uint32_t)t._version();
+    return true;
+}
+// A few words of a host tensor's content (first, last, 14 in between): writes that do not bump the version counter -- a
+// numpy array aliased by torch.from_numpy and changed between calls, a shared-memory writer -- usually change one of them.
+// Not a proof of equality; the documented contract is "bump the version or clear the cache".
+inline uint64_t host_fingerprint(const Tensor &t) {
+    const int64_t n = t.numel();
+    const size_t es = (size_t)t.element_size();
+    const unsigned char *base = static_cast<const unsigned char *>(t.data_ptr());
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
+    for (int i = 0; i < 16 && n > 0; ++i) {
+        const int64_t j = (i == 15) ? n - 1 : (n / 16) * i;
+        uint64_t w = 0;
+        std::memcpy(&w, base + (size_t)j * es, es < 8 ? es : 8);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
+    }
+    return h;
+}
 struct ResidentGraphs {
     struct Entry {
         c10::weak_intrusive_ptr<c10::StorageImpl> storage;
@@ -108,6 +134,7 @@ struct ResidentGraphs {
         int64_t n;
         uint32_t version;
         int dev;
+        uint64_t fingerprint;
         Tensor copy;
         uint64_t used;
     };
@@ -126,20 +153,35 @@ struct ResidentGraphs {
         for (const Entry &e : entries) b += (int64_t)e.copy.nbytes();
         return b;
     }
+    static Tensor upload(const Tensor &t, const c10::Device &dev) {
+        c10::InferenceMode plain(false); // the copy is an ordinary tensor even when the call runs under inference_mode()
+        return t.contiguous().to(dev);
+    }
     Tensor get(const Tensor &t, const c10::Device &dev) {
+        uint32_t version = 0;
+        // memoised: contiguous tensors with a version counter only (a strided view shares storage, address, length and
+        // version with other views of its base; an inference tensor has no counter)
+        if (!t.is_contiguous() || !memo_version(t, &version) || limit_bytes() <= 0) {
+            std::lock_guard<std::mutex> lock(mu);
+            ++uploads;
+            return upload(t, dev);
+        }
         c10::StorageImpl *impl = t.storage().unsafeGetStorageImpl();
         const void *ptr = t.data_ptr();
-        const uint32_t version = t._version();
+        const uint64_t fp = host_fingerprint(t);
+        auto same = [&](const Entry &e) {
+            return e.impl == impl && e.p == ptr && e.n == t.numel() && e.version == version && e.dev == dev.index() &&
+                   e.copy.scalar_type() == t.scalar_type();
+        };
         {
             std::lock_guard<std::mutex> lock(mu);
             for (size_t i = 0; i < entries.size();) {
-                if (entries[i].storage.expired()) {
-                    entries.erase(entries.begin() + (long)i);
+                if (entries[i].storage.expired() || (same(entries[i]) && entries[i].fingerprint != fp)) {
+                    entries.erase(entries.begin() + (long)i); // freed, or rewritten behind the version counter's back
                     continue;
                 }
                 Entry &e = entries[i];
-                if (e.impl == impl && e.p == ptr && e.n == t.numel() && e.version == version && e.dev == dev.index() &&
-                    e.copy.scalar_type() == t.scalar_type()) {
+                if (same(e)) {
                     e.used = ++tick;
                     ++hits;
                     return e.copy;
@@ -147,8 +189,13 @@ struct ResidentGraphs {
                 ++i;
             }
         }
-        Tensor copy = t.contiguous().to(dev);
+        Tensor copy = upload(t, dev);
         std::lock_guard<std::mutex> lock(mu);
+        for (Entry &e : entries) // another thread uploaded the same tensor meanwhile: keep one copy
+            if (same(e) && e.fingerprint == fp && !e.storage.expired()) {
+                e.used = ++tick;
+                return e.copy;
+            }
         ++uploads;
         if ((int64_t)copy.nbytes() > limit_bytes()) return copy; // larger than the whole budget: not kept
         while (!entries.empty() && bytes_locked() + (int64_t)copy.nbytes() > limit_bytes()) {
@@ -158,7 +205,7 @@ struct ResidentGraphs {
             entries.erase(entries.begin() + (long)lru);
         }
         entries.push_back(Entry{c10::weak_intrusive_ptr<c10::StorageImpl>(t.storage().getWeakStorageImpl()), impl, ptr,
-                                t.numel(), version, (int)dev.index(), copy, ++tick});
+                                t.numel(), version, (int)dev.index(), fp, copy, ++tick});
         return copy;
     }
     static ResidentGraphs &instance() {
@@ -253,8 +300,9 @@ inline void check_graph_ids(const Tensor &indices, int64_t hi, const c10::Device
     if (indices.numel() == 0) return;
     c10::StorageImpl *impl = indices.storage().unsafeGetStorageImpl();
     const void *ptr = indices.data_ptr();
-    const uint32_t version = indices._version();
-    {
+    uint32_t version = 0;
+    const bool memo = memo_version(indices, &version) && indices.is_contiguous();
+    if (memo) {
         std::lock_guard<std::mutex> lock(mu);
         for (size_t i = 0; i < seen.size();) {
             if (seen[i].storage.expired()) { // the tensor it described is gone: its address may be reused
@@ -269,6 +317,7 @@ inline void check_graph_ids(const Tensor &indices, int64_t hi, const c10::Device
     RangeCheck rc(dev);
     rc.add(indices, hi);
     rc.verify(what);
+    if (!memo) return; // an inference tensor (no version counter) or a strided view: checked again next time
     std::lock_guard<std::mutex> lock(mu);
     if (seen.size() >= 64) seen.erase(seen.begin());
     seen.push_back(Key{c10::weak_intrusive_ptr<c10::StorageImpl>(indices.storage().getWeakStorageImpl()), impl, ptr,
@@ -308,6 +357,8 @@ struct EdgeSets {
     // the set of (ptrs, idx) on `dev`, or an undefined tensor: not cached and `build` is false, or it does not fit
     Tensor get(const Tensor &ptrs, const Tensor &idx, const tg_graph &g, const c10::Device &dev, bool build) {
         if (g.n_major >= (int64_t)0xffffffff) return Tensor();
+        uint32_t vp_now = 0, vi_now = 0;
+        if (!memo_version(ptrs, &vp_now) || !memo_version(idx, &vi_now)) return Tensor(); // inference tensors: never memoised
         c10::StorageImpl *ip = ptrs.storage().unsafeGetStorageImpl(), *ii = idx.storage().unsafeGetStorageImpl();
         {
             std::lock_guard<std::mutex> lock(mu);
@@ -318,7 +369,7 @@ struct EdgeSets {
                 }
                 Entry &e = entries[i];
                 if (e.ip == ip && e.ii == ii && e.pp == ptrs.data_ptr() && e.pi == idx.data_ptr() && e.np == ptrs.numel() &&
-                    e.ni == idx.numel() && e.vp == (uint32_t)ptrs._version() && e.vi == (uint32_t)idx._version() &&
+                    e.ni == idx.numel() && e.vp == vp_now && e.vi == vi_now &&
                     e.dev == dev.index()) {
                     e.used = ++tick;
                     ++hits;
@@ -336,7 +387,7 @@ struct EdgeSets {
         std::lock_guard<std::mutex> lock(mu);
         for (Entry &e : entries) // another thread built the same set meanwhile: keep one
             if (e.ip == ip && e.ii == ii && e.pp == ptrs.data_ptr() && e.pi == idx.data_ptr() && e.np == ptrs.numel() &&
-                e.ni == idx.numel() && e.vp == (uint32_t)ptrs._version() && e.vi == (uint32_t)idx._version() &&
+                e.ni == idx.numel() && e.vp == vp_now && e.vi == vi_now &&
                 e.dev == dev.index() && !e.sp.expired() && !e.si.expired()) {
                 e.used = ++tick;
                 return e.set;
@@ -350,8 +401,7 @@ struct EdgeSets {
         }
         entries.push_back(Entry{c10::weak_intrusive_ptr<c10::StorageImpl>(ptrs.storage().getWeakStorageImpl()),
                                 c10::weak_intrusive_ptr<c10::StorageImpl>(idx.storage().getWeakStorageImpl()), ip, ii,
-                                ptrs.data_ptr(), idx.data_ptr(), ptrs.numel(), idx.numel(), (uint32_t)ptrs._version(),
-                                (uint32_t)idx._version(),
+                                ptrs.data_ptr(), idx.data_ptr(), ptrs.numel(), idx.numel(), vp_now, vi_now,
                                 (int)dev.index(), set, ++tick});
         return set;
     }

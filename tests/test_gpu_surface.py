@@ -408,6 +408,65 @@ def test_cpu_resident_graph_is_uploaded_once(tg):
     assert tg.graph_cache_info()["entries"] == 0
 
 
+def test_inference_mode_strided_views_and_aliased_writes(tg):
+    """(a) tensors made under torch.inference_mode() have no version counter -- the identity memos must not ask
+    for one (an eval loop calls the samplers there, with CPU adjacency as the reference does); (b) two strided views of one
+    storage share address, length and version -- only contiguous tensors are memoised; (c) a write that does not bump the
+    version (numpy alias) is caught by the content fingerprint of the resident copy."""
+    DEV = "cuda:0"
+    ei = torch.from_numpy(load_karate()[0])
+    ptrs_d, idx_d, _ = tg.to_csc(ei.to(DEV), 34)
+    rptrs_d, ridx_d, _ = tg.to_csr(ei.to(DEV), 34)
+    inputs = torch.tensor([0, 1, 4, 5])
+    tg.seed(3)
+    ref = tg.neighbor_sampling_homogenous(ptrs_d, idx_d, inputs.to(DEV), [5, 5])
+    tg.seed(3)
+    ref_w = tg.random_walk(rptrs_d, ridx_d, inputs.to(DEV), 6, 0.5, 2.0)
+    tg.graph_cache_clear()
+    with torch.inference_mode():
+        ptrs, idx = ptrs_d.cpu().clone(), idx_d.cpu().clone()           # inference tensors, on the CPU
+        rptrs, ridx = rptrs_d.cpu().clone(), ridx_d.cpu().clone()
+        assert ptrs.is_inference()
+        for _ in range(2):
+            tg.seed(3)
+            o = tg.neighbor_sampling_homogenous(ptrs, idx, inputs.clone(), [5, 5])
+            assert all(torch.equal(a, b.cpu()) for a, b in zip(o[:4], ref[:4])) and o[4] == ref[4]
+            tg.seed(3)
+            w = tg.random_walk(rptrs, ridx, inputs.clone(), 6, 0.5, 2.0)
+            assert torch.equal(w, ref_w.cpu())
+        tg.seed(3)                                                        # ... and device-resident inference tensors
+        o = tg.neighbor_sampling_homogenous(ptrs_d.clone(), idx_d.clone(), inputs.to(DEV), [5, 5])
+        assert all(torch.equal(a, b) for a, b in zip(o[:4], ref[:4]))
+    # (b) idx_a and idx_b: same storage, address, length, version -- different content
+    both = torch.stack([idx_d.cpu(), torch.zeros_like(idx_d.cpu())], dim=1).reshape(-1)   # idx interleaved with zeros
+    idx_a, idx_b = both[0::2], both[1::2][: idx_d.numel()]
+    base_p = ptrs_d.cpu()
+    tg.seed(3)
+    oa = tg.neighbor_sampling_homogenous(base_p, idx_a, inputs, [5, 5])
+    assert all(torch.equal(a, b.cpu()) for a, b in zip(oa[:4], ref[:4]))
+    view0 = both[0::2]
+    shifted = torch.stack([torch.zeros_like(idx_d.cpu()), idx_d.cpu()], dim=1).reshape(-1)
+    tg.seed(3)
+    ob = tg.neighbor_sampling_homogenous(base_p, shifted[1::2], inputs, [5, 5])          # another strided view: not a stale hit
+    assert all(torch.equal(a, b.cpu()) for a, b in zip(ob[:4], ref[:4]))
+    del idx_b, view0
+    # (c) numpy alias: the write below does not move the version counter
+    arr = idx_d.cpu().numpy().copy()
+    t = torch.from_numpy(arr)
+    tg.seed(3)
+    o1 = tg.neighbor_sampling_homogenous(base_p, t, inputs, [5, 5])
+    assert torch.equal(o1[0], ref[0].cpu())
+    v = t._version
+    arr[:] = np.roll(arr, 1)                                              # behind torch's back
+    assert t._version == v
+    tg.seed(3)
+    o2 = tg.neighbor_sampling_homogenous(base_p, t, inputs, [5, 5])
+    tg.seed(3)
+    want = tg.neighbor_sampling_homogenous(ptrs_d, torch.from_numpy(arr.copy()).to(DEV), inputs.to(DEV), [5, 5])
+    assert torch.equal(o2[0], want[0].cpu()) and torch.equal(o2[3], want[3].cpu())
+    tg.graph_cache_clear()
+
+
 @pytest.mark.parametrize("deg", [20_000, 100_000, 700_000])
 @pytest.mark.parametrize("filtered", [False, True])
 def test_weighted_sampling_of_long_columns(tg, deg, filtered):
