@@ -305,6 +305,10 @@ int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_
                                const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                                const tg_ns_out *out, hipStream_t stream); // ns_homo_scan.hip
 
+int tg_ns_homo_flat_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                           const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                           const tg_ns_out *out, void *ws, int64_t ws_bytes, int32_t mode, hipStream_t stream,
+                           int *rc_out); // ns_homo_flat.hip
 int tg_ns_homo_windowed_applicable(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
                                    int32_t n_hops, const tg_ns_config *cfg, const tg_ns_out *out,
                                    int32_t mode); // ns_homo_win.hip
@@ -339,9 +343,14 @@ static int ns_homo_batched_impl(const tg_graph *csc, const int64_t *seeds, int64
     TG_REQUIRE(sampler >= TG_SAMPLER_UNIFORM && sampler <= TG_SAMPLER_WEIGHTED, "tg_ns_homo_batched: bad sampler %d",
                sampler);
     TG_REQUIRE(filter >= TG_FILTER_NONE && filter <= TG_FILTER_DYNAMIC, "tg_ns_homo_batched: bad filter %d", filter);
-    if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE)
+    if (sampler == TG_SAMPLER_WEIGHTED || filter != TG_FILTER_NONE) {
+        int rc_flat = TG_OK; // few batches + a workspace: hop by hop over the whole device (ns_homo_flat.hip)
+        if (tg_ns_homo_flat_launch(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out, ws, ws_bytes, mode,
+                                   (hipStream_t)stream, &rc_flat))
+            return rc_flat;
         return tg_ns_homo_filtered_launch(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out,
                                           (hipStream_t)stream);
+    }
 
     if (ws && tg_ns_homo_windowed_applicable(csc, n_batches, n_seeds, fanout, n_hops, cfg, out, mode))
         return tg_ns_homo_windowed_launch(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out, ws, ws_bytes,

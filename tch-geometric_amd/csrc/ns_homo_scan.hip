@@ -45,6 +45,7 @@ struct NsScanParams {
     uint64_t seed, call_id;
     uint32_t tag;
     int64_t id_base;
+    const int32_t *only_if; // non-null: run only when *only_if & 3 != 0 (the fall-back behind the flat path, ns_homo_flat.hip)
 };
 
 __host__ __device__ inline size_t nss_wave_lds_bytes(int kmax) {
@@ -93,6 +94,7 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const int64_t b = blockIdx.x;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (p.only_if && (*p.only_if & 3) == 0) return; // uniform: the flat path finished, nothing to redo
 
     uint32_t *chunk_off = reinterpret_cast<uint32_t *>(smem);
     unsigned char *wbase = smem + ((((size_t)(NSS_CHUNKS_PER_ROUND + 1) * 4) + 15) & ~(size_t)15) +
@@ -450,10 +452,19 @@ __global__ void ns_homo_scan_kernel(const NsScanParams p) {
 
 } // namespace tg
 
+int tg_ns_homo_filtered_launch_if(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                                  const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                                  const tg_ns_out *out, const int32_t *only_if, hipStream_t stream);
 int tg_ns_homo_filtered_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
                                const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
                                const tg_ns_out *out, hipStream_t stream) {
+    return tg_ns_homo_filtered_launch_if(csc, seeds, n_batches, n_seeds, fanout, n_hops, cfg, rng, out, nullptr, stream);
+}
+int tg_ns_homo_filtered_launch_if(const tg_graph *csc, const int64_t *seeds, int64_t n_batches, int64_t n_seeds,
+                                  const int64_t *fanout, int32_t n_hops, const tg_ns_config *cfg, const tg_rng *rng,
+                                  const tg_ns_out *out, const int32_t *only_if, hipStream_t stream) {
     tg::NsScanParams p;
+    p.only_if = only_if;
     p.ptrs = csc->ptrs;
     p.indices = csc->indices;
     p.weights = csc->weights;

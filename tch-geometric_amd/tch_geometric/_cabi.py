@@ -32,7 +32,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol",
            "tg_debug_bounds_set_flag", "tg_part_sample_workspace_bytes", "tg_part_sample_ws",
            "tg_part_sample_order_thresholds", "tg_ns_homo_batched_pipeline", "tg_graph_max_degree",
-           "tg_ns_homo_workspace_bytes_for"]
+           "tg_ns_homo_workspace_bytes_for", "tg_ns_homo_batched_workspace_bytes"]
 
 
 class TgGraph(C.Structure):
@@ -188,6 +188,19 @@ def ns_homo_workspace(n_batches, n_seeds, fanout, device, staged=None, graph=Non
         if prev is not None:
             ns_win_tuning_set(staged=prev["staged"])
     return torch.empty(nbytes.value // 8 + 1, dtype=torch.int64, device=device)
+
+
+def ns_homo_batched_workspace(graph, n_batches, n_seeds, fanout, device, sampler=SAMPLER_UNIFORM, filter_mode=FILTER_NONE):
+    """The workspace tg_ns_homo_batched_ws wants for THIS configuration (tg_ns_homo_batched_workspace_bytes): the
+    window-ordered form's for the plain samplers, the flat path's for few filtered / weighted batches; None when the launch
+    takes none."""
+    cfg = TgNsConfig()
+    cfg.sampler, cfg.filter_mode = sampler, filter_mode
+    nbytes = C.c_int64(0)
+    fan = (C.c_int64 * max(len(fanout), 1))(*fanout)
+    check(lib.tg_ns_homo_batched_workspace_bytes(C.byref(graph), C.c_int64(n_batches), C.c_int64(n_seeds), fan,
+                                                 C.c_int32(len(fanout)), C.byref(cfg), C.byref(nbytes)))
+    return torch.empty(nbytes.value // 8 + 1, dtype=torch.int64, device=device) if nbytes.value > 0 else None
 
 
 def ns_homo_batched(graph, seeds, fanout, seed, call_id, out, sampler=SAMPLER_UNIFORM, filter_mode=FILTER_NONE,

@@ -54,8 +54,20 @@ for name, kw in (("temporal_static_window_half", dict(filter_mode=_cabi.FILTER_S
                                                    filter_mode=kw.get("filter_mode", _cabi.FILTER_NONE), window=kw.get("window", (0, 0)),
                                                    seeds_state=states if filtered else None))
     same = bool(torch.equal(out.counts, ref.counts))
-    res[name] = {"flat_hops_ms": ms, "per_batch_workgroups_ms": ms_b, "sampled_edges": edges,
-                 "flat_G_edges_per_s": edges / ms / 1e6, "same_counts": same}
+    # round 4: the C ABI's own switch -- tg_ns_homo_batched_ws with the workspace of tg_ns_homo_batched_workspace_bytes
+    ws = _cabi.ns_homo_batched_workspace(g, G, B, fan, dev, sampler=kw.get("sampler", _cabi.SAMPLER_UNIFORM),
+                                         filter_mode=kw.get("filter_mode", _cabi.FILTER_NONE))
+    own = _cabi.NsBatchedOut(G, B, fan, dev, with_states=filtered)
+    ms_o, _ = timed(lambda: _cabi.ns_homo_batched(g, seeds, fan, 7, 100, own, sampler=kw.get("sampler", _cabi.SAMPLER_UNIFORM),
+                                                   filter_mode=kw.get("filter_mode", _cabi.FILTER_NONE), window=kw.get("window", (0, 0)),
+                                                   seeds_state=states if filtered else None, ws=ws)) if ws is not None else (None, None)
+    same_own = None
+    if ws is not None:   # used prefixes of batch 0 and the last batch, and every count
+        cnt = ref.counts.cpu()
+        same_own = bool(torch.equal(own.counts, ref.counts)) and all(
+            all(torch.equal(x, y) for x, y in zip(own.batch(j, cnt)[:4], ref.batch(j, cnt)[:4])) for j in (0, G - 1))
+    res[name] = {"flat_hops_ms": ms, "per_batch_workgroups_ms": ms_b, "c_abi_own_switch_ms": ms_o, "sampled_edges": edges,
+                 "flat_G_edges_per_s": edges / ms / 1e6, "same_counts": same, "own_switch_same_output": same_own}
     print(json.dumps({name: res[name]}), file=sys.stderr, flush=True)
     del ps, ref
 print(json.dumps(res))
