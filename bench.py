@@ -50,10 +50,10 @@ def parse_args(argv=None):
                     help="--mode partitioned with one rank: still run every collective of the protocol over RCCL (the rank "
                          "exchanges with itself) -- what a one-GPU box can exercise of the transport")
     ap.add_argument("--lanes", type=int, default=1,
-                    help="--mode partitioned: super-batches in flight at once, each lane a PartitionedSampler of its own on "
-                         "its own HIP stream, host thread and process group (communicator), so that the exchange of one "
-                         "super-batch overlaps the sampling of the next (SURVEY.md 8(e)).  Verified with ONE rank exchanging "
-                         "with itself only; refused with more ranks")
+                    help="--mode partitioned: super-batches in flight at once -- each lane a PartitionedSampler of its own on "
+                         "its own HIP stream, all driven from ONE host thread over ONE communicator in a fixed, rank-independent "
+                         "enqueue order (tch_geometric.partitioned.interleave), so that the exchange of one super-batch overlaps "
+                         "the sampling of the next (SURVEY.md 8(e)); legal with any number of ranks")
     ap.add_argument("--pipelines", choices=["auto", "push", "staged", "staged2"], default="auto",
                     help="pipeline of the window-ordered launch: auto = time all of them in the untimed set-up and keep the "
                          "fastest (staged2 = the staged pipeline in two parts, the emit pass of one beside the chain of the next)")
@@ -492,60 +492,30 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     lanes = max(1, args.lanes)
-    if lanes > 1 and world > 1:
-        # several communicators driven from several host threads with blocking size read-backs in between: collectives of
-        # different communicators may be enqueued in different orders on different ranks -- a known way to deadlock.  Only
-        # ever run (and verified) with ONE rank exchanging with itself; refused beyond that until a multi-GPU run exists.
-        raise SystemExit("bench.py: --lanes > 1 is verified for one rank only (world %d); use --lanes 1" % world)
     exchanging = world > 1 or args.force_exchange
-    # a lane's collectives must meet the same lane's on every rank in the same order: one communicator per lane
-    groups = [dist.new_group(ranks=list(range(world))) if (exchanging and lanes > 1) else None for _ in range(lanes)]
-    pss = [partitioned.PartitionedSampler(shard, G, B, fanout, group=groups[j], force_exchange=args.force_exchange)
-           for j in range(lanes)]
-    ps = pss[0]
-    streams = [torch.cuda.Stream(device=dev) if lanes > 1 else torch.cuda.current_stream(dev) for _ in range(lanes)]
+    # a communicator per lane (their collectives then pass each other); legal with any number of ranks because ONE host thread
+    # enqueues every collective of every lane in a fixed, rank-independent order (partitioned.interleave)
+    groups = [dist.new_group(ranks=list(range(world))) for _ in range(lanes)] if (exchanging and lanes > 1) else None
+    pipe = partitioned.PipelinedPartitionedSampler(shard, G, B, fanout, lanes=lanes, groups=groups,
+                                                   force_exchange=args.force_exchange)
+    ps = pipe.samplers[0]
     firsts = [sharding.rank_batch_range(r, world, (W + K) * G)[0] for r in range(world)]
     first = firsts[rank]
-    accs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(lanes)]
+    accs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(lanes)]   # one per lane (= per stream)
     events = []
 
-    def run_lane(j, lo, hi, timed):
-        with torch.cuda.stream(streams[j]):
-            for i in range(lo + j, hi, lanes):
-                seeds = _cabi.seed_batches(0xBA7C4, first + i * G, G, B, n, dev)
-                if timed:
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ev0.record()
-                out = pss[j].sample(seeds, 0, first + i * G, first_call_ids=[f + i * G for f in firsts])
-                if timed:
-                    ev1.record()
-                    events.append((ev0, ev1))
-                accs[j].add_(out.counts[:, 1].sum())
-
     def run(lo, hi, timed):
-        if lanes == 1:
-            return run_lane(0, lo, hi, timed)
-        import threading
-        errs = []
-
-        def guarded(j):
-            try:
-                torch.cuda.set_device(dev)
-                run_lane(j, lo, hi, timed)
-            except BaseException as ex:  # noqa: BLE001
-                # the other lanes may sit in collectives that this lane will never join: do not wait for them
-                import traceback
-                traceback.print_exc()
-                sys.stderr.write("bench.py: lane %d failed (%r); leaving at once\n" % (j, ex))
-                sys.stderr.flush()
-                os._exit(3)
-        ts = [threading.Thread(target=guarded, args=(j,)) for j in range(lanes)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        if errs:
-            raise errs[0]
+        """super-batches lo .. hi - 1; with --lanes > 1 two (or more) are in flight, interleaved by ONE host thread"""
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        pipe.sample_many(hi - lo,
+                         lambda i: _cabi.seed_batches(0xBA7C4, first + (lo + i) * G, G, B, n, dev),
+                         0, lambda i: (first + (lo + i) * G, [f + (lo + i) * G for f in firsts]),
+                         lambda i, out: accs[i % lanes].add_(out.counts[:, 1].sum()))
+        if timed:
+            ev1.record()
+            events.append((ev0, ev1, hi - lo))
 
     run(0, W, False)
     torch.cuda.synchronize(dev)
@@ -559,7 +529,7 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
     acc = torch.stack(accs).sum(0)
     dt_max, tot = sharding.reduce_measurement(dt, torch.cat([acc, torch.zeros(2, dtype=torch.int64, device=dev)]))
     edges_all = int(tot.tolist()[0])
-    ms = [a.elapsed_time(b) for a, b in events]
+    ms = [a.elapsed_time(b) / cnt for a, b, cnt in events]
     result = {
         "metric": "sampled edges/sec, neighbor_sampling_homogenous fanout [%s] on RMAT-%d" % (args.fanout, args.scale),
         "value": edges_all / dt_max, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,

@@ -219,14 +219,34 @@ class PartitionedSampler:
 
     def _sizes(self, mine):
         """mine: [world] int64 device tensor -> (mine as a list, the peers' as a list): one read-back"""
+        return self._sizes_end(self._sizes_begin(mine, 0))
+
+    def _sizes_begin(self, mine, which):
+        """Starts the size exchange: the collective and the copy of both rows to pinned host memory are ENQUEUED, nothing is
+        waited for -- `steps` yields between _begin and _end, so the wait of one super-batch passes while the scheduler
+        enqueues another's work.  (gloo stages through the host and is blocking by nature.)"""
         if self.gloo:
             theirs = torch.empty(self.world, dtype=torch.int64)
             m_host = mine.cpu()
             dist.all_to_all_single(theirs, m_host, group=self.group)
-            return m_host.tolist(), theirs.tolist()
+            return (m_host.tolist(), theirs.tolist())
         theirs = torch.empty_like(mine)
         dist.all_to_all_single(theirs, mine.contiguous(), group=self.group)
-        both = torch.stack([mine, theirs]).tolist()
+        key = "pinned_sizes_%d" % which
+        pin = self._bufs.get(key)
+        if pin is None:
+            pin = self._bufs[key] = (torch.empty((2, self.world), dtype=torch.int64).pin_memory(), torch.cuda.Event())
+        host, ev = pin
+        host.copy_(torch.stack([mine, theirs]), non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
+        return (host, ev)
+
+    def _sizes_end(self, handle):
+        if isinstance(handle[0], list):
+            return handle
+        host, ev = handle
+        ev.synchronize()
+        both = host.tolist()
         return both[0], both[1]
 
     def _owner_general(self, got, got_states, m_dev, m_cap, seg, call0, k, seed, stream):
@@ -315,10 +335,19 @@ class PartitionedSampler:
         return int(b[0]) | (int(b[1]) << 1)
 
     def _sample_once(self, seeds, seed, first_call_id, first_call_ids=None, seeds_state=None):
+        for _ in self.steps(seeds, seed, first_call_id, first_call_ids, seeds_state):
+            pass
+        return self.out
+
+    def steps(self, seeds, seed, first_call_id, first_call_ids=None, seeds_state=None):
+        """One call as a GENERATOR: it yields right before every blocking size read-back (two per hop with an exchange: the
+        request split sizes, the reply split sizes), having enqueued everything up to there.  A scheduler that drives
+        several samplers' generators in a fixed order from one host thread (`interleave`) keeps the GPU busy with one
+        super-batch while the host waits for another's sizes.  Run to exhaustion it is `_sample_once`."""
         C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
         world, nb, B, H = self.world, self.nb, self.B, len(self.fanout)
         assert tuple(seeds.shape) == (nb, B) and seeds.device == self.dev
-        stream = _cabi.stream_ptr(self.dev)
+        stream = _cabi.stream_ptr(self.dev)   # the stream current when the generator STARTS: a scheduler keeps it per lane
         so = self.out.struct()
         seeds = seeds.contiguous()
         if self.exchange and first_call_ids is None:
@@ -346,7 +375,9 @@ class PartitionedSampler:
                 got, m_cap, m_dev = self.requests, cap, self.send_counts[1:]
                 seg = (C.c_int64 * 65)(0, cap)
             else:
-                send, recv = self._sizes(self.send_counts[:world])
+                pending = self._sizes_begin(self.send_counts[:world], 0)
+                yield ("request sizes", h)
+                send, recv = self._sizes_end(pending)
                 got = self._a2a(self.requests[:int(sum(send))], send, recv, "req_recv")
                 if self.filtered:
                     got_states = self._a2a(self.request_states[:int(sum(send))], send, recv, "st_recv")
@@ -365,7 +396,9 @@ class PartitionedSampler:
             if not self.exchange:
                 cnt_back, reply_back = cnt, reply
             else:
-                rc_send, rc_recv = self._sizes(self.reply_counts[:world])
+                pending = self._sizes_begin(self.reply_counts[:world], 1)
+                yield ("reply sizes", h)
+                rc_send, rc_recv = self._sizes_end(pending)
                 cnt_back = self._buf("cnt_back", self.request_cap, torch.int32)
                 n_back = int(sum(send))
                 cnt_back[:n_back] = self._a2a(cnt[:m_cap], recv, send, "cnt_recv")
@@ -376,7 +409,6 @@ class PartitionedSampler:
                                          C.c_int64(cap), C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H),
                                          ptr(self.ws), ptr(cnt_back), None if self.exchange else ptr(off), ptr(reply_back),
                                          C.c_int32(self.reply_format), stream))
-        return self.out
 
     def _owner_uniform(self, graph, got, m_dev, m_cap, seg, call0, k, seed, stream):
         """owner side, unweighted and unfiltered: the dedicated count / sample kernels of csrc/partition.hip"""
@@ -401,6 +433,107 @@ class PartitionedSampler:
         return cnt, off, reply
 
 
+def interleave(jobs, lanes, start, finish=None):
+    """Drives `jobs` generators, at most `lanes` at a time, from ONE host thread in a FIXED order: job i runs on lane
+    i % lanes; every tick advances the active lanes 0, 1, ... by one step each (a step = up to the generator's next yield, i.e.
+    up to its next blocking read-back).  The order depends on nothing but (number of jobs, lanes, steps per job), which are the
+    same on every rank -- so the collectives the steps enqueue on ONE communicator meet in the same order everywhere, which
+    thread-per-lane schedules cannot promise (SURVEY.md 8(e) mode 2: the exchange of one super-batch under the sampling of
+    the next).  start(i, lane) -> generator; finish(i, lane) is called when job i is exhausted, before its lane is reused."""
+    active = [None] * lanes            # (job index, generator) per lane
+    nxt = 0
+    while nxt < jobs or any(a is not None for a in active):
+        for lane in range(lanes):
+            if active[lane] is None and nxt < jobs and nxt % lanes == lane:
+                active[lane] = (nxt, start(nxt, lane))
+                nxt += 1
+            if active[lane] is None:
+                continue
+            i, gen = active[lane]
+            try:
+                next(gen)
+            except StopIteration:
+                if finish is not None:
+                    finish(i, lane)
+                active[lane] = None
+
+
+class PipelinedPartitionedSampler:
+    """`lanes` PartitionedSamplers (each with its own buffers, output slabs and HIP stream) driven by `interleave` over ONE
+    communicator: while the host waits for the split sizes of one super-batch, the kernels and collectives of the other
+    are already enqueued and run.  Legal with any number of ranks (round 3's thread-per-lane / communicator-per-lane form
+    was verified for one rank only and refused beyond)."""
+
+    def __init__(self, shard, n_batches, n_seeds, fanout, lanes=2, groups=None, **kw):
+        """groups: optionally one process group (communicator) per lane.  With ONE communicator the lanes' collectives queue
+        behind each other on its stream (a lane's tiny size exchange waits for the other lane's reply all-to-all and the
+        kernels that one waits for); a communicator per lane lets them pass each other -- and stays deadlock-free here,
+        because `interleave` enqueues every collective of every communicator in the same order on every rank (what
+        thread-per-lane schedules could not promise)."""
+        n_l = max(1, int(lanes))
+        if groups is not None:
+            assert len(groups) == n_l and "group" not in kw
+        self.samplers = [PartitionedSampler(shard, n_batches, n_seeds, fanout, **(dict(kw, group=groups[j]) if groups else kw))
+                         for j in range(n_l)]
+        dev = shard.ptrs.device
+        self.dev = dev
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.samplers] if dev.type == "cuda" else [None] * len(self.samplers)
+
+    def sample_many(self, n_jobs, seeds_of, seed, call_ids_of, consume, seeds_state_of=None):
+        """Super-batch i: seeds_of(i) -> [n_batches, n_seeds] seeds, call_ids_of(i) -> (this rank's first call id, every
+        rank's first call ids or None).  consume(i, out) runs when super-batch i is complete, on its lane's stream, before
+        the lane's slabs are reused.  Plain samplers only need this; under a filter / with weights the call's status word
+        is read when a super-batch ends (overflow or a non-positive weight sum raise: no silent retry inside a pipeline)."""
+        cur = torch.cuda.current_stream(self.dev) if self.dev.type == "cuda" else None
+        for st in self.streams:
+            if st is not None:
+                st.wait_stream(cur)
+
+        def on(lane):
+            return torch.cuda.stream(self.streams[lane]) if self.streams[lane] is not None else _Null()
+
+        def start(i, lane):
+            def run():
+                ps = self.samplers[lane]
+                with on(lane):
+                    ps._status_acc.zero_()
+                    first, all_first = call_ids_of(i)
+                    gen = ps.steps(seeds_of(i), seed, first, all_first, seeds_state_of(i) if seeds_state_of else None)
+                while True:
+                    with on(lane):
+                        try:
+                            next(gen)
+                        except StopIteration:
+                            return
+                    yield
+            return run()
+
+        def finish(i, lane):
+            ps = self.samplers[lane]
+            with on(lane):
+                if ps.general:
+                    word = ps._agreed_status()
+                    if word & 2:
+                        raise RuntimeError("weighted sampling met a non-positive running weight sum (the reference panics here)")
+                    if word & 1:
+                        raise RuntimeError("column-group workspace overflow inside a pipelined call: sample this super-batch "
+                                           "with PartitionedSampler.sample(), which retries")
+                consume(i, ps.out)
+
+        interleave(n_jobs, len(self.samplers), start, finish)
+        for st in self.streams:
+            if st is not None:
+                cur.wait_stream(st)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
                                filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), seeds_state=None,
                                packed_replies=None):
@@ -412,7 +545,20 @@ def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sample
 
 def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
                         _hop_fn=None):
-    """seeds: [n_batches, B] int64 on the shard's device; batch j of this rank has call id first_call_id + j.
+    """`ns_homo_partitioned_steps` run to its end."""
+    gen = ns_homo_partitioned_steps(shard, seeds, fanout, seed, first_call_id, sampler, group, _hop_fn)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as done:
+            return done.value
+
+
+def ns_homo_partitioned_steps(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
+                              _hop_fn=None):
+    """A generator (it yields before every size exchange, like PartitionedSampler.steps, so that `interleave` can drive
+    several calls over one communicator); its return value is the result.
+    seeds: [n_batches, B] int64 on the shard's device; batch j of this rank has call id first_call_id + j.
 
     Returns a list of per-batch (samples, rows, cols, edge_index, layer_offsets), equal to what the
     replicated-graph sampler returns for the same (seed, call id).  Everything stays flat (batch-major) on the
@@ -438,6 +584,7 @@ def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPL
             send_counts = torch.bincount(owner, minlength=world).tolist()
             req = torch.stack([f_vertex[perm], first_call_id + f_batch[perm], f_slot[perm]], dim=1)
             # ---- 2. sizes, then requests
+            yield ("request sizes", len(hops))
             recv_counts = _exchange_counts(send_counts, group, dev)
             got = _all_to_all_rows(req, send_counts, recv_counts, group)
             r_vertex, r_call, r_slot = got[:, 0], got[:, 1], got[:, 2]
@@ -451,6 +598,7 @@ def ns_homo_partitioned(shard, seeds, fanout, seed, first_call_id, sampler=SAMPL
             cnt_sorted = _all_to_all_rows(cnt_r, recv_counts, send_counts, group)
             peer_of_req = torch.repeat_interleave(torch.arange(world, **i64), torch.as_tensor(recv_counts, **i64))
             rep_send = torch.zeros(world, **i64).index_add_(0, peer_of_req, cnt_r).tolist()
+            yield ("reply sizes", len(hops))
             rep_recv = _exchange_counts(rep_send, group, dev)
             data_sorted = _all_to_all_rows(torch.stack([nbr_r, ep_r], dim=1), rep_send, rep_recv, group)
             # ---- 5. back to frontier (slot) order

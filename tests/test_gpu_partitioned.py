@@ -430,38 +430,45 @@ def _rccl_worker(port, q):
             for b in range(4):
                 x, y = got.batch(b, c), want.batch(b, c)
                 ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
-        # two super-batches in flight: a sampler, a stream, a host thread and a communicator per lane (bench.py --lanes)
-        import threading
-        lanes = 2
-        groups = [dist.new_group(ranks=[0]) for _ in range(lanes)]
-        samplers = [partitioned.PartitionedSampler(shard, 4, B, [6, 4], group=groups[j], force_exchange=True) for j in range(lanes)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
-        lane_seeds = [_cabi.seed_batches(33 + j, 900 + 10 * j, 4, B, n, dev) for j in range(lanes)]
-        results, errs = [None] * lanes, []
-
-        def lane(j):
-            try:
-                torch.cuda.set_device(dev)
-                with torch.cuda.stream(streams[j]):
-                    for _ in range(3):                      # the same call three times: buffers are reused under overlap
-                        results[j] = samplers[j].sample(lane_seeds[j], SEED, 900 + 10 * j)
-                    streams[j].synchronize()
-            except Exception as ex:  # noqa: BLE001
-                errs.append(repr(ex))
-
-        ts_ = [threading.Thread(target=lane, args=(j,)) for j in range(lanes)]
-        for t in ts_:
-            t.start()
-        for t in ts_:
-            t.join()
-        ok = ok and not errs
+        # super-batches in flight from ONE host thread over ONE communicator (round 4: PipelinedPartitionedSampler,
+        # bench.py --lanes): the steps of two samplers interleave in a fixed order; every lane's slabs are reused
+        errs = []
+        n_jobs = 5
+        job_seeds = [_cabi.seed_batches(33 + i, 900 + 10 * i, 4, B, n, dev) for i in range(n_jobs)]
         plain = dict(sampler=0, filter_mode=-1, forward=False, window=(0, 0))
-        for j in range(lanes):
-            want = _replicated_general(aptrs, aidx, ts, w, lane_seeds[j], states, [6, 4], 900 + 10 * j, plain)
+        pipe = partitioned.PipelinedPartitionedSampler(shard, 4, B, [6, 4], lanes=2, force_exchange=True)
+        kept = {}
+
+        def consume(i, out):
+            c = out.counts.clone()
+            kept[i] = (c, [tuple(t.clone() for t in out.batch(b, c.cpu())[:4]) + (out.batch(b, c.cpu())[4],) for b in range(4)])
+
+        pipe.sample_many(n_jobs, lambda i: job_seeds[i], SEED, lambda i: (900 + 10 * i, [900 + 10 * i]), consume)
+        torch.cuda.synchronize()
+        for i in range(n_jobs):
+            want = _replicated_general(aptrs, aidx, ts, w, job_seeds[i], states, [6, 4], 900 + 10 * i, plain)
             c = want.counts.cpu()
-            ok = ok and results[j] is not None and torch.equal(results[j].counts.cpu(), c)
+            ok = ok and i in kept and torch.equal(kept[i][0].cpu(), c)
             for b in range(4):
-                x, y = results[j].batch(b, c), want.batch(b, c)
+                y = want.batch(b, c)
+                x = kept[i][1][b]
+                ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+        # ... and under a filter with weights (the status word is read per super-batch)
+        case = FILTER_CASES[4]
+        pipe_g = partitioned.PipelinedPartitionedSampler(shard, 4, B, [6, 4], lanes=2, force_exchange=True, sampler=case["sampler"],
+                                                         filter_mode=case["filter_mode"], forward=case["forward"],
+                                                         window=case["window"])
+        kept.clear()
+        pipe_g.sample_many(3, lambda i: job_seeds[i], SEED, lambda i: (900 + 10 * i, [900 + 10 * i]), consume,
+                           seeds_state_of=lambda i: states)
+        torch.cuda.synchronize()
+        for i in range(3):
+            want = _replicated_general(aptrs, aidx, ts, w, job_seeds[i], states, [6, 4], 900 + 10 * i, case)
+            c = want.counts.cpu()
+            ok = ok and torch.equal(kept[i][0].cpu(), c)
+            for b in range(4):
+                y = want.batch(b, c)
+                x = kept[i][1][b]
                 ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
         q.put(("ok" if ok else "mismatch %r" % (errs,), calls, dist.get_backend()))
         dist.destroy_process_group()

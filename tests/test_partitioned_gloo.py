@@ -51,7 +51,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, sampler, q):
+def _worker(rank, world, port, sampler, q, pipelined=False):
     _paths()
     import orc
     from tch_geometric import partitioned
@@ -61,7 +61,31 @@ def _worker(rank, world, port, sampler, q):
     shard = partitioned.CscShard.from_full(torch.from_numpy(ptrs), torch.from_numpy(idx), rank, world)
     first = rank * PER_RANK
     seeds = torch.from_numpy(orc.seed_batches(5, first, PER_RANK, B, n))
-    res = partitioned.ns_homo_partitioned(shard, seeds, FANOUT, SEED, first, sampler=sampler, _hop_fn=_oracle_hop)
+    if not pipelined:
+        res = partitioned.ns_homo_partitioned(shard, seeds, FANOUT, SEED, first, sampler=sampler, _hop_fn=_oracle_hop)
+    else:
+        # every batch a super-batch of its own; two in flight from ONE thread over ONE communicator, in the fixed,
+        # rank-independent order of `interleave` (hop h of super-batch i + 1 is enqueued between the request and the reply
+        # exchange of super-batch i); a log of the steps shows the schedule really interleaves
+        res, log = [None] * PER_RANK, []
+
+        def start(i, lane):
+            def run():
+                gen = partitioned.ns_homo_partitioned_steps(shard, seeds[i:i + 1], FANOUT, SEED, first + i, sampler=sampler,
+                                                            _hop_fn=_oracle_hop)
+                while True:
+                    try:
+                        log.append((i, next(gen)))
+                    except StopIteration as done:
+                        res[i] = done.value[0]
+                        return
+                    yield
+            return run()
+
+        partitioned.interleave(PER_RANK, 2, start)
+        jobs = [i for i, _ in log]
+        assert any(a != b for a, b in zip(jobs, jobs[1:])) and jobs != sorted(jobs), "the schedule did not interleave"
+        q.put(("log%d" % rank, log))
     q.put((rank, [(s.tolist(), r.tolist(), c.tolist(), e.tolist(), lo) for s, r, c, e, lo in res]))
     dist.barrier()
     dist.destroy_process_group()
@@ -89,6 +113,51 @@ def test_two_rank_partitioned_equals_replicated(sampler):
             s, r, c, e, lo = got[rank][j]
             assert lo == o[4]
             assert s == o[0].tolist() and r == o[1].tolist() and c == o[2].tolist() and e == o[3].tolist()
+
+
+def test_two_rank_pipelined_schedule_equals_replicated():
+    """the pipelined schedule that is legal with several ranks -- one host thread, one communicator, a
+    fixed enqueue order -- gives the replicated result bit for bit, and both ranks walk the same step sequence."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 0, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2 * world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got["log0"] == got["log1"] and len(got["log0"]) == PER_RANK * 2 * len(FANOUT)   # two size exchanges per hop
+    import orc
+    ptrs, idx, n = _graph()
+    for rank in range(world):
+        seeds = orc.seed_batches(5, rank * PER_RANK, PER_RANK, B, n)
+        for j in range(PER_RANK):
+            o = orc.ns_homo(ptrs, idx, seeds[j], FANOUT, orc.rng_philox(SEED, rank * PER_RANK + j))
+            s, r, c, e, lo = got[rank][j]
+            assert lo == o[4]
+            assert s == o[0].tolist() and r == o[1].tolist() and c == o[2].tolist() and e == o[3].tolist()
+
+
+def test_interleave_order_is_fixed():
+    _paths()
+    from tch_geometric import partitioned
+    order = []
+
+    def start(i, lane):
+        def run():
+            for step in range(3):
+                order.append((i, lane, step))
+                yield
+        return run()
+
+    done = []
+    partitioned.interleave(5, 2, start, lambda i, lane: done.append(i))
+    assert done == [0, 1, 2, 3, 4]
+    assert order[:6] == [(0, 0, 0), (1, 1, 0), (0, 0, 1), (1, 1, 1), (0, 0, 2), (1, 1, 2)]
+    assert [(i, l) for i, l, s in order if s == 0] == [(0, 0), (1, 1), (2, 0), (3, 1), (4, 0)]
 
 
 def test_shards_tile_the_graph():
