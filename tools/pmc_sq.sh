@@ -18,10 +18,12 @@ for d in sorted(glob.glob("gpurun_out/pmc_sq_${tag}_*/")):
     for f in glob.glob(d + "*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            for key in ("win_gather", "win_emit", "win_scatter", "win_hist"):
+            for key in ("win_stage_gather", "win_stage_emit", "win_stage_first", "win_sort_fine", "win_scatter8",
+                        "win_gather", "win_emit", "win_scatter", "win_hist"):
                 if key in name:
                     direct = "DIRECT" if ("true>" in name.replace(" ", "") and key == "win_emit") else ""
                     acc[key + direct][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    break
 for k in sorted(acc):
     print(k)
     for c in sorted(acc[k]):
