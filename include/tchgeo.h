@@ -156,8 +156,8 @@ TG_API int tg_ns_homo_workspace_bytes_for(const tg_graph *csc, int64_t n_batches
 /* The workspace for a launch with THIS sampler / filter configuration: the window-ordered form's for the plain samplers
  * (as above); for the weighted sampler or a temporal filter with at most 256 batches, the workspace of the FLAT path -- the
  * launch then runs hop by hop over the whole device (tg_ns_hop_scan / tg_ns_hop_weighted_groups on all batches' frontiers
- * at once) instead of one workgroup per batch: 64 weighted batches of 1 024 seeds on RMAT-24 54 -> 15 ms, temporal 5.5 ->
- * 2.4 ms.  Results are tg_ns_homo_batched's bit for bit (the per-batch kernel runs behind the flat path whenever that could
+ * at once) instead of one workgroup per batch: 64 weighted batches of 1 024 seeds on RMAT-24 53 -> 15 ms, temporal 5.5 ->
+ * 2.3 ms; 8 batches 47 -> 2.2 / 5.2 -> 0.55 ms.  Results are tg_ns_homo_batched's bit for bit (the per-batch kernel runs behind the flat path whenever that could
  * not finish: a column-group bound reached, a non-positive weight sum).  0 bytes: the launch takes no workspace. */
 TG_API int tg_ns_homo_batched_workspace_bytes(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout,
                                        int32_t n_hops, const tg_ns_config *cfg, int64_t *n_bytes);

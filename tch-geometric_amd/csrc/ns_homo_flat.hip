@@ -5,9 +5,10 @@
 // batches of 1 024 seeds on RMAT-24 leave three quarters of the CUs idle while each workgroup inspects 3 * 10^7 edges
 // (weighted 54 ms, temporal 5.5 ms; through the flat hops 15.3 / 2.4 ms).  The reference has ONE entry point
 // (src/python.rs:210-257), so the C ABI switches by itself: with a workspace (tg_ns_homo_batched_workspace_bytes) a launch of
-// at most 256 weighted / 128 filtered batches runs, per hop,
+// at most 256 weighted / filtered batches runs, per hop,
 //   frontier   every batch's frontier slice -> one flat array (vertex, draw id = id_base + slot, call id = call + batch,
-//              filter state), padded with -1 to the hop's worst case per batch;
+//              filter state), the batches' REAL frontiers back to back (a one-workgroup scan of their lengths first), the
+//              unused tail up to the hop's worst case filled with -1: the flat hops' wavefronts over the tail leave at once;
 //   flat hop   tg_ns_hop_scan / tg_ns_hop_weighted_groups: the columns cut into 512-edge groups processed all over the
 //              device (the draws are named by (call id, slot): the same as the per-batch kernel's and the oracle's);
 //   emit       one workgroup per batch copies its slice of the compact hop output into the batch's slabs in slot order
@@ -38,6 +39,7 @@ struct FlatParams {
     uint64_t call_id;
     int64_t *samples, *rows, *cols, *edge_index, *layer_offsets, *counts, *states;
     FlatState *st;
+    int64_t *boff; // [n_batches + 1] start of every batch's slice in the hop's flat frontier
     int64_t *vertices, *ids, *call_ids, *fstates;                              // the hop's flat frontier [n_batches * pitch]
     int64_t *cnt, *offsets, *neighbors, *edge_ptrs, *parents, *states_out;     // the flat hop's outputs
 };
@@ -57,31 +59,64 @@ __global__ void flat_begin_kernel(const FlatParams p) {
     }
 }
 
+// boff = exclusive prefix of the batches' frontier lengths (n_batches <= 256: one workgroup, one pass)
+__global__ void __launch_bounds__(256) flat_offsets_kernel(const FlatParams p) {
+    __shared__ int64_t wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t len = tid < p.n_batches ? p.st[tid].end - p.st[tid].begin : 0;
+    int64_t incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int64_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry += wave_tot[w];
+    if (tid < p.n_batches) p.boff[tid] = carry + incl - len;
+    if (tid == p.n_batches - 1) p.boff[p.n_batches] = carry + incl;
+}
+
 __global__ void flat_frontier_kernel(const FlatParams p) {
-    const int64_t m = p.n_batches * p.pitch;
+    const int64_t m = p.n_batches * p.pitch, total = p.boff[p.n_batches];
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = j / p.pitch, i = j - b * p.pitch;
-        const FlatState st = p.st[b];
-        const int64_t slot = st.begin + i;
-        const bool live = slot < st.end;
-        p.vertices[j] = live ? p.samples[b * p.cap_nodes + slot] : -1; // the flat hops skip negative vertices
+        if (j >= total) { // the unused tail: the flat hops skip negative vertices
+            p.vertices[j] = -1;
+            p.ids[j] = 0;
+            p.call_ids[j] = 0;
+            p.fstates[j] = 0;
+            continue;
+        }
+        int lo = 0, hi = (int)p.n_batches; // the batch whose slice holds j: largest b with boff[b] <= j
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (p.boff[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int64_t b = lo;
+        const int64_t slot = p.st[b].begin + (j - p.boff[b]);
+        p.vertices[j] = p.samples[b * p.cap_nodes + slot];
         p.ids[j] = p.id_base + slot;
         p.call_ids[j] = (int64_t)(p.call_id + (uint64_t)b);
-        p.fstates[j] = (live && p.states) ? p.states[b * p.cap_nodes + slot] : 0;
+        p.fstates[j] = p.states ? p.states[b * p.cap_nodes + slot] : 0;
     }
 }
 
 __global__ void flat_emit_kernel(const FlatParams p) {
     const int64_t b = blockIdx.x;
     const FlatState st = p.st[b];
-    const int64_t base = p.offsets[b * p.pitch], tot = p.offsets[(b + 1) * p.pitch] - base;
+    const int64_t f0 = p.boff[b]; // the batch's slice of the flat frontier: [f0, boff[b + 1])
+    const int64_t base = p.offsets[f0], tot = p.offsets[p.boff[b + 1]] - base;
     int64_t *samples = p.samples + b * p.cap_nodes, *rows = p.rows + b * p.cap_edges;
     int64_t *cols = p.cols + b * p.cap_edges, *eidx = p.edge_index + b * p.cap_edges;
     for (int64_t q = threadIdx.x; q < tot; q += blockDim.x) {
         const int64_t e = st.ne + q;
         samples[p.n_seeds + e] = p.neighbors[base + q];                  // :215
         rows[e] = p.n_seeds + e;                                         // :217
-        cols[e] = st.begin + (p.parents[base + q] - b * p.pitch);
+        cols[e] = st.begin + (p.parents[base + q] - f0);
         eidx[e] = p.edge_ptrs[base + q];
         if (p.states) p.states[b * p.cap_nodes + p.n_seeds + e] = p.states_out[base + q];
     }
@@ -101,7 +136,7 @@ __global__ void flat_emit_kernel(const FlatParams p) {
 }
 
 struct FlatLayout {
-    size_t st, status, vertices, ids, call_ids, fstates, cnt, offsets, neighbors, edge_ptrs, parents, states_out, hop_ws, total;
+    size_t st, status, boff, vertices, ids, call_ids, fstates, cnt, offsets, neighbors, edge_ptrs, parents, states_out, hop_ws, total;
     int64_t m_max, out_max, group_cap, hop_ws_bytes;
 };
 
@@ -136,6 +171,7 @@ static int flat_layout(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, 
     };
     L->st = take((size_t)n_batches * sizeof(FlatState));
     L->status = take(256);
+    L->boff = take((size_t)(n_batches + 1) * 8);
     const size_t m8 = (size_t)L->m_max * 8, o8 = (size_t)L->out_max * 8;
     L->vertices = take(m8);
     L->ids = take(m8);
@@ -155,9 +191,10 @@ static int flat_layout(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, 
 } // namespace tg
 
 // measured on RMAT-24, 1 024 seeds, [15, 10] (profiles/r04/flat_scan_*.json; per-batch workgroups -> this path): weighted 8 /
-// 64 / 256 batches 47 -> 4.4, 54 -> 20, 118 -> 65 ms; temporal filter 5.2 -> 1.7, 5.6 -> 4.9, 10.4 -> 10.8 ms
-#define TG_NS_FLAT_MAX_BATCHES 256          /* weighted (with or without a filter) */
-#define TG_NS_FLAT_MAX_BATCHES_FILTER 128   /* unweighted under a filter: the per-batch kernel catches up sooner */
+// 64 / 256 batches 47 -> 2.2, 53 -> 15.2, 117 -> 57 ms; temporal filter 5.2 -> 0.55, 5.5 -> 2.3, 10.4 -> 6.9 ms; at 1 024
+// batches the per-batch kernel is the faster form again (157 against 220 ms weighted, 19 against 29 ms filtered)
+#define TG_NS_FLAT_MAX_BATCHES 256
+#define TG_NS_FLAT_MAX_BATCHES_FILTER 256
 
 static bool flat_applies(const tg_graph *csc, int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
                          const tg_ns_config *cfg) {
@@ -229,6 +266,7 @@ int tg_ns_homo_flat_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_
         p.states = filtered ? out->states : nullptr;
         p.st = reinterpret_cast<FlatState *>(w + L.st);
         int32_t *status = reinterpret_cast<int32_t *>(w + L.status);
+        p.boff = reinterpret_cast<int64_t *>(w + L.boff);
         p.vertices = reinterpret_cast<int64_t *>(w + L.vertices);
         p.ids = reinterpret_cast<int64_t *>(w + L.ids);
         p.call_ids = reinterpret_cast<int64_t *>(w + L.call_ids);
@@ -247,6 +285,7 @@ int tg_ns_homo_flat_launch(const tg_graph *csc, const int64_t *seeds, int64_t n_
             p.hop = h;
             p.pitch = pitch;
             const int64_t m = n_batches * pitch;
+            hipLaunchKernelGGL(flat_offsets_kernel, dim3(1), dim3(256), 0, stream, p);
             hipLaunchKernelGGL(flat_frontier_kernel, dim3((unsigned)std::min<int64_t>((m + 255) / 256, 8192)), dim3(256), 0,
                                stream, p);
             TG_LAUNCH_CHECK();

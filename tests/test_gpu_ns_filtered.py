@@ -169,7 +169,7 @@ def _flat_vs_batched(cabi, dev, ptrs, idx, seeds, fanout, sampler=0, weights=Non
     return a
 
 
-@pytest.mark.parametrize("nb", [8, 64, 128])
+@pytest.mark.parametrize("nb", [8, 64, 256])
 @pytest.mark.parametrize("case", ["dynamic_fwd", "static", "relative_bwd_repl", "weighted", "weighted_filtered"])
 def test_few_batches_take_the_flat_hops(cabi, dev, rmat13, nb, case):
     ptrs, idx, n = rmat13
@@ -217,7 +217,7 @@ def test_workspace_query_by_configuration(cabi, dev, rmat13):
     assert cabi.ns_homo_batched_workspace(g, 64, 32, [5, 5], dev, sampler=2) is not None           # few weighted batches: flat
     assert cabi.ns_homo_batched_workspace(g, 1024, 32, [5, 5], dev, sampler=2) is None             # many: a workgroup per batch
     assert cabi.ns_homo_batched_workspace(g, 64, 32, [5, 5], dev, filter_mode=2) is not None
-    assert cabi.ns_homo_batched_workspace(g, 256, 32, [5, 5], dev, filter_mode=2) is None           # filter only: up to 128
-    assert cabi.ns_homo_batched_workspace(g, 256, 32, [5, 5], dev, sampler=2) is not None
+    assert cabi.ns_homo_batched_workspace(g, 256, 32, [5, 5], dev, filter_mode=2) is not None
+    assert cabi.ns_homo_batched_workspace(g, 257, 32, [5, 5], dev, filter_mode=2) is None
     plain = cabi.ns_homo_batched_workspace(g, 64, 32, [5, 5], dev)
     assert plain is not None and plain.numel() == cabi.ns_homo_workspace(64, 32, [5, 5], dev, graph=g).numel()
