@@ -398,7 +398,10 @@ __global__ void win_stage_gather_kernel(const WinParams p, const StageBits sb) {
             if (cnt > 0) {
                 if (REPLACE || n > (uint32_t)k) {
                     const CallKey ck = p.call_keys[b];
-                    const uint64_t did = (uint64_t)(p.id_base + p.state[b].begin + (int64_t)idx);
+                    // the hop's frontier begins at the same slot in every batch when it is hop 1 (right behind the seeds):
+                    // no look-up of the batch's state then
+                    const int64_t fbegin = p.hop == 1 ? p.n_seeds : p.state[b].begin;
+                    const uint64_t did = (uint64_t)(p.id_base + fbegin + (int64_t)idx);
                     if (REPLACE) // sampling.rs:57-69
                         slot_draws<KMAX, true>(ck, did, n, k, pos);
                     else

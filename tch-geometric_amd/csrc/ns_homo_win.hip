@@ -784,7 +784,7 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_FOLD_HIST", 1),
         win_env_int("TG_WIN_EMIT_BLOCKS", 768),
         win_env_int("TG_WIN_STAGED", 0),
-        win_env_int("TG_WIN_STAGE_ROUND_CHUNKS", 8),
+        win_env_int("TG_WIN_STAGE_ROUND_CHUNKS", 2),
         win_env_int("TG_WIN_STAGE_GATHER_THREADS", 512),
         win_env_int("TG_WIN_STAGE_GATHER_BLOCKS", 512),
         win_env_int("TG_WIN_STAGE_EMIT_THREADS", 256),
