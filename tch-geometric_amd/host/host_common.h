@@ -328,7 +328,21 @@ inline void check_graph_ids(const Tensor &indices, int64_t hi, const c10::Device
 // set answers it with one hash probe instead of a binary search of the row.  Built on the first LARGE p != q call on a graph
 // (>= 2^20 walker steps: the build costs about two such calls) and kept per (ptrs, indices) identity + content version, least
 // recently used first out, within TG_EDGE_SET_GB (default 32) -- 16 bytes per edge; a graph whose set would not fit keeps the
-// binary search.  Same walks either way.
+// binary search.  Same walks either way ON SORTED ROWS: the reference's has_edge is a binary search of the row
+// (graph.rs:80-83), which may miss an edge of an unsorted row that the set would find -- so the build first checks that every
+// row ascends (one pass, remembered with the entry) and an unsorted graph keeps the binary search, whatever the call size.
+// The set is built on the stream current at build time; an event recorded behind the build makes a later call on another
+// stream wait for it.
+inline bool rows_ascend(const Tensor &ptrs, const Tensor &idx) {
+    const int64_t e = idx.numel();
+    if (e < 2) return true;
+    Tensor down = idx.narrow(0, 1, e - 1).lt(idx.narrow(0, 0, e - 1)); // down[i]: idx[i + 1] < idx[i]
+    Tensor starts = ptrs.narrow(0, 1, ptrs.numel() - 1).to(at::kLong) - ptrs.select(0, 0).to(at::kLong) - 1;
+    starts = starts.masked_select(starts.ge(0).logical_and(starts.lt(e - 1))); // i + 1 opens a row: no order across it
+    down.index_fill_(0, starts, false);
+    return !down.any().item<bool>();
+}
+
 struct EdgeSets {
     struct Entry {
         c10::weak_intrusive_ptr<c10::StorageImpl> sp, si;
@@ -336,12 +350,24 @@ struct EdgeSets {
         int64_t np, ni;
         uint32_t vp, vi;
         int dev;
-        Tensor set;
+        Tensor set; // undefined: the graph's rows do not ascend, no set is kept for it
+        std::shared_ptr<void> built; // hipEvent_t behind the build
         uint64_t used;
     };
     std::mutex mu;
     std::vector<Entry> entries;
     uint64_t tick = 0, hits = 0, builds = 0;
+    static std::shared_ptr<void> event_behind(void *stream) {
+        hipEvent_t ev = nullptr;
+        TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+        TORCH_CHECK(hipEventRecord(ev, (hipStream_t)stream) == hipSuccess, "hipEventRecord failed");
+        return std::shared_ptr<void>((void *)ev, [](void *e) { (void)hipEventDestroy((hipEvent_t)e); });
+    }
+    static const Tensor &wait_built(const Entry &e, const c10::Device &dev) {
+        if (e.built) TORCH_CHECK(hipStreamWaitEvent((hipStream_t)stream_of(dev), (hipEvent_t)e.built.get(), 0) == hipSuccess,
+                                 "hipStreamWaitEvent failed");
+        return e.set;
+    }
     static int64_t limit_bytes() {
         static const int64_t gb = [] {
             const char *v = getenv("TG_EDGE_SET_GB");
@@ -351,7 +377,7 @@ struct EdgeSets {
     }
     int64_t bytes_locked() const {
         int64_t b = 0;
-        for (const Entry &e : entries) b += (int64_t)e.set.nbytes();
+        for (const Entry &e : entries) b += e.set.defined() ? (int64_t)e.set.nbytes() : 0;
         return b;
     }
     // the set of (ptrs, idx) on `dev`, or an undefined tensor: not cached and `build` is false, or it does not fit
@@ -373,7 +399,7 @@ struct EdgeSets {
                     e.dev == dev.index()) {
                     e.used = ++tick;
                     ++hits;
-                    return e.set;
+                    return wait_built(e, dev);
                 }
                 ++i;
             }
@@ -382,17 +408,23 @@ struct EdgeSets {
         int64_t bytes = 0;
         check_rc(tg_edge_set_bytes(&g, &bytes));
         if (bytes > limit_bytes()) return Tensor();
-        Tensor set = at::empty({bytes / 8}, at::TensorOptions().dtype(at::kLong).device(dev));
-        check_rc(tg_edge_set_build(&g, set.data_ptr<int64_t>(), bytes, stream_of(dev)));
+        Tensor set;
+        std::shared_ptr<void> built;
+        if (rows_ascend(ptrs, idx)) {
+            set = at::empty({bytes / 8}, at::TensorOptions().dtype(at::kLong).device(dev));
+            check_rc(tg_edge_set_build(&g, set.data_ptr<int64_t>(), bytes, stream_of(dev)));
+            built = event_behind(stream_of(dev));
+        } else
+            bytes = 0;
         std::lock_guard<std::mutex> lock(mu);
         for (Entry &e : entries) // another thread built the same set meanwhile: keep one
             if (e.ip == ip && e.ii == ii && e.pp == ptrs.data_ptr() && e.pi == idx.data_ptr() && e.np == ptrs.numel() &&
                 e.ni == idx.numel() && e.vp == vp_now && e.vi == vi_now &&
                 e.dev == dev.index() && !e.sp.expired() && !e.si.expired()) {
                 e.used = ++tick;
-                return e.set;
+                return wait_built(e, dev);
             }
-        ++builds;
+        if (set.defined()) ++builds;
         while (!entries.empty() && bytes_locked() + bytes > limit_bytes()) {
             size_t lru = 0;
             for (size_t i = 1; i < entries.size(); ++i)
@@ -402,7 +434,7 @@ struct EdgeSets {
         entries.push_back(Entry{c10::weak_intrusive_ptr<c10::StorageImpl>(ptrs.storage().getWeakStorageImpl()),
                                 c10::weak_intrusive_ptr<c10::StorageImpl>(idx.storage().getWeakStorageImpl()), ip, ii,
                                 ptrs.data_ptr(), idx.data_ptr(), ptrs.numel(), idx.numel(), vp_now, vi_now,
-                                (int)dev.index(), set, ++tick});
+                                (int)dev.index(), set, built, ++tick});
         return set;
     }
     static EdgeSets &instance() {

@@ -86,7 +86,7 @@ class MiniBatch:
     """Mini-batch j of a SuperBatch.  Nothing is built until it is asked for: sizes are python ints, tensors are views
     (torch.narrow) made on first access -- handing a mini-batch out costs well under a microsecond of host time instead
     of the ~20 us an eagerly built container with a dozen attributes took (profiles/r01/loader_end_to_end.json)."""
-    __slots__ = ("_sb", "_j", "_cache")
+    __slots__ = ("_sb", "_j", "_cache", "__dict__")   # __dict__: a consumer may hang its own attributes on a mini-batch
 
     def __init__(self, sb, j):
         self._sb, self._j, self._cache = sb, j, None
@@ -155,7 +155,7 @@ class NeighborLoader:
                 self._node_attrs.append((key, value.to(self.device)))
             elif kind == "edge":
                 self._edge_attrs.append((key, value.to(self.device)))
-        self._slabs = [None, None]          # two slab sets: one being consumed, one being sampled
+        self._pool = []                     # slab sets of finished iterators (each live iterator owns its own)
         self._ws = None
         self._side = None
         self.epoch = 0
@@ -165,17 +165,19 @@ class NeighborLoader:
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     # ---- stage 1 (side stream): sample G mini-batches into slab set `which`, sizes -> pinned host memory
-    def _sample(self, which, seeds: Tensor, first_batch: int):
+    def _sample(self, slabs, which, seeds: Tensor, first_batch: int):
+        """`slabs` is the iterator's own set: slots 0 / 1 for full launches (one consumed, one sampled), "ragged" for the
+        epoch's last, narrower mini-batch -- so that one neither replaces the big slabs nor is replaced by them"""
         G, B = seeds.shape
         H = len(self.fanout)
-        slab = self._slabs[which]
+        slab = slabs.get(which)
         if slab is None or slab["out"].n_batches < G or slab["out"].n_seeds != B:
-            cap = max(G, min(self.prefetch, len(self)))
+            cap = G if which == "ragged" else max(G, min(self.prefetch, len(self)))
             slab = {"out": _cabi.NsBatchedOut(cap, B, self.fanout, self.device),
                     "counts": torch.empty((cap, 2), dtype=torch.int64).pin_memory(),
                     "lo": torch.empty((cap, max(H, 1), 3), dtype=torch.int64).pin_memory(),
                     "free": None}
-            self._slabs[which] = slab
+            slabs[which] = slab
         if G >= 2048 and self._ws is None:   # many batches per launch: the window-ordered form pays (DESIGN.md 4.1b)
             self._ws = _cabi.ns_homo_workspace(max(G, min(self.prefetch, len(self))), B, self.fanout, self.device)
         cur = torch.cuda.current_stream(self.device)
@@ -195,12 +197,11 @@ class NeighborLoader:
             done = torch.cuda.Event()
             done.record(side)
         seeds.record_stream(side)
-        return (which, G, B, first_batch, done)
+        return (slab, G, B, first_batch, done)
 
     # ---- stage 2 (caller's stream): flatten, gather the attribute rows
     def _finish(self, ticket) -> SuperBatch:
-        which, G, B, first_batch, done = ticket
-        slab = self._slabs[which]
+        slab, G, B, first_batch, done = ticket
         out = slab["out"]
         done.synchronize()                   # the host needs the sizes; the device work it waits for is long done
         cur = torch.cuda.current_stream(self.device)
@@ -248,13 +249,22 @@ class NeighborLoader:
             work.append((nodes[start * B:(start + G) * B].reshape(G, B), batch0 + start))
         if not self.drop_last and n_full * B < n:               # ragged last mini-batch: its own launch
             work.append((nodes[n_full * B:].reshape(1, -1), batch0 + n_full))
+        # this iterator's own slabs (two iterators alive at once -- zip(loader, loader), a restart after an abandoned
+        # epoch -- must not sample into each other's); they go back to the pool when the iterator ends or is dropped
+        slabs = self._pool.pop() if self._pool else {}
+        which_of = lambda i: "ragged" if work[i][0].shape[1] != B else i & 1
         pending = None
-        for i, (seeds, first) in enumerate(work):
-            if pending is None:
-                pending = self._sample(i & 1, seeds, first)
-            ticket = pending
-            pending = self._sample((i + 1) & 1, *work[i + 1]) if i + 1 < len(work) else None
-            yield self._finish(ticket)
+        try:
+            for i in range(len(work)):
+                if pending is None:
+                    pending = self._sample(slabs, which_of(i), *work[i])
+                ticket = pending
+                pending = self._sample(slabs, which_of(i + 1), *work[i + 1]) if i + 1 < len(work) else None
+                yield self._finish(ticket)
+        finally:
+            if pending is not None:          # abandoned with a launch in flight: it still writes into these slabs
+                pending[4].synchronize()
+            self._pool.append(slabs)
 
     def __iter__(self) -> Iterator[MiniBatch]:
         for sb in self.super_batches():

@@ -129,3 +129,38 @@ def test_out_of_range_input_nodes_raise():
     for bad in ([0, 500], [-1, 3]):
         with pytest.raises(IndexError):
             NeighborLoader(g, [3], input_nodes=torch.tensor(bad), batch_size=2)
+
+
+def test_two_live_iterators_and_an_abandoned_epoch():
+    """two iterators over ONE loader (zip(loader, loader); a restart after `break`) own their slab sets: neither's
+    prefetched launch lands in the slabs the other's pending mini-batches are cut from; the ragged last mini-batch has
+    its own small slab; a mini-batch takes user attributes"""
+    from tch_geometric.loader import NeighborLoader
+    g, ei, x, y, ea = _graph(seed=4)
+    ptrs, idx, perm = orc.to_csc(ei, 500)
+    loader = NeighborLoader(g, [5, 4], batch_size=64, prefetch=2, seed=9, call_id0=0)
+
+    def check(b, epoch, j):
+        seeds = np.arange(j * 64, min((j + 1) * 64, 500))
+        o = orc.ns_homo(ptrs, idx, seeds, [5, 4], orc.rng_philox(9, epoch * 8 + j))
+        assert b.call_id == epoch * 8 + j
+        assert np.array_equal(b.n_id.cpu().numpy(), o[0]) and np.array_equal(b.e_id.cpu().numpy(), perm[o[3]])
+        assert np.array_equal(b.x.cpu().numpy(), x[o[0]])
+
+    n = 0
+    for j, (u, v) in enumerate(zip(loader, loader)):           # epochs 0 and 1, interleaved
+        check(u, 0, j)
+        check(v, 1, j)
+        u.note = "mine"                                        # a consumer's own attribute
+        assert u.note == "mine" and not hasattr(v, "note")
+        n += 1
+    assert n == 8 and len(loader._pool) == 2
+    it = iter(loader)                                          # epoch 2, abandoned with its next launch in flight
+    first = next(it)
+    check(first, 2, 0)
+    it.close()
+    for j, b in enumerate(loader):                             # epoch 3 reuses pooled slabs, ragged one included
+        check(b, 3, j)
+    big = {id(s["out"]) for slabs in loader._pool for k, s in slabs.items() if k != "ragged"}
+    rag = [s["out"] for slabs in loader._pool for k, s in slabs.items() if k == "ragged"]
+    assert len(loader._pool) == 2 and len(big) <= 4 and all(r.n_batches == 1 and r.n_seeds == 500 - 7 * 64 for r in rag)

@@ -201,6 +201,44 @@ def test_large_node2vec_calls_build_and_reuse_the_edge_set(tg):
     assert tg.graph_cache_info()["edge_sets"] == 0
 
 
+def test_unsorted_rows_keep_the_binary_search_whatever_the_call_size(tg):
+    """has_edge is the reference's binary search of the row (graph.rs:80-83): on rows that do not ascend it can miss an
+    edge the hash set would find, so such a graph never gets a set -- small and large calls, first or later, walk alike
+    (and like the oracle, which searches the same way); a call on another stream waits for a set built elsewhere"""
+    rs = np.random.default_rng(22)
+    n = 1 << 12
+    ei = np.stack([rs.integers(0, n, n * 12), rs.integers(0, n, n * 12)])
+    ptrs, idx, _ = orc.to_csr(ei, n)
+    mixed = idx.copy()
+    for v in range(n):                                                      # every row in a random order
+        mixed[ptrs[v]:ptrs[v + 1]] = rs.permutation(mixed[ptrs[v]:ptrs[v + 1]])
+    assert not np.array_equal(mixed, idx)
+    P, I = torch.from_numpy(ptrs).cuda(), torch.from_numpy(mixed).cuda()
+    tg.graph_cache_clear()
+    builds0 = tg.graph_cache_info()["edge_set_builds"]                      # the counters run on across clears
+    small, big = rs.integers(0, n, 100), rs.integers(0, n, 1 << 15)
+    tg.seed(9)
+    w0 = tg.random_walk(P, I, torch.from_numpy(small).cuda(), 20, 0.5, 2.0)
+    w1 = tg.random_walk(P, I, torch.from_numpy(big).cuda(), 40, 0.5, 2.0)           # 1.3 M steps: would build a set
+    info = tg.graph_cache_info()
+    assert info["edge_set_builds"] == builds0 and info["edge_set_bytes"] == 0
+    w2 = tg.random_walk(P, I, torch.from_numpy(small).cuda(), 20, 0.5, 2.0)
+    assert tg.graph_cache_info()["edge_set_builds"] == builds0
+    for w, s, L, c in ((w0, small, 20, 0), (w1, big, 40, 1), (w2, small, 20, 2)):
+        assert np.array_equal(_np(w), orc.random_walk(ptrs, mixed, s, L, 0.5, 2.0, orc.rng_philox(9, c)))
+    # sorted rows: the set built on the default stream serves a call on another stream (event behind the build)
+    Is = torch.from_numpy(idx).cuda()
+    tg.seed(9)
+    tg.random_walk(P, Is, torch.from_numpy(big).cuda(), 40, 0.5, 2.0)
+    assert tg.graph_cache_info()["edge_set_builds"] == builds0 + 1
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        w = tg.random_walk(P, Is, torch.from_numpy(small).cuda(), 20, 0.5, 2.0)
+    side.synchronize()
+    assert np.array_equal(_np(w), orc.random_walk(ptrs, idx, small, 20, 0.5, 2.0, orc.rng_philox(9, 1)))
+    tg.graph_cache_clear()
+
+
 def test_out_of_range_node_ids_raise_instead_of_faulting(tg):
     """the reference panics (index out of bounds) on a node id outside the graph; here: IndexError, no device fault"""
     P, I = torch.tensor([0, 1, 2]).cuda(), torch.tensor([1, 0]).cuda()       # 2 nodes
