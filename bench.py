@@ -43,6 +43,9 @@ def parse_args(argv=None):
                     help="sets of output slabs + workspace to allocate at start-up; the launch is timed once on each and "
                          "the fastest set is kept, the others freed (where an allocation lands decides 5-10 %% of the "
                          "launch time, DESIGN.md 4.1b); 1 = take the first")
+    ap.add_argument("--replies", choices=["auto", "compact"], default="auto",
+                    help="--mode partitioned: auto = fixed-size slot replies where they apply (one size read-back per hop); "
+                         "compact = counts + entries (two read-backs per hop), the round-2/3 protocol")
     ap.add_argument("--mode", choices=["replicated", "partitioned"], default="replicated",
                     help="replicated: CSC on every rank, seed batches sharded (the headline).  partitioned: every rank owns "
                          "the columns of a contiguous vertex range; remote neighbours are fetched by all-to-all (cfg5 shape)")
@@ -497,7 +500,8 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
     # enqueues every collective of every lane in a fixed, rank-independent order (partitioned.interleave)
     groups = [dist.new_group(ranks=list(range(world))) for _ in range(lanes)] if (exchanging and lanes > 1) else None
     pipe = partitioned.PipelinedPartitionedSampler(shard, G, B, fanout, lanes=lanes, groups=groups,
-                                                   force_exchange=args.force_exchange)
+                                                   force_exchange=args.force_exchange,
+                                                   slot_replies=None if args.replies == "auto" else False)
     ps = pipe.samplers[0]
     firsts = [sharding.rank_batch_range(r, world, (W + K) * G)[0] for r in range(world)]
     first = firsts[rank]
@@ -540,12 +544,15 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
                         "CSC RANGE-PARTITIONED over %d rank(s)" % (args.scale, fanout, B, world),
             "step": "one PartitionedSampler.sample() over %d seed batches per rank" % G,
             "batches_per_step_per_rank": G,
-            "parallelism": "range-partitioned CSC (contiguous vertex ranges) over %d rank(s); per hop requests and compact "
+            "parallelism": "range-partitioned CSC (contiguous vertex ranges) over %d rank(s); per hop requests and %s "
                            "replies travel by all_to_all_single (RCCL)%s" %
-                           (world, "" if world > 1 else ("; one rank exchanging with itself over RCCL (all collectives and "
+                           (world, "fixed-size slot" if ps.slots else "compact", "" if world > 1 else ("; one rank exchanging with itself over RCCL (all collectives and "
                                                          "read-backs of the multi-rank protocol run)" if args.force_exchange
                                                          else "; one rank: no exchange, no host read-back")),
-            "reply_entry_bytes": 8 * ps.reply_words,
+            "replies": ({"form": "slots", "bytes_per_request_by_hop": [4 * w for w in ps.slot_words],
+                         "size_read_backs_per_hop": 1 if exchanging else 0} if ps.slots else
+                        {"form": "compact", "bytes_per_entry": 8 * ps.reply_words,
+                         "size_read_backs_per_hop": 2 if exchanging else 0}),
             "lanes": lanes,
             "avg_call_ms_this_rank": sum(ms) / len(ms),
             "shard_build_s": round(t_build, 2),

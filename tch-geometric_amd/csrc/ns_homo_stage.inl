@@ -302,52 +302,7 @@ __global__ void __launch_bounds__(1024) win_fine_starts_kernel(const WinParams p
 // caller gave none) -- per LAUNCH, uniform, passed as kernel arguments; the host picks W so that 40 + k (bv + bp) bits fit.
 // RMAT-24, k = 10: 40 + 10 * (24 + 19) = 470 bits: one chunk.  Because the chosen POSITIONS travel with the gathered
 // neighbours, the emit pass computes no draws: it is a pure stream (the round-3 form recomputed them, and the two passes
-// then both hung on the vector ALUs).
-struct StageBits {
-    int32_t bv, bp;
-};
-__host__ __device__ inline int stage_bits_of(uint64_t max_value) { // bits that hold 0 .. max_value
-    int b = 1;
-    while (b < 64 && (max_value >> b) != 0) ++b;
-    return b;
-}
-__host__ __device__ inline int stage_slot_bits(int k, StageBits sb) { return 40 + k * (sb.bv + sb.bp); }
-
-// LDS bit-stream writer / reader over a lane's row of the tile (uniform control flow: bv, bp and the unrolled slot index
-// are the same for every lane, so `fill` and the word index are scalars)
-struct BitWriter {
-    uint32_t *row;
-    uint64_t acc;
-    int fill, w;
-    __device__ __forceinline__ void push(uint32_t v, int bits) { // bits <= 32, v < 2^bits
-        acc |= (uint64_t)v << fill;
-        fill += bits;
-        if (fill >= 32) {
-            row[w++] = (uint32_t)acc;
-            acc >>= 32;
-            fill -= 32;
-        }
-    }
-    __device__ __forceinline__ void finish(int n_words) {
-        if (fill > 0) row[w++] = (uint32_t)acc;
-        for (; w < n_words; ++w) row[w] = 0u;
-    }
-};
-struct BitReader {
-    const uint32_t *row;
-    uint64_t acc;
-    int fill, w;
-    __device__ __forceinline__ uint32_t pop(int bits) { // bits <= 32
-        if (fill < bits) {
-            acc |= (uint64_t)row[w++] << fill;
-            fill += 32;
-        }
-        const uint32_t v = (uint32_t)acc & (bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u));
-        acc >>= bits;
-        fill -= bits;
-        return v;
-    }
-};
+// then both hung on the vector ALUs).  StageBits / BitWriter / BitReader: stage_bits.h.
 
 // ---------------------------------------------------------------- G: window-ordered gather into the stage slots
 // W = words per stage slot; KMAX = unroll bound of the slot loops (>= the hop's fan-out).

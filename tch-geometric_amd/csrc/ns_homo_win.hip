@@ -30,6 +30,7 @@
 #include <mutex>
 
 #include "ns_tickets.h"
+#include "stage_bits.h"
 #include "tg_device.h"
 #include "tg_host.h"
 

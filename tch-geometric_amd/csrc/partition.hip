@@ -22,7 +22,12 @@
 //                      copies its frontier's replies in slot order (the reference's output order,
 //                      neighbor_sampling.rs:195-218) into the slabs (counts -> LDS scan -> LDS staging -> coalesced
 //                      writes) and advances the batch state.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "ns_tickets.h"
+#include "stage_bits.h"
 #include "tg_device.h"
 #include "tg_host.h"
 
@@ -179,16 +184,11 @@ __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const PartRe
         }
 }
 
-// world == 1: the frontier order IS the request order
-__global__ void part_identity_kernel(const PartRequest *__restrict__ req_in, const unsigned long long *n_req,
-                                     PartRequest *req_out, uint32_t *req_pos, int64_t *send_counts,
-                                     const int64_t *rstate_in, int64_t *rstate_out) {
+// world == 1: the frontier order IS the request order (part_requests_kernel wrote the send buffer itself)
+__global__ void part_identity_kernel(const unsigned long long *n_req, uint32_t *req_pos, int64_t *send_counts) {
     const uint64_t n = *n_req;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        req_out[j] = req_in[j];
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
         req_pos[j] = (uint32_t)j;
-        if (rstate_out) rstate_out[j] = rstate_in[j];
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         send_counts[0] = (int64_t)n;
         send_counts[1] = (int64_t)n;
@@ -207,6 +207,7 @@ __host__ __device__ inline bool part_reply_has_state(int format) {
 struct PartOwnerParams {
     const int64_t *ptrs, *indices;
     const uint32_t *indices32; // optional u32 shadow of `indices`
+    const uint32_t *ptrs32;    // optional u32 shadow of `ptrs` (a shard of < 2^32 edges)
     int64_t n_major, v_lo, e_lo;
     const PartRequest *req;
     const int64_t *m_dev; // number of requests (device)
@@ -336,7 +337,14 @@ struct PartSortParams {
     int64_t v_lo, n_major;
     int32_t shift, n_windows;
     uint32_t *vtab, *hist, *base, *perm;
+    struct PartSorted *sorted; // optional: the requests themselves in window order (slot replies) instead of `perm`
 };
+struct PartSorted { // 16 bytes: a request moved into window order
+    uint32_t v;     // vertex rebased to the shard (0xffffffff: not this shard's)
+    uint32_t j;     // its index in arrival order = where its slot goes
+    uint32_t batch, slot;
+};
+static_assert(sizeof(PartSorted) == 16, "sorted request layout");
 __global__ void psort_vtab_kernel(const PartSortParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n_windows) return;
@@ -434,8 +442,15 @@ __global__ void __launch_bounds__(PSORT_THREADS) psort_scatter_kernel(const Part
     __syncthreads();
     const int64_t m = *p.m_dev;
     for (int64_t t0 = (int64_t)blockIdx.x * 4096; t0 < m; t0 += (int64_t)gridDim.x * 4096)
-        for (int64_t j = t0 + threadIdx.x; j < min(m, t0 + 4096); j += blockDim.x)
-            p.perm[atomicAdd(&cur[psort_window(lvtab, p.n_windows, p.req[j].vertex - p.v_lo, p.n_major)], 1u)] = (uint32_t)j;
+        for (int64_t j = t0 + threadIdx.x; j < min(m, t0 + 4096); j += blockDim.x) {
+            const PartRequest r = p.req[j];
+            const int64_t w = r.vertex - p.v_lo;
+            const uint32_t at = atomicAdd(&cur[psort_window(lvtab, p.n_windows, w, p.n_major)], 1u);
+            if (p.sorted)
+                p.sorted[at] = PartSorted{(w >= 0 && w < p.n_major) ? (uint32_t)w : 0xffffffffu, (uint32_t)j, r.batch, r.slot};
+            else
+                p.perm[at] = (uint32_t)j;
+        }
 }
 
 // part_sample_kernel over the SORTED order: lane <- request perm[i]; the replies of a request go to off[request]
@@ -686,6 +701,8 @@ __global__ void part_emit_kernel(const PartEmitParams p) {
     }
 }
 
+#include "partition_slots.inl"
+
 // ---------------------------------------------------------------- exclusive prefix of u32 counts, length on the device
 // (the host only knows an upper bound of the number of requests; scanning that bound would cost 5x the work)
 constexpr int PSCAN_BLOCKS = PSCAN_BLOCKS_HOST, PSCAN_THREADS = 256;
@@ -810,12 +827,14 @@ extern "C" int tg_part_requests(const tg_ns_out *out, int64_t n_batches, int64_t
     TG_REQUIRE(!request_states || out->states, "tg_part_requests: request states need the `states` slab");
     int64_t *rstate_in = request_states ? reinterpret_cast<int64_t *>(w + L.rstate_in) : nullptr;
     TG_HIP(hipMemsetAsync(n_req, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(part_requests_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, out->samples, out->states,
-                       out->cap_nodes, state, n_req, req_in, rstate_in);
-    if (world == 1) {
-        hipLaunchKernelGGL(part_identity_kernel, dim3(part_grid(request_cap, 256, 4096)), dim3(256), 0, s, req_in, n_req,
-                           static_cast<PartRequest *>(requests), req_pos, send_counts, rstate_in, request_states);
+    if (world == 1) { // the frontier order IS the request order: straight into the send buffer
+        hipLaunchKernelGGL(part_requests_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, out->samples, out->states,
+                           out->cap_nodes, state, n_req, static_cast<PartRequest *>(requests), request_states);
+        hipLaunchKernelGGL(part_identity_kernel, dim3(part_grid(request_cap, 256, 4096)), dim3(256), 0, s, n_req, req_pos,
+                           send_counts);
     } else {
+        hipLaunchKernelGGL(part_requests_kernel, dim3((unsigned)n_batches), dim3(256), 0, s, out->samples, out->states,
+                           out->cap_nodes, state, n_req, req_in, rstate_in);
         hipLaunchKernelGGL(part_hist_kernel, dim3(PART_BLOCKS), dim3(PART_THREADS), 0, s, req_in, n_req, shard_size,
                            (int)world, hist);
         hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(64), 0, s, hist, PART_BLOCKS, (int)world, base, send_counts);
@@ -840,6 +859,7 @@ static int part_owner_params(tg::PartOwnerParams &p, const tg_graph *shard, int6
     p.ptrs = shard->ptrs;
     p.indices = shard->indices;
     p.indices32 = shard->indices32;
+    p.ptrs32 = shard->ptrs32;
     p.n_major = shard->n_major;
     p.v_lo = v_lo;
     p.e_lo = e_lo;
@@ -915,7 +935,7 @@ extern "C" int tg_part_sample(const tg_graph *shard, int64_t v_lo, int64_t e_lo,
 }
 
 struct PartSortLayout {
-    size_t vtab, hist, base, perm, total;
+    size_t vtab, hist, base, perm, sorted, keys, total;
 };
 static PartSortLayout part_sort_layout(int64_t m_cap) {
     PartSortLayout L;
@@ -929,8 +949,44 @@ static PartSortLayout part_sort_layout(int64_t m_cap) {
     L.hist = take((size_t)tg::PSORT_BLOCKS * tg::PSORT_MAX_WINDOWS * 4);
     L.base = take((size_t)(tg::PSORT_MAX_WINDOWS + 8) * 4);
     L.perm = take((size_t)(m_cap > 0 ? m_cap : 1) * 4);
+    L.sorted = take((size_t)(m_cap > 0 ? m_cap : 1) * 16);
+    L.keys = take((size_t)tg::PART_MAX_WORLD * 4096 * 8); // PART_KEY_CAP call keys per requesting rank
     L.total = at;
     return L;
+}
+
+// the window order of a hop's requests (psort_*): -> the permutation in the workspace
+static int part_order_requests(const tg::PartOwnerParams &p, const tg_graph *shard, int64_t v_lo, const int64_t *m_dev,
+                               void *workspace, const PartSortLayout &L, hipStream_t s, const uint32_t **perm,
+                               const tg::PartSorted **sorted = nullptr) {
+    unsigned char *w = static_cast<unsigned char *>(workspace);
+    tg::PartSortParams sp;
+    sp.req = p.req;
+    sp.m_dev = m_dev;
+    sp.ptrs = shard->ptrs;
+    sp.v_lo = v_lo;
+    sp.n_major = shard->n_major;
+    const int elem = shard->indices32 ? 4 : 8;
+    int shift = 0;
+    while (((int64_t)elem << shift) < (512 << 10)) ++shift; // 512 KB of the gathered array per window ...
+    while (((shard->n_edges >> shift) + 1) > tg::PSORT_MAX_WINDOWS) ++shift; // ... as far as the counters go
+    sp.shift = shift;
+    sp.n_windows = (int32_t)((shard->n_edges >> shift) + 1);
+    sp.vtab = reinterpret_cast<uint32_t *>(w + L.vtab);
+    sp.hist = reinterpret_cast<uint32_t *>(w + L.hist);
+    sp.base = reinterpret_cast<uint32_t *>(w + L.base);
+    sp.perm = reinterpret_cast<uint32_t *>(w + L.perm);
+    sp.sorted = sorted ? reinterpret_cast<tg::PartSorted *>(w + L.sorted) : nullptr;
+    hipLaunchKernelGGL(tg::psort_vtab_kernel, dim3((sp.n_windows + 255) / 256), dim3(256), 0, s, sp);
+    hipLaunchKernelGGL(tg::psort_hist_kernel, dim3(tg::PSORT_BLOCKS), dim3(tg::PSORT_THREADS), 0, s, sp);
+    hipLaunchKernelGGL(tg::psort_colscan_kernel, dim3((sp.n_windows + 63) / 64), dim3(64 * tg::PSORT_SCAN_GROUPS), 0, s, sp,
+                       tg::PSORT_BLOCKS);
+    hipLaunchKernelGGL(tg::psort_basescan_kernel, dim3(1), dim3(1024), 0, s, sp);
+    hipLaunchKernelGGL(tg::psort_scatter_kernel, dim3(tg::PSORT_BLOCKS), dim3(tg::PSORT_THREADS), 0, s, sp);
+    TG_LAUNCH_CHECK();
+    if (perm) *perm = sp.perm;
+    if (sorted) *sorted = sp.sorted;
+    return TG_OK;
 }
 
 static int64_t g_part_order_min_requests = (int64_t)1 << 21, g_part_order_min_edges = (int64_t)1 << 24;
@@ -972,37 +1028,16 @@ extern "C" int tg_part_sample_ws(const tg_graph *shard, int64_t v_lo, int64_t e_
     p.reply = reply;
     p.reply_counts = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    unsigned char *w = static_cast<unsigned char *>(workspace);
-    tg::PartSortParams sp;
-    sp.req = p.req;
-    sp.m_dev = m_dev;
-    sp.ptrs = shard->ptrs;
-    sp.v_lo = v_lo;
-    sp.n_major = shard->n_major;
-    const int elem = shard->indices32 ? 4 : 8;
-    int shift = 0;
-    while (((int64_t)elem << shift) < (512 << 10)) ++shift; // 512 KB of the gathered array per window ...
-    while (((shard->n_edges >> shift) + 1) > tg::PSORT_MAX_WINDOWS) ++shift; // ... as far as the counters go
-    sp.shift = shift;
-    sp.n_windows = (int32_t)((shard->n_edges >> shift) + 1);
-    sp.vtab = reinterpret_cast<uint32_t *>(w + L.vtab);
-    sp.hist = reinterpret_cast<uint32_t *>(w + L.hist);
-    sp.base = reinterpret_cast<uint32_t *>(w + L.base);
-    sp.perm = reinterpret_cast<uint32_t *>(w + L.perm);
-    hipLaunchKernelGGL(tg::psort_vtab_kernel, dim3((sp.n_windows + 255) / 256), dim3(256), 0, s, sp);
-    hipLaunchKernelGGL(tg::psort_hist_kernel, dim3(tg::PSORT_BLOCKS), dim3(tg::PSORT_THREADS), 0, s, sp);
-    hipLaunchKernelGGL(tg::psort_colscan_kernel, dim3((sp.n_windows + 63) / 64), dim3(64 * tg::PSORT_SCAN_GROUPS), 0, s, sp,
-                       tg::PSORT_BLOCKS);
-    hipLaunchKernelGGL(tg::psort_basescan_kernel, dim3(1), dim3(1024), 0, s, sp);
-    hipLaunchKernelGGL(tg::psort_scatter_kernel, dim3(tg::PSORT_BLOCKS), dim3(tg::PSORT_THREADS), 0, s, sp);
-    TG_LAUNCH_CHECK();
+    const uint32_t *perm = nullptr;
+    rc = part_order_requests(p, shard, v_lo, m_dev, workspace, L, s, &perm);
+    if (rc != TG_OK) return rc;
     const int n_waves = 4;
     const size_t lds = (size_t)n_waves * (128 * sizeof(int64_t) + (size_t)64 * fanout * 4 + (((size_t)64 * fanout + 15) & ~(size_t)15));
     const unsigned grid = 1024; // a multiple of 8: eight groups of equal size
     if (fanout <= 16)
-        hipLaunchKernelGGL(tg::part_sample_sorted_kernel<16>, dim3(grid), dim3(64 * n_waves), lds, s, p, sp.perm);
+        hipLaunchKernelGGL(tg::part_sample_sorted_kernel<16>, dim3(grid), dim3(64 * n_waves), lds, s, p, perm);
     else
-        hipLaunchKernelGGL(tg::part_sample_sorted_kernel<32>, dim3(grid), dim3(64 * n_waves), lds, s, p, sp.perm);
+        hipLaunchKernelGGL(tg::part_sample_sorted_kernel<32>, dim3(grid), dim3(64 * n_waves), lds, s, p, perm);
     TG_LAUNCH_CHECK();
     return TG_OK;
 }
@@ -1104,6 +1139,166 @@ extern "C" int tg_part_emit(const tg_ns_out *out, int64_t n_batches, int64_t n_s
     const size_t lds = ((((size_t)(PART_CHUNKS_PER_ROUND + 1) * 4) + 15) & ~(size_t)15) +
                        (size_t)(threads / 64) * (64 * sizeof(int64_t) + 2 * (((size_t)64 * fanout + 15) & ~(size_t)15));
     hipLaunchKernelGGL(part_emit_kernel, dim3((unsigned)n_batches), dim3(threads), lds, s, p);
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+// ---------------------------------------------------------------- slot replies (partition_slots.inl)
+static int part_slot_format(int32_t fanout, int32_t vertex_bits, int32_t position_bits, tg::StageBits *sb, int *words) {
+    TG_REQUIRE(fanout >= 1 && vertex_bits >= 1 && vertex_bits <= 32 && position_bits >= 1 && position_bits <= 32,
+               "tg_part slots: fan-out >= 1, 1 <= vertex_bits, position_bits <= 32");
+    sb->bv = vertex_bits;
+    sb->bp = position_bits;
+    const int bits = tg::stage_slot_bits((int)fanout, *sb);
+    *words = fanout > 16 ? 0 : bits <= 512 ? 16 : bits <= 1024 ? 32 : 0;
+    return TG_OK;
+}
+
+extern "C" int tg_part_slot_words(int32_t fanout, int32_t vertex_bits, int32_t position_bits, int32_t *words) {
+    TG_REQUIRE(words, "tg_part_slot_words: null result");
+    tg::StageBits sb;
+    int w = 0;
+    int rc = part_slot_format(fanout, vertex_bits, position_bits, &sb, &w);
+    if (rc != TG_OK) return rc;
+    *words = w;
+    return TG_OK;
+}
+
+static int part_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <int W, int KMAX>
+static void part_slot_sample_launch(const tg::PartOwnerParams &p, const tg::PartSorted *sorted, const tg::CallKey *keys,
+                                    tg::StageBits sb, uint32_t *slots, int64_t m_cap, hipStream_t s) {
+    static const int threads = std::min(512, std::max(64, part_env_int("TG_PART_SAMPLE_THREADS", 256) & ~63));
+    static const int chunks = std::max(1, part_env_int("TG_PART_SAMPLE_CHUNKS", 1)); // per wave
+    const size_t lds = (size_t)(threads / 64) * (64 * (W + 1) + 64) * sizeof(uint32_t);
+    const int64_t per_block = (int64_t)(threads / 64) * chunks;
+    const int64_t per_x = (((m_cap + 63) / 64 + 7) / 8 + per_block - 1) / per_block + 1; // eight groups of equal size
+    const unsigned blocks = (unsigned)(8 * per_x);
+    if (p.replace)
+        hipLaunchKernelGGL((tg::part_slot_sample_kernel<W, KMAX, true>), dim3(blocks), dim3(threads), lds, s, p, sorted, keys, sb,
+                           slots, chunks);
+    else
+        hipLaunchKernelGGL((tg::part_slot_sample_kernel<W, KMAX, false>), dim3(blocks), dim3(threads), lds, s, p, sorted, keys, sb,
+                           slots, chunks);
+}
+
+extern "C" int tg_part_sample_slots(const tg_graph *shard, int64_t v_lo, const void *requests, const int64_t *m_dev,
+                                    int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
+                                    int32_t fanout, int32_t sampler, uint64_t seed, int32_t vertex_bits,
+                                    int32_t position_bits, void *slots, void *workspace, int64_t workspace_bytes,
+                                    void *stream) {
+    tg::PartOwnerParams p;
+    int rc = part_owner_params(p, shard, v_lo, 0, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed, m_cap);
+    if (rc != TG_OK) return rc;
+    tg::StageBits sb;
+    int W = 0;
+    rc = part_slot_format(fanout, vertex_bits, position_bits, &sb, &W);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(W != 0, "tg_part_sample_slots: fan-out %d with %d + %d bits per sample does not fit a slot (tg_part_slot_words)",
+               fanout, vertex_bits, position_bits);
+    TG_REQUIRE(shard->n_edges < ((int64_t)1 << 32) && m_cap < ((int64_t)1 << 32), "tg_part_sample_slots: a shard of < 2^32 edges, < 2^32 requests");
+    TG_REQUIRE((shard->n_major <= 1 || vertex_bits >= 1) && (slots || m_cap == 0) && ((uintptr_t)slots & 63) == 0,
+               "tg_part_sample_slots: slots null or not 64-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const tg::CallKey *keys = nullptr;
+    if (workspace && m_cap > 0) { // the call keys of the first PART_KEY_CAP batches of every requesting rank
+        const PartSortLayout L = part_sort_layout(m_cap);
+        TG_REQUIRE(workspace_bytes >= (int64_t)L.total && ((uintptr_t)workspace & 255) == 0,
+                   "tg_part_sample_slots: workspace too small or not 256-byte aligned");
+        tg::CallKey *k = reinterpret_cast<tg::CallKey *>(static_cast<unsigned char *>(workspace) + L.keys);
+        hipLaunchKernelGGL(tg::part_call_keys_kernel, dim3((unsigned)(world * tg::PART_KEY_CAP + 255) / 256), dim3(256), 0, s, p, k);
+        keys = k;
+    }
+    const tg::PartSorted *perm = nullptr; // the requests in window order, or NULL: arrival order
+    const bool ordered = workspace && m_cap >= g_part_order_min_requests && shard->n_edges >= g_part_order_min_edges &&
+                         shard->n_major < ((int64_t)0xffffffff);
+    if (ordered) {
+        const PartSortLayout L = part_sort_layout(m_cap);
+        TG_REQUIRE(workspace_bytes >= (int64_t)L.total && ((uintptr_t)workspace & 255) == 0,
+                   "tg_part_sample_slots: workspace too small or not 256-byte aligned");
+        rc = part_order_requests(p, shard, v_lo, m_dev, workspace, L, s, nullptr, &perm);
+        if (rc != TG_OK) return rc;
+    }
+    if (m_cap == 0) return TG_OK;
+    uint32_t *out = static_cast<uint32_t *>(slots);
+    if (W == 16) {
+        if (fanout <= 12)
+            part_slot_sample_launch<16, 12>(p, perm, keys, sb, out, m_cap, s);
+        else
+            part_slot_sample_launch<16, 16>(p, perm, keys, sb, out, m_cap, s);
+    } else {
+        if (fanout <= 12)
+            part_slot_sample_launch<32, 12>(p, perm, keys, sb, out, m_cap, s);
+        else
+            part_slot_sample_launch<32, 16>(p, perm, keys, sb, out, m_cap, s);
+    }
+    TG_LAUNCH_CHECK();
+    return TG_OK;
+}
+
+template <int W, int KMAX>
+static void part_slot_emit_launch(const tg::PartSlotEmitParams &p, tg::StageBits sb, int64_t n_batches, hipStream_t s) {
+    static const int waves = part_env_int("TG_PART_EMIT_WAVES", 2);
+    const size_t lds = (size_t)waves * tg::part_slot_emit_wave_bytes(W, p.k);
+    if (waves == 1)
+        hipLaunchKernelGGL((tg::part_slot_emit_kernel<W, KMAX, 1>), dim3((unsigned)n_batches), dim3(64), lds, s, p, sb);
+    else if (waves == 4)
+        hipLaunchKernelGGL((tg::part_slot_emit_kernel<W, KMAX, 4>), dim3((unsigned)n_batches), dim3(256), lds, s, p, sb);
+    else
+        hipLaunchKernelGGL((tg::part_slot_emit_kernel<W, KMAX, 2>), dim3((unsigned)n_batches), dim3(128), lds, s, p, sb);
+}
+
+extern "C" int tg_part_emit_slots(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int32_t world,
+                                  int32_t fanout, int32_t hop, int32_t n_hops, void *workspace, const void *slots,
+                                  int32_t vertex_bits, int32_t position_bits, const int64_t *e_lo_of, void *stream) {
+    TG_REQUIRE(out && workspace && slots && e_lo_of && n_batches >= 1 && hop >= 0 && hop < n_hops && n_hops <= TG_MAX_HOPS &&
+                   world >= 1 && world <= tg::PART_MAX_WORLD,
+               "tg_part_emit_slots: bad arguments");
+    TG_REQUIRE(out->samples && out->rows && out->cols && out->edge_index && out->layer_offsets && out->counts,
+               "tg_part_emit_slots: null output slabs");
+    using namespace tg;
+    StageBits sb;
+    int W = 0;
+    int rc = part_slot_format(fanout, vertex_bits, position_bits, &sb, &W);
+    if (rc != TG_OK) return rc;
+    TG_REQUIRE(W != 0, "tg_part_emit_slots: no slot format for fan-out %d (tg_part_slot_words)", fanout);
+    const PartLayout L = part_layout(n_batches, request_cap, world);
+    unsigned char *w = static_cast<unsigned char *>(workspace);
+    PartSlotEmitParams p;
+    p.n_seeds = n_seeds;
+    p.cap_nodes = out->cap_nodes;
+    p.cap_edges = out->cap_edges;
+    p.samples = out->samples;
+    p.rows = out->rows;
+    p.cols = out->cols;
+    p.edge_index = out->edge_index;
+    p.layer_offsets = out->layer_offsets;
+    p.counts = out->counts;
+    p.state = reinterpret_cast<PartState *>(w + L.state);
+    p.req_pos = reinterpret_cast<uint32_t *>(w + L.req_pos);
+    p.slots = static_cast<const uint32_t *>(slots);
+    p.base = reinterpret_cast<const int64_t *>(w + L.base);
+    for (int i = 0; i < world; ++i) p.e_lo_of[i] = e_lo_of[i];
+    p.k = fanout;
+    p.hop = hop;
+    p.n_hops = n_hops;
+    p.world = world;
+    hipStream_t s = (hipStream_t)stream;
+    if (W == 16) {
+        if (fanout <= 12)
+            part_slot_emit_launch<16, 12>(p, sb, n_batches, s);
+        else
+            part_slot_emit_launch<16, 16>(p, sb, n_batches, s);
+    } else {
+        if (fanout <= 12)
+            part_slot_emit_launch<32, 12>(p, sb, n_batches, s);
+        else
+            part_slot_emit_launch<32, 16>(p, sb, n_batches, s);
+    }
     TG_LAUNCH_CHECK();
     return TG_OK;
 }

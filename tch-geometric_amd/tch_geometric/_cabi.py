@@ -26,7 +26,7 @@ EXPORTS = ["tg_version", "tg_last_error", "tg_ns_homo_capacity", "tg_ns_homo_bat
            "tg_ns_hop_scan_workspace_bytes", "tg_ns_hop_scan", "tg_ns_hop_weighted", "tg_ns_hop_weighted_groups", "tg_ns_hop_weighted_workspace_bytes", "tg_gather_rows",
            "tg_biased_walk_workspace_bytes", "tg_biased_tempo_random_walk", "tg_ns_hetero_capacity",
            "tg_ns_hetero_batched", "tg_ns_homo_compact", "tg_part_workspace_bytes", "tg_part_begin",
-           "tg_sanitize_range", "tg_ns_hop_segments", "tg_het_hop_begin_all", "tg_het_hop_end_all", "tg_part_requests", "tg_part_count", "tg_part_scan_workspace_bytes", "tg_part_sample", "tg_part_emit", "tg_part_unpack", "tg_part_pack", "tg_compact_rows", "tg_budget_capacity",
+           "tg_sanitize_range", "tg_ns_hop_segments", "tg_het_hop_begin_all", "tg_het_hop_end_all", "tg_part_requests", "tg_part_count", "tg_part_scan_workspace_bytes", "tg_part_sample", "tg_part_emit", "tg_part_slot_words", "tg_part_sample_slots", "tg_part_emit_slots", "tg_part_unpack", "tg_part_pack", "tg_compact_rows", "tg_budget_capacity",
            "tg_budget_workspace_bytes", "tg_budget_sample", "tg_ns_homo_workspace_bytes", "tg_ns_homo_batched_ws", "tg_het_meta_words", "tg_het_step_begin",
            "tg_het_step_end", "tg_het_hop_end", "tg_ns_homo_batched_form", "tg_ns_win_tuning_get", "tg_ns_win_tuning_set",
            "tg_ns_win_stage_timing", "tg_ns_win_stage_times", "tg_probe_ns_sol",

@@ -42,8 +42,10 @@ class CscShard:
     def graph_view(self):
         if self._view is None:   # u32 shadow of the neighbour ids: half the bytes per gathered line (ids < 2^32)
             i32 = self.indices.to(torch.int32) if self.n_nodes < 2 ** 32 and self.indices.is_cuda else None
+            # ... and of the column starts (a shard of < 2^32 edges; the kernels read the words as unsigned)
+            p32 = self.ptrs.to(torch.int32) if self.indices.numel() < 2 ** 32 and self.ptrs.is_cuda else None
             self._view = _cabi.graph_view(self.ptrs, self.indices, weights=self.weights, timestamps=self.timestamps,
-                                          indices32=i32)
+                                          indices32=i32, ptrs32=p32)
         return self._view
 
     @staticmethod
@@ -133,16 +135,18 @@ def _a2a_flat(send, send_rows, recv_rows, row_len, group):
 class PartitionedSampler:
     """The device form of the exchange (csrc/partition.hip) with every buffer allocated once and reused across calls.
 
-    Per hop: tg_part_requests -> [sizes, requests all-to-all] -> tg_part_count / tg_part_sample (owner: compact replies
-    = per-request counts + (neighbour, global edge pointer) pairs) -> [counts, reply sizes, replies all-to-all] ->
-    tg_part_emit.  Every size lives on the device; with world == 1 the plain samplers read nothing back at all (filters /
-    weights: one status word when the call ends), with world > 1 the host reads only the all-to-all split sizes (two small
-    read-backs per hop).  The returned `_cabi.NsBatchedOut` equals
+    Per hop, plain samplers (slot replies): tg_part_requests -> [sizes, requests all-to-all] -> tg_part_sample_slots (owner:
+    one fixed-size packed slot per request) -> [slots all-to-all, the request sizes mirrored] -> tg_part_emit_slots.
+    Per hop, filters / weights / wide fan-outs (compact replies): tg_part_requests -> [sizes, requests all-to-all] ->
+    tg_part_count / tg_part_sample (owner: per-request counts + (neighbour, global edge pointer) entries) -> [counts,
+    reply sizes, replies all-to-all] -> tg_part_emit.  Every size lives on the device; with world == 1 the plain samplers read nothing back at all (filters /
+    weights: one status word when the call ends), with world > 1 the host reads only the all-to-all split sizes (one small
+    read-back per hop with slot replies, two with compact ones).  The returned `_cabi.NsBatchedOut` equals
     the replicated-graph sampler's bit for bit."""
 
     def __init__(self, shard, n_batches, n_seeds, fanout, sampler=SAMPLER_UNIFORM, group=None,
                  filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), force_exchange=False,
-                 packed_replies=None):
+                 packed_replies=None, slot_replies=None):
         """sampler: uniform / with replacement / weighted (shard.weights); filter_mode: a TemporalFilter mode over
         shard.timestamps (`sample()` then takes the seeds' filter states).  Filters and weights take the general
         owner path: tg_part_unpack -> tg_ns_hop_scan / tg_ns_hop_weighted -> tg_part_pack.
@@ -151,7 +155,13 @@ class PartitionedSampler:
         a one-GPU box.
         packed_replies: a reply entry is one word (neighbour | global edge pointer << 32) instead of two -- half the bytes
         of the largest all-to-all.  None = whenever the graph allows it (shard.n_nodes and shard.n_edges_global < 2^32);
-        every rank must pass the same value."""
+        every rank must pass the same value.
+        slot_replies: the owner answers every request with one fixed-size packed slot (csrc/partition_slots.inl) instead
+        of a compact reply: no count / prefix passes, whole-chunk writes, and ONE size read-back per hop instead of two
+        (the reply exchange mirrors the request exchange's split sizes).  None = whenever it applies -- unweighted,
+        unfiltered sampling, fan-outs <= 16, every shard below 2^32 edges, a slot of <= 128 bytes; the ranks agree on
+        that (and on the slot's bit widths) in one small all-reduce at construction.  True raises where it does not
+        apply; every rank must pass the same value."""
         import ctypes as C
         self.C, self.shard, self.group, self.sampler = C, shard, group, sampler
         self.filter_mode, self.forward, self.window = filter_mode, bool(forward), tuple(window)
@@ -193,6 +203,44 @@ class PartitionedSampler:
         self.reply_format = ((_cabi.PART_REPLY_PACKED_STATE if packed else _cabi.PART_REPLY_TRIPLES) if self.filtered
                              else (_cabi.PART_REPLY_PACKED if packed else _cabi.PART_REPLY_PAIRS))
         self.reply_words = 2 if self.reply_format == _cabi.PART_REPLY_PACKED_STATE else self.reply_format
+        self._init_slots(slot_replies)
+
+    def _init_slots(self, wanted):
+        """slot replies: the format every rank agrees on -- vertex bits of the whole graph, position bits of its longest
+        column, words per slot of every hop -- and the shards' global edge offsets"""
+        C = self.C
+        self.slots, self.slot_words = False, []
+        if wanted is False:
+            return
+        shard = self.shard
+        mine_ok = (not self.general and max(self.fanout + [0]) <= 16 and shard.indices.numel() < 2 ** 32
+                   and shard.n_nodes <= 2 ** 32 and self.dev.type == "cuda")
+        longest = _cabi.graph_max_degree(shard.graph_view(), self.dev) if mine_ok and shard.ptrs.numel() > 1 else 0
+        word = torch.tensor([longest, 0 if mine_ok else 1, shard.e_lo], dtype=torch.int64)
+        e_lo_of = [shard.e_lo]
+        if self.exchange and self.world > 1:
+            on = word if self.gloo else word.to(self.dev)
+            parts = [torch.empty_like(on) for _ in range(self.world)]
+            dist.all_gather(parts, on, group=self.group)
+            allw = torch.stack(parts).cpu()
+            word = torch.tensor([int(allw[:, 0].max()), int(allw[:, 1].max()), 0])
+            e_lo_of = [int(x) for x in allw[:, 2].tolist()]
+        ok = int(word[1]) == 0
+        bits = lambda hi: max(1, int(hi).bit_length())        # bits that hold 0 .. hi
+        self.slot_bv, self.slot_bp = bits(max(shard.n_nodes, 1) - 1), bits(max(int(word[0]), 1) - 1)
+        words = []
+        for k in self.fanout:
+            w = C.c_int32(0)
+            if ok:
+                _cabi.check(_cabi.lib.tg_part_slot_words(C.c_int32(k), C.c_int32(self.slot_bv), C.c_int32(self.slot_bp),
+                                                         C.byref(w)))
+            words.append(w.value)
+        ok = ok and all(w > 0 for w in words)
+        if wanted and not ok:
+            raise ValueError("slot replies do not apply here (filters / weights, a fan-out > 16, a shard of >= 2^32 edges, "
+                             "or more than 1024 bits per slot)")
+        self.slots, self.slot_words = ok, words
+        self.e_lo_of = (C.c_int64 * 64)(*e_lo_of)
 
     def _buf(self, name, n, dtype, cols=None):
         """persistent scratch that only ever grows"""
@@ -340,8 +388,9 @@ class PartitionedSampler:
         return self.out
 
     def steps(self, seeds, seed, first_call_id, first_call_ids=None, seeds_state=None):
-        """One call as a GENERATOR: it yields right before every blocking size read-back (two per hop with an exchange: the
-        request split sizes, the reply split sizes), having enqueued everything up to there.  A scheduler that drives
+        """One call as a GENERATOR: it yields right before every blocking size read-back (with an exchange, per hop: the
+        request split sizes, and -- compact replies only -- the reply split sizes; slot replies mirror the request sizes),
+        having enqueued everything up to there.  A scheduler that drives
         several samplers' generators in a fixed order from one host thread (`interleave`) keeps the GPU busy with one
         super-batch while the host waits for another's sizes.  Run to exhaustion it is `_sample_once`."""
         C, lib, ptr = self.C, _cabi.lib, _cabi.ptr
@@ -389,6 +438,30 @@ class PartitionedSampler:
                     off_l.append(acc)
                     acc += r
                 seg = (C.c_int64 * 65)(*(off_l + [acc]))
+            if self.slots:
+                # one fixed-size slot per request, written at the request's index: the reply exchange mirrors the request
+                # exchange's split sizes -- nothing to read back
+                W = self.slot_words[h]
+                slots = self._buf("slots%d" % W, m_cap, torch.int64, W // 2)
+                ws_bytes = C.c_int64(0)
+                _cabi.check(lib.tg_part_sample_workspace_bytes(C.c_int64(m_cap), C.byref(ws_bytes)))
+                sws = self._buf("sample_ws", ws_bytes.value // 8 + 64, torch.int64)
+                _cabi.check(lib.tg_part_sample_slots(C.byref(graph), C.c_int64(shard.v_lo), ptr(got), ptr(m_dev),
+                                                     C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
+                                                     C.c_int32(self.sampler), C.c_uint64(seed), C.c_int32(self.slot_bv),
+                                                     C.c_int32(self.slot_bp), ptr(slots), ptr(sws),
+                                                     C.c_int64(sws.numel() * 8), stream))
+                if self.exchange:
+                    slots_back = self._a2a(slots[:m_cap], recv, send, "slots_recv%d" % W)
+                    if slots_back.numel() == 0:
+                        slots_back = self._buf("slots_recv%d" % W, 1, torch.int64, W // 2)
+                else:
+                    slots_back = slots
+                _cabi.check(lib.tg_part_emit_slots(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(self.request_cap),
+                                                   C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H), ptr(self.ws),
+                                                   ptr(slots_back), C.c_int32(self.slot_bv), C.c_int32(self.slot_bp),
+                                                   self.e_lo_of, stream))
+                continue
             if self.general:
                 cnt, off, reply = self._owner_general(got, got_states, m_dev, m_cap, seg, call0, k, seed, stream)
             else:
@@ -536,10 +609,11 @@ class _Null:
 
 def ns_homo_partitioned_device(shard, seeds, fanout, seed, first_call_id, sampler=SAMPLER_UNIFORM, group=None,
                                filter_mode=_cabi.FILTER_NONE, forward=False, window=(0, 0), seeds_state=None,
-                               packed_replies=None):
+                               packed_replies=None, slot_replies=None):
     """One call of the device form (a throw-away PartitionedSampler; keep one around to reuse its buffers)."""
     ps = PartitionedSampler(shard, seeds.shape[0], seeds.shape[1], fanout, sampler=sampler, group=group,
-                            filter_mode=filter_mode, forward=forward, window=window, packed_replies=packed_replies)
+                            filter_mode=filter_mode, forward=forward, window=window, packed_replies=packed_replies,
+                            slot_replies=slot_replies)
     return ps.sample(seeds, seed, first_call_id, seeds_state=seeds_state)
 
 

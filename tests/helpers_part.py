@@ -7,10 +7,11 @@ import torch
 
 
 def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0, filter_mode=-1, forward=False,
-                          window=(0, 0), seeds_state=None, packed=False):
+                          window=(0, 0), seeds_state=None, packed=False, slots=False):
     """-> (NsBatchedOut filled through tg_part_begin / requests / [count + sample | unpack + flat hop + pack] / emit,
     requests that left shard 0).  Filters / weights take the general owner path.  packed: one-word reply entries
-    (TG_PART_REPLY_PACKED / _PACKED_STATE) instead of pairs / triples."""
+    (TG_PART_REPLY_PACKED / _PACKED_STATE) instead of pairs / triples.  slots: the fixed-size slot replies
+    (tg_part_sample_slots / tg_part_emit_slots; unweighted, unfiltered sampling only)."""
     filtered = filter_mode != -1
     general = filtered or sampler == 2
     fmt = (4 if packed else 3) if filtered else (1 if packed else 2)     # tchgeo.h TG_PART_REPLY_*
@@ -40,6 +41,11 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
                                  C.c_int32(H), C.byref(so), C.c_int64(request_cap), C.c_int32(world), ptr(ws), stream))
     crossed = 0
     call0 = (C.c_uint64 * 64)(first_call)                   # owner side sees ONE requesting rank: the origin
+    if slots:
+        assert not general
+        longest = max(int((sh.ptrs[1:] - sh.ptrs[:-1]).max()) if sh.ptrs.numel() > 1 else 0 for sh in shards)
+        bv, bp = max(1, (shards[0].n_nodes - 1).bit_length()), max(1, (max(longest, 1) - 1).bit_length())
+        e_lo_of = (C.c_int64 * 64)(*[sh.e_lo for sh in shards])
     for h, k in enumerate(fan):
         cabi.check(lib.tg_part_requests(C.byref(so), C.c_int64(nb), C.c_int64(request_cap),
                                         C.c_int64(shards[0].shard_size), C.c_int32(world), ptr(ws), ptr(requests),
@@ -54,6 +60,23 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
                 assert bool((owner == p).all())
                 crossed += m if p else 0
             m_dev = torch.tensor([m], **i64)
+            if slots:
+                W = C.c_int32(0)
+                cabi.check(lib.tg_part_slot_words(C.c_int32(k), C.c_int32(bv), C.c_int32(bp), C.byref(W)))
+                assert W.value in (16, 32)
+                mine_slots = torch.empty((max(m, 1), W.value // 2), **i64)
+                seg = (C.c_int64 * 65)(0, m)
+                g = shards[p].graph_view()
+                wb = C.c_int64(0)
+                cabi.check(lib.tg_part_sample_workspace_bytes(C.c_int64(m), C.byref(wb)))
+                sws = torch.empty(wb.value // 8 + 64, **i64)
+                cabi.check(lib.tg_part_sample_slots(C.byref(g), C.c_int64(shards[p].v_lo), ptr(mine), ptr(m_dev),
+                                                    C.c_int64(m), C.c_int32(1), seg, call0, C.c_int32(k),
+                                                    C.c_int32(sampler), C.c_uint64(seed), C.c_int32(bv), C.c_int32(bp),
+                                                    ptr(mine_slots), ptr(sws), C.c_int64(sws.numel() * 8), stream))
+                replies.append(mine_slots[:m])
+                lo += m
+                continue
             if general:
                 cnt, rep = _general_owner(cabi, shards[p], mine, req_states[lo:lo + m].contiguous() if filtered else None,
                                           m_dev, m, k, sampler, filter_mode, forward, window, seed, call0, fmt, stream)
@@ -82,6 +105,14 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
             cnts.append(cnt[:m])
             replies.append(rep[:total])
             lo += m
+        if slots:
+            back = torch.cat(replies).contiguous()
+            if back.numel() == 0:
+                back = torch.empty((1, W.value // 2), **i64)
+            cabi.check(lib.tg_part_emit_slots(C.byref(so), C.c_int64(nb), C.c_int64(B), C.c_int64(request_cap),
+                                              C.c_int32(world), C.c_int32(k), C.c_int32(h), C.c_int32(H), ptr(ws), ptr(back),
+                                              C.c_int32(bv), C.c_int32(bp), e_lo_of, stream))
+            continue
         cnt_back = torch.zeros(request_cap, dtype=torch.int32, device=dev)
         allc = torch.cat(cnts)
         cnt_back[:allc.numel()] = allc

@@ -52,9 +52,10 @@ def test_single_rank_partitioned_equals_batched(sampler):
     assert np.array_equal(res[2][0].cpu().numpy(), o[0]) and np.array_equal(res[2][3].cpu().numpy(), o[3])
     # the device form of the exchange (csrc/partition.hip) fills ordinary per-batch slabs with the same contents
     # (with one-word packed replies, which this small graph allows, and with pairs)
-    for packed in (None, False):
+    # (slot replies, the default here; compact replies as packed words and as pairs)
+    for packed, slots in ((None, None), (None, False), (False, False)):
         dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler,
-                                                      packed_replies=packed)
+                                                      packed_replies=packed, slot_replies=slots)
         torch.cuda.synchronize()
         for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
             s, r, c, e, lo = dout.batch(b)
@@ -62,10 +63,10 @@ def test_single_rank_partitioned_equals_batched(sampler):
 
 
 @pytest.mark.parametrize("sampler", [0, 1])
-@pytest.mark.parametrize("packed", [None, False])
+@pytest.mark.parametrize("packed", [None, False, "slots"])
 def test_owner_side_in_window_order(sampler, packed):
-    """tg_part_sample_ws: the owner sorts a hop's requests by the window of their column and samples in that order; the
-    replies are the same words in the same places.  Thresholds lowered so that the small graph takes the ordered path;
+    """tg_part_sample_ws / tg_part_sample_slots: the owner sorts a hop's requests by the window of their column and samples
+    in that order; the replies are the same words in the same places.  Thresholds lowered so that the small graph takes the ordered path;
     then a launch that takes it by itself (RMAT-22, 512 batches: 7.8 M requests in the second hop)."""
     import ctypes as C
     from tch_geometric import _cabi, partitioned
@@ -77,14 +78,16 @@ def test_owner_side_in_window_order(sampler, packed):
         seeds[3, :5] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))
         shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
         ref = _replicated(ptrs, idx, seeds, 40, sampler)
-        dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler, packed_replies=packed)
+        slots = packed == "slots"
+        dout = partitioned.ns_homo_partitioned_device(shard, seeds, FANOUT, SEED, 40, sampler=sampler,
+                                                      packed_replies=None if slots else packed, slot_replies=slots)
         torch.cuda.synchronize()
         for b, (rs, rr, rc, re_, rlo) in enumerate(ref):
             s, r, c, e, lo = dout.batch(b)
             assert lo == rlo and torch.equal(s, rs) and torch.equal(r, rr) and torch.equal(c, rc) and torch.equal(e, re_), b
     finally:
         _cabi.lib.tg_part_sample_order_thresholds(C.c_int64(1 << 21), C.c_int64(1 << 24))
-    if sampler == 0 and packed is None:
+    if sampler == 0 and packed in (None, "slots"):
         n = 1 << 22
         row, col = _cabi.rmat_edges(22, n * 16, 0x5EED0016, dev)
         ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, True)
@@ -92,7 +95,8 @@ def test_owner_side_in_window_order(sampler, packed):
         nb = 512
         seeds = _cabi.seed_batches(0xBA7C4, 0, nb, 1024, n, dev)
         shard = partitioned.CscShard.from_full(ptrs, idx, 0, 1)
-        ps = partitioned.PartitionedSampler(shard, nb, 1024, FANOUT)
+        ps = partitioned.PartitionedSampler(shard, nb, 1024, FANOUT, slot_replies=packed == "slots")
+        assert ps.slots == (packed == "slots")
         out = ps.sample(seeds, SEED, 0)
         ref = _cabi.NsBatchedOut(nb, 1024, FANOUT, dev)
         _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, FANOUT, SEED, 0, ref)
@@ -204,7 +208,7 @@ def test_two_ranks_on_one_gpu_over_gloo():
         assert edges > 0 and remote > 0        # the test really crossed the partition boundary
 
 
-@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("packed", [False, True, "slots"])
 @pytest.mark.parametrize("world", [3, 8])
 def test_device_kernels_with_an_emulated_world(world, packed):
     """The request bucketing / owner sampling / emit kernels for world > 2, with the all-to-alls emulated in one
@@ -217,7 +221,7 @@ def test_device_kernels_with_an_emulated_world(world, packed):
     nb, fan = 6, [7, 5]
     seeds = _cabi.seed_batches(13, 500, nb, B, n, dev)
     shards = [partitioned.CscShard.from_full(ptrs, idx, r, world) for r in range(world)]
-    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 500, packed=packed)
+    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 500, packed=packed is True, slots=packed == "slots")
     ref = _cabi.NsBatchedOut(nb, B, fan, dev)
     _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED, 500, ref)
     torch.cuda.synchronize()
@@ -227,7 +231,8 @@ def test_device_kernels_with_an_emulated_world(world, packed):
             assert (x == y) if isinstance(x, list) else torch.equal(x, y)
 
 
-def test_ranks_without_requests():
+@pytest.mark.parametrize("slots", [False, True])
+def test_ranks_without_requests(slots):
     """all seeds in one shard's vertex range, one hop: the other owners receive nothing and may be handed no request
     buffer at all (tg_part_count / tg_part_sample with m = 0)"""
     from helpers_part import emulated_world_sample
@@ -237,7 +242,7 @@ def test_ranks_without_requests():
     world, fan = 4, [3]
     seeds = torch.randint(0, n // world // 2, (2, 8), device=dev)
     shards = [partitioned.CscShard.from_full(ptrs, idx, r, world) for r in range(world)]
-    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 9)
+    out, crossed = emulated_world_sample(_cabi, shards, seeds, fan, SEED, 9, slots=slots)
     assert crossed == 0
     ref = _cabi.NsBatchedOut(2, 8, fan, dev)
     _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED, 9, ref)
@@ -261,16 +266,27 @@ def test_rccl_backend_gets_device_tensors_only(monkeypatch):
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
     monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
     monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    def fake_all_gather(parts, t, group=None):
+        seen.append((parts[0].device.type, t.device.type))
+        for p in parts:
+            p.copy_(t)
+
     monkeypatch.setattr(dist, "all_to_all_single", fake_a2a)
+    monkeypatch.setattr(dist, "all_gather", fake_all_gather)
     dev = torch.device("cuda:0")
     assert partitioned._exchange_counts([3, 4], None, dev) == [3, 4]
     ptrs, idx, n = _graph(dev)
     shard = partitioned.CscShard.from_full(ptrs, idx, 0, 2)
-    ps = partitioned.PartitionedSampler(shard, 3, B, [4, 3])
     seeds = _cabi.seed_batches(9, 0, 3, B, n, dev) % shard.v_hi          # keep every seed inside this rank's shard
-    ps.sample(seeds, SEED, 0, first_call_ids=[0, 0])
-    torch.cuda.synchronize()
-    assert len(seen) >= 1 + 2 * 5 and all(a == "cuda" and b == "cuda" for a, b in seen)
+    # collectives per hop: compact replies 5 (request sizes, requests, reply sizes, counts, replies); slot replies 3
+    # (request sizes, requests, slots) + the one all_gather that agrees on the slot format when the sampler is made
+    for slots, per_hop, once in ((False, 5, 0), (None, 3, 1)):
+        del seen[1:]
+        ps = partitioned.PartitionedSampler(shard, 3, B, [4, 3], slot_replies=slots)
+        assert ps.slots == (slots is None)
+        ps.sample(seeds, SEED, 0, first_call_ids=[0, 0])
+        torch.cuda.synchronize()
+        assert len(seen) == 1 + once + 2 * per_hop and all(a == "cuda" and b == "cuda" for a, b in seen)
 
 
 # ---------------------------------------------------------------- temporal filters and weights on a partitioned graph
