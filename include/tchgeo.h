@@ -470,15 +470,17 @@ TG_API int tg_part_sample_ws(const tg_graph *shard, int64_t v_lo, int64_t e_lo, 
  * back ONE set of sizes per hop instead of two, and neither side runs a count / prefix pass.  vertex_bits = bits of the
  * largest vertex id of the WHOLE graph, position_bits = bits of (longest column of the whole graph - 1): every rank
  * passes the same values.  A shard holds < 2^32 edges.  workspace: tg_part_sample_workspace_bytes(m_cap) (hops with many
- * requests are sampled in window order, as tg_part_sample_ws) or NULL.
+ * requests are sampled in window order, as tg_part_sample_ws) or NULL.  order_scale (>= 1) multiplies the request threshold
+ * of that ordering for this hop: a call's FIRST hop asks about its seeds -- mostly short columns that are read whole, one
+ * or two lines each -- and pays for the ordering only from about 4 x as many requests on (pass 4 there, 1 for later hops).
  * tg_part_emit_slots: slots as returned to the origin (its send-buffer order); e_lo_of: host [world], the global edge
  * offset of every rank's shard -- a sample's edge pointer = e_lo_of[owner] + column start + position.
  * Same draws as tg_part_sample, so the same results as the replicated sampler. */
 TG_API int tg_part_slot_words(int32_t fanout, int32_t vertex_bits, int32_t position_bits, int32_t *words);
 TG_API int tg_part_sample_slots(const tg_graph *shard, int64_t v_lo, const void *requests, const int64_t *m_dev, int64_t m_cap,
                                 int32_t world, const int64_t *seg_off, const uint64_t *seg_call0, int32_t fanout,
-                                int32_t sampler, uint64_t seed, int32_t vertex_bits, int32_t position_bits, void *slots,
-                                void *workspace, int64_t workspace_bytes, void *stream);
+                                int32_t sampler, uint64_t seed, int32_t vertex_bits, int32_t position_bits, int32_t order_scale,
+                                void *slots, void *workspace, int64_t workspace_bytes, void *stream);
 TG_API int tg_part_emit_slots(const tg_ns_out *out, int64_t n_batches, int64_t n_seeds, int64_t request_cap, int32_t world,
                               int32_t fanout, int32_t hop, int32_t n_hops, void *workspace, const void *slots,
                               int32_t vertex_bits, int32_t position_bits, const int64_t *e_lo_of, void *stream);

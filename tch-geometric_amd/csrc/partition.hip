@@ -955,6 +955,11 @@ static PartSortLayout part_sort_layout(int64_t m_cap) {
     return L;
 }
 
+static int part_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 // the window order of a hop's requests (psort_*): -> the permutation in the workspace
 static int part_order_requests(const tg::PartOwnerParams &p, const tg_graph *shard, int64_t v_lo, const int64_t *m_dev,
                                void *workspace, const PartSortLayout &L, hipStream_t s, const uint32_t **perm,
@@ -968,7 +973,8 @@ static int part_order_requests(const tg::PartOwnerParams &p, const tg_graph *sha
     sp.n_major = shard->n_major;
     const int elem = shard->indices32 ? 4 : 8;
     int shift = 0;
-    while (((int64_t)elem << shift) < (512 << 10)) ++shift; // 512 KB of the gathered array per window ...
+    static const int64_t window_bytes = (int64_t)std::max(16, part_env_int("TG_PART_WINDOW_KIB", 512)) << 10;
+    while (((int64_t)elem << shift) < window_bytes) ++shift; // 512 KB of the gathered array per window ...
     while (((shard->n_edges >> shift) + 1) > tg::PSORT_MAX_WINDOWS) ++shift; // ... as far as the counters go
     sp.shift = shift;
     sp.n_windows = (int32_t)((shard->n_edges >> shift) + 1);
@@ -1164,11 +1170,6 @@ extern "C" int tg_part_slot_words(int32_t fanout, int32_t vertex_bits, int32_t p
     return TG_OK;
 }
 
-static int part_env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 template <int W, int KMAX>
 static void part_slot_sample_launch(const tg::PartOwnerParams &p, const tg::PartSorted *sorted, const tg::CallKey *keys,
                                     tg::StageBits sb, uint32_t *slots, int64_t m_cap, hipStream_t s) {
@@ -1189,8 +1190,8 @@ static void part_slot_sample_launch(const tg::PartOwnerParams &p, const tg::Part
 extern "C" int tg_part_sample_slots(const tg_graph *shard, int64_t v_lo, const void *requests, const int64_t *m_dev,
                                     int64_t m_cap, int32_t world, const int64_t *seg_off, const uint64_t *seg_call0,
                                     int32_t fanout, int32_t sampler, uint64_t seed, int32_t vertex_bits,
-                                    int32_t position_bits, void *slots, void *workspace, int64_t workspace_bytes,
-                                    void *stream) {
+                                    int32_t position_bits, int32_t order_scale, void *slots, void *workspace,
+                                    int64_t workspace_bytes, void *stream) {
     tg::PartOwnerParams p;
     int rc = part_owner_params(p, shard, v_lo, 0, requests, m_dev, world, seg_off, seg_call0, fanout, sampler, seed, m_cap);
     if (rc != TG_OK) return rc;
@@ -1214,7 +1215,8 @@ extern "C" int tg_part_sample_slots(const tg_graph *shard, int64_t v_lo, const v
         keys = k;
     }
     const tg::PartSorted *perm = nullptr; // the requests in window order, or NULL: arrival order
-    const bool ordered = workspace && m_cap >= g_part_order_min_requests && shard->n_edges >= g_part_order_min_edges &&
+    const bool ordered = workspace && m_cap >= g_part_order_min_requests * std::max(order_scale, 1) &&
+                         shard->n_edges >= g_part_order_min_edges &&
                          shard->n_major < ((int64_t)0xffffffff);
     if (ordered) {
         const PartSortLayout L = part_sort_layout(m_cap);

@@ -449,7 +449,7 @@ class PartitionedSampler:
                 _cabi.check(lib.tg_part_sample_slots(C.byref(graph), C.c_int64(shard.v_lo), ptr(got), ptr(m_dev),
                                                      C.c_int64(m_cap), C.c_int32(world), seg, call0, C.c_int32(k),
                                                      C.c_int32(self.sampler), C.c_uint64(seed), C.c_int32(self.slot_bv),
-                                                     C.c_int32(self.slot_bp), ptr(slots), ptr(sws),
+                                                     C.c_int32(self.slot_bp), C.c_int32(4 if h == 0 else 1), ptr(slots), ptr(sws),
                                                      C.c_int64(sws.numel() * 8), stream))
                 if self.exchange:
                     slots_back = self._a2a(slots[:m_cap], recv, send, "slots_recv%d" % W)

@@ -73,7 +73,7 @@ def emulated_world_sample(cabi, shards, seeds, fan, seed, first_call, sampler=0,
                 cabi.check(lib.tg_part_sample_slots(C.byref(g), C.c_int64(shards[p].v_lo), ptr(mine), ptr(m_dev),
                                                     C.c_int64(m), C.c_int32(1), seg, call0, C.c_int32(k),
                                                     C.c_int32(sampler), C.c_uint64(seed), C.c_int32(bv), C.c_int32(bp),
-                                                    ptr(mine_slots), ptr(sws), C.c_int64(sws.numel() * 8), stream))
+                                                    C.c_int32(1), ptr(mine_slots), ptr(sws), C.c_int64(sws.numel() * 8), stream))
                 replies.append(mine_slots[:m])
                 lo += m
                 continue

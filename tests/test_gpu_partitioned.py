@@ -503,3 +503,52 @@ def test_protocol_over_rccl_with_one_rank():
     p.join(timeout=120)
     assert status == "ok", status
     assert backend == "nccl" and calls >= 3 * 2 * 5      # three configurations x two hops x >= 5 collectives per hop
+
+
+def test_slot_replies_random_sweep():
+    """slot replies over emulated worlds of 1 .. 8 ranks: random fan-outs (1 .. 16, one- and two-chunk slots), both plain
+    samplers, graphs with empty columns, a hub, shards that own nothing, seeds that repeat -- each equal to the replicated
+    launch; and the format's limits (fan-out 17, > 1 024 bits: no slot format)"""
+    import ctypes as C
+    from helpers_part import emulated_world_sample
+    from tch_geometric import _cabi, partitioned
+    dev = torch.device("cuda:0")
+    rs = np.random.default_rng(77)
+    w = C.c_int32(-1)
+    _cabi.check(_cabi.lib.tg_part_slot_words(C.c_int32(17), C.c_int32(20), C.c_int32(10), C.byref(w)))
+    assert w.value == 0
+    _cabi.check(_cabi.lib.tg_part_slot_words(C.c_int32(16), C.c_int32(32), C.c_int32(32), C.byref(w)))
+    assert w.value == 0                                              # 40 + 16 * 64 = 1 064 bits
+    _cabi.check(_cabi.lib.tg_part_slot_words(C.c_int32(16), C.c_int32(32), C.c_int32(29), C.byref(w)))
+    assert w.value == 32                                             # 1 016 bits: two chunks
+    _cabi.check(_cabi.lib.tg_part_slot_words(C.c_int32(10), C.c_int32(24), C.c_int32(19), C.byref(w)))
+    assert w.value == 16                                             # RMAT-24's 470 bits: one chunk
+    for case in range(14):
+        n = int(rs.integers(40, 3000))
+        e = int(rs.integers(n, 12 * n))
+        row, col = rs.integers(0, n, e), rs.integers(0, max(1, n - n // 5), e)   # the last fifth of the columns is empty
+        if case % 3 == 0:
+            col[: e // 4] = int(rs.integers(0, n))                   # a hub column
+        ptrs_h, idx_h, _ = orc.to_csc(np.stack([row, col]), n)
+        ptrs, idx = torch.from_numpy(ptrs_h).to(dev), torch.from_numpy(idx_h).to(dev)
+        world = int(rs.integers(1, 9))
+        hops = int(rs.integers(1, 4))
+        fan = [int(rs.integers(1, 17)) for _ in range(hops)]
+        while np.prod(fan) > 600:
+            fan[int(np.argmax(fan))] //= 2
+        sampler = int(rs.integers(0, 2))
+        nb, B_ = int(rs.integers(1, 7)), int(rs.integers(1, 40))
+        seeds = torch.from_numpy(rs.integers(0, n, (nb, B_))).to(dev)
+        seeds[0, : min(3, B_)] = int(col[0])                         # repeated seeds
+        shards = [partitioned.CscShard.from_full(ptrs, idx, r, world) for r in range(world)]
+        out, _ = emulated_world_sample(_cabi, shards, seeds, fan, SEED + case, 1000 * case, sampler=sampler, slots=True)
+        ref = _cabi.NsBatchedOut(nb, B_, fan, dev)
+        _cabi.ns_homo_batched(_cabi.graph_view(ptrs, idx), seeds, fan, SEED + case, 1000 * case, ref, sampler=sampler)
+        torch.cuda.synchronize()
+        for b in range(nb):
+            for x, y in zip(out.batch(b), ref.batch(b)):
+                assert (x == y) if isinstance(x, list) else torch.equal(x, y), (case, world, fan, sampler, b)
+        if case < 4:                                                  # and the oracle itself, for one batch
+            o = orc.ns_homo(ptrs_h, idx_h, seeds[0].cpu().numpy(), fan, orc.rng_philox(SEED + case, 1000 * case), sampler=sampler)
+            s, r, c, e_, lo = out.batch(0)
+            assert np.array_equal(s.cpu().numpy(), o[0]) and np.array_equal(e_.cpu().numpy(), o[3]) and lo == o[4]
