@@ -425,6 +425,11 @@ def main(argv=None):
             result["secondary"]["batches_per_launch_sweep"] = launch_size_sweep(torch, _cabi, graph, dev, B, fanout, n_nodes, first)
         except Exception as e:  # noqa: BLE001  (a secondary run must never cost the headline line)
             result["secondary"]["batches_per_launch_sweep"] = {"error": repr(e)}
+        try:  # mode 2 (range-partitioned CSC) with this one rank owning everything: the protocol's own cost
+            result["secondary"]["mode2_partitioned_one_rank_4096_batches"] = mode2_one_rank(
+                torch, _cabi, ptrs, indices, dev, B, fanout, n_nodes, first)
+        except Exception as e:  # noqa: BLE001
+            result["secondary"]["mode2_partitioned_one_rank_4096_batches"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ptrs, indices, seeds[:min(int(seeds.shape[0]), 16384)], fanout)
     if rank == 0:
@@ -562,6 +567,49 @@ def partitioned_mode(args, torch, dist, _cabi, sharding, dev, world, rank, fanou
         print_result(result)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def mode2_one_rank(torch, _cabi, ptrs, indices, dev, B, fanout, n_nodes, first, G=4096, reps=6):
+    """SURVEY.md 8(e) mode 2 with ONE rank that owns every column: requests -> owner-side sampling into slot replies -> emit,
+    no exchange, nothing read back -- what the partition costs a rank before any link is involved (the replicated launch
+    of the same batches is `batches_per_launch_sweep`).  Checked against the replicated launch (counts and edge pointers of
+    every batch).  `bench.py --mode partitioned [--force-exchange --lanes L]` is the full form with the collectives."""
+    from tch_geometric import partitioned
+    shard = partitioned.CscShard.from_full(ptrs, indices, 0, 1)
+    res = {}
+    for name, slots in (("slot_replies", None), ("compact_replies", False)):
+        ps = partitioned.PartitionedSampler(shard, G, B, fanout, slot_replies=slots)
+        seeds = _cabi.seed_batches(0xBA7C4, first, G, B, n_nodes, dev)
+        for _ in range(2):
+            out = ps.sample(seeds, 0, first)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = ps.sample(seeds, 0, first)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        edges = int(out.counts[:, 1].sum())
+        slots_n = int(out.layer_offsets[:, len(fanout) - 1, 0].sum()) if fanout else 0
+        entry = {"ms_per_call": ms, "sampled_edges": edges, "edges_per_s": edges / ms * 1e3, "uses_slot_replies": bool(ps.slots),
+                 "roofline": roofline_block(24 * slots_n + 40 * edges + 16 * B * G, ms,
+                                            "the replicated operator's bytes (SURVEY 8d): requests and replies are the "
+                                            "protocol's own traffic and count as waste")}
+        if name == "slot_replies":   # same results as the replicated launch
+            ref = _cabi.NsBatchedOut(G, B, fanout, dev)
+            _cabi.ns_homo_batched(_cabi.graph_view(ptrs, indices), seeds, fanout, 0, first, ref)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(out.counts, ref.counts)) and bool(torch.equal(out.layer_offsets, ref.layer_offsets))
+            ar = torch.arange(out.edge_index.shape[1], device=dev)[None, :]
+            same = same and bool(((out.edge_index == ref.edge_index) | (ar >= ref.counts[:, 1:2])).all())
+            entry["equals_replicated_launch"] = same
+            if not same:
+                raise RuntimeError("mode 2 differs from the replicated launch")
+            del ref
+        res[name] = entry
+        del ps, out
+        torch.cuda.empty_cache()
+    return res
 
 
 def roofline_block(alg_bytes, ms, what):
