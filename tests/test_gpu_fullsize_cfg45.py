@@ -231,7 +231,16 @@ def test_cfg5_rmat27_partitioned_world8(cabi):
             assert torch.equal(x, y), b
         beyond += int((got[3] >= 2 ** 30).sum())
     assert beyond > 0                                        # edge pointers in the upper half of the 2^31 range occurred
-    del shards
+    # ... and with the slot replies (27 vertex bits + the longest column's position bits: two-chunk slots for both hops;
+    # the edge pointer = the owner shard's 2^28-edge offset + 32-bit local parts)
+    out2, _ = emulated_world_sample(cabi, shards, seeds, fan, seed, first, slots=True)
+    torch.cuda.synchronize()
+    for b in range(nb):
+        got, want = out2.batch(b), ref.batch(b)
+        assert got[4] == want[4]
+        for x, y in zip(got[:4], want[:4]):
+            assert torch.equal(x, y), b
+    del shards, out2
     # one batch of the replicated launch replayed by the oracle on the host copy of the 18 GB CSC
     hp, hi = ptrs.cpu().numpy(), idx.cpu().numpy()
     o = orc.ns_homo(hp, hi, seeds[1].cpu().numpy(), fan, orc.rng_philox(seed, first + 1))

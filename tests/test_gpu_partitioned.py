@@ -424,6 +424,15 @@ def _rccl_worker(port, q):
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         ok, calls = True, 0
+        errs = []
+
+        def chk(cond, label):                 # the first labels that differ travel back in the status string
+            nonlocal ok
+            if not cond:
+                ok = False
+                if len(errs) < 6:
+                    errs.append(label)
+
         real = dist.all_to_all_single
 
         def counted(*a, **k):
@@ -442,13 +451,13 @@ def _rccl_worker(port, q):
             got = ps.sample(seeds, SEED, 70, seeds_state=states if case["filter_mode"] != -1 else None)
             want = _replicated_general(aptrs, aidx, ts, w, seeds, states, [6, 4], 70, case)
             c = want.counts.cpu()
-            ok = ok and torch.equal(got.counts.cpu(), c)
+            chk(torch.equal(got.counts.cpu(), c), ("single", case["sampler"], case["filter_mode"], "counts"))
             for b in range(4):
                 x, y = got.batch(b, c), want.batch(b, c)
-                ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+                chk(x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4])),
+                    ("single", case["sampler"], case["filter_mode"], "batch", b))
         # super-batches in flight from ONE host thread over ONE communicator (round 4: PipelinedPartitionedSampler,
         # bench.py --lanes): the steps of two samplers interleave in a fixed order; every lane's slabs are reused
-        errs = []
         n_jobs = 5
         job_seeds = [_cabi.seed_batches(33 + i, 900 + 10 * i, 4, B, n, dev) for i in range(n_jobs)]
         plain = dict(sampler=0, filter_mode=-1, forward=False, window=(0, 0))
@@ -464,11 +473,11 @@ def _rccl_worker(port, q):
         for i in range(n_jobs):
             want = _replicated_general(aptrs, aidx, ts, w, job_seeds[i], states, [6, 4], 900 + 10 * i, plain)
             c = want.counts.cpu()
-            ok = ok and i in kept and torch.equal(kept[i][0].cpu(), c)
+            chk(i in kept and torch.equal(kept[i][0].cpu(), c), ("lanes", i, "counts"))
             for b in range(4):
                 y = want.batch(b, c)
                 x = kept[i][1][b]
-                ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+                chk(x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4])), ("lanes", i, "batch", b))
         # ... and under a filter with weights (the status word is read per super-batch)
         case = FILTER_CASES[4]
         pipe_g = partitioned.PipelinedPartitionedSampler(shard, 4, B, [6, 4], lanes=2, force_exchange=True, sampler=case["sampler"],
@@ -481,11 +490,11 @@ def _rccl_worker(port, q):
         for i in range(3):
             want = _replicated_general(aptrs, aidx, ts, w, job_seeds[i], states, [6, 4], 900 + 10 * i, case)
             c = want.counts.cpu()
-            ok = ok and torch.equal(kept[i][0].cpu(), c)
+            chk(torch.equal(kept[i][0].cpu(), c), ("lanes, filter + weights", i, "counts"))
             for b in range(4):
                 y = want.batch(b, c)
                 x = kept[i][1][b]
-                ok = ok and x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4]))
+                chk(x[4] == y[4] and all(torch.equal(u, v) for u, v in zip(x[:4], y[:4])), ("lanes, filter + weights", i, "batch", b))
         q.put(("ok" if ok else "mismatch %r" % (errs,), calls, dist.get_backend()))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
