@@ -211,6 +211,9 @@ typedef struct {
                                        the side stream, beside the hop's sort and gather; the emit pass writes `samples` only
                                        (< 0 in _set keeps) */
     int32_t stage_split_round_chunks; /* ... whose tiles hold this many 64-slot chunks (default 4; 0 in _set keeps) */
+    int32_t store_align64;          /* the emit passes' store instructions start on 64-byte boundaries (the elements before the
+                                       first boundary are stored alone): non-temporal stores of a chunk that two instructions
+                                       share go out as two partial writes (default 1; 0: 16-byte boundaries; < 0 in _set keeps) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

@@ -523,19 +523,23 @@ __device__ __forceinline__ void win_stage_emit_batch(const WinParams &p, const S
                 }
             }
             wave_lds_handoff();
-            // rows / cols / edge_index share the parity of their addresses (equal pitch, 16-byte aligned bases); samples
-            // (offset by n_seeds, pitch cap_nodes) has its own.  An element at an address that is not 16-byte aligned is
-            // stored alone, the rest as 16-byte pairs, one stream after the other (the emit kernel's store shape).
-            const uint32_t head = (uint32_t)(((uintptr_t)(rows + ea) >> 3) & 1);
-            const uint32_t head_s = (uint32_t)(((uintptr_t)(samples + n_seeds + ea) >> 3) & 1);
-            if (lane == 0 && total > 0) {
-                if (head && !SPLIT) {
-                    __builtin_nontemporal_store(n_seeds + ea, &rows[ea]);
-                    __builtin_nontemporal_store(i0 + (int64_t)slane[0], &cols[ea]);
-                    __builtin_nontemporal_store((int64_t)sptr[0], &eidx[ea]);
-                }
-                if (head_s) __builtin_nontemporal_store((int64_t)sval[0], &samples[n_seeds + ea]);
+            // rows / cols / edge_index share the alignment of their addresses (equal pitch, 16-byte aligned bases); samples
+            // (offset by n_seeds, pitch cap_nodes) has its own.  The elements up to the next 64-byte boundary (head: 0 .. 7)
+            // are stored alone, the rest as 16-byte pairs, one stream after the other: every store instruction of the
+            // wavefront then covers whole aligned 64-byte chunks.  The stores are non-temporal, and a chunk that two
+            // instructions share went out to memory as two partial writes: 14 % more write requests than the streams hold
+            // chunks (profiles/r04/pmc_traffic_staged_bpl16384.json); aligned: emit pass 3.03 -> 2.93 ms
+            // (tg_ns_win_tuning.store_align64, profiles/r04/ab_store_align64.jsonl)
+            const uint32_t am = p.store_align;
+            const uint32_t head = (uint32_t)((am + 1u - (uint32_t)(((uintptr_t)(rows + ea) >> 3) & am)) & am);
+            const uint32_t head_s = (uint32_t)((am + 1u - (uint32_t)(((uintptr_t)(samples + n_seeds + ea) >> 3) & am)) & am);
+            if ((uint32_t)lane < head && (uint32_t)lane < total && !SPLIT) {
+                __builtin_nontemporal_store(n_seeds + ea + (int64_t)lane, &rows[ea + lane]);
+                __builtin_nontemporal_store(i0 + (int64_t)slane[lane], &cols[ea + lane]);
+                __builtin_nontemporal_store((int64_t)sptr[lane], &eidx[ea + lane]);
             }
+            if ((uint32_t)lane < head_s && (uint32_t)lane < total)
+                __builtin_nontemporal_store((int64_t)sval[lane], &samples[n_seeds + ea + lane]);
             for (uint32_t q = head_s + 2u * lane; q < total; q += 128) { // :215
                 const int64_t e = ea + q;
                 if (q + 1 < total) {

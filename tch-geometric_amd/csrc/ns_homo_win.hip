@@ -85,6 +85,7 @@ struct WinParams {
     uint32_t *stage; // [max_items][stage_words] {column start, degree, neighbours}
     int32_t n_windows, idx_bits, next_idx_bits;
     int32_t n_wbuckets; // window buckets (multiple of 64); the staged form sorts by n_buckets = n_wbuckets / 8 COARSE buckets first
+    uint32_t store_align; // 7: the emit passes' store instructions start on 64-byte boundaries; 1: on 16-byte ones (round 3)
     void *items_fine;   // staged form: the items after the second sort level (what the gather kernel reads)
     uint32_t *fine_tot, *fine_start; // [(n_buckets + 1) * 128] items per absolute fine key / start of each key's run
     uint32_t *fine_tile_off;         // [tiles][256] offset of a tile's items inside each key's run
@@ -370,11 +371,15 @@ __device__ __forceinline__ WinState win_emit_hop(const WinParams &p, unsigned ch
                 // an element at an address that is not 16-byte aligned is stored alone (rows / cols / edge_index share the
                 // parity: equal pitch, 16-byte aligned bases); taken from the ADDRESS -- with an odd cap_edges the slabs of
                 // odd batches start on an odd element
-                const uint32_t head = (uint32_t)(((uintptr_t)(rows + ea) >> 3) & 1);
-                if (head && lane == 0 && total > 0) {
-                    __builtin_nontemporal_store(n_seeds + ea, &rows[ea]);
-                    __builtin_nontemporal_store(i0 + (int64_t)slane[0], &cols[ea]);
-                    __builtin_nontemporal_store(col0[c * 64 + slane[0]] + (int64_t)spos[0], &eidx[ea]);
+                // ... up to the next 64-byte boundary (WinParams.store_align = 7; round 3: 16-byte, = 1): from there every store
+                // instruction covers whole aligned chunks -- a chunk that two non-temporal store instructions share goes out as
+                // two partial writes
+                const uint32_t am = p.store_align;
+                const uint32_t head = (uint32_t)((am + 1u - (uint32_t)(((uintptr_t)(rows + ea) >> 3) & am)) & am);
+                if ((uint32_t)lane < head && (uint32_t)lane < total) {
+                    __builtin_nontemporal_store(n_seeds + ea + (int64_t)lane, &rows[ea + lane]);
+                    __builtin_nontemporal_store(i0 + (int64_t)slane[lane], &cols[ea + lane]);
+                    __builtin_nontemporal_store(col0[c * 64 + slane[lane]] + (int64_t)spos[lane], &eidx[ea + lane]);
                 }
                 for (uint32_t q = head + 2u * lane; q < total; q += 128) {
                     const int64_t e = ea + q;
@@ -772,7 +777,7 @@ struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
     int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches, stage_sort_blocks;
-    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks;
+    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks, store_align64;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -796,6 +801,7 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_CONCURRENT", 0),
         win_env_int("TG_WIN_STAGE_SPLIT", 0),
         win_env_int("TG_WIN_STAGE_SPLIT_ROUND_CHUNKS", 4),
+        win_env_int("TG_WIN_STORE_ALIGN64", 1),
     };
     return t;
 }
@@ -1315,6 +1321,7 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
                (long long)ws_bytes, (long long)L.total_push);
     TG_REQUIRE(((uintptr_t)ws & 255) == 0, "tg_ns_homo_batched_ws: workspace must be 256-byte aligned");
     WinParams p;
+    p.store_align = win_tuning().store_align64 ? 7u : 1u;
     p.ptrs = csc->ptrs;
     p.indices = csc->indices;
     p.indices32 = csc->indices32;
@@ -1393,6 +1400,7 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_concurrent = w.stage_concurrent;
     t->stage_split = w.stage_split;
     t->stage_split_round_chunks = w.stage_split_round_chunks;
+    t->store_align64 = w.store_align64;
     return TG_OK;
 }
 
@@ -1426,6 +1434,7 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_concurrent >= 0) w.stage_concurrent = t->stage_concurrent != 0;
     if (t->stage_split >= 0) w.stage_split = t->stage_split != 0;
     if (t->stage_split_round_chunks > 0) w.stage_split_round_chunks = t->stage_split_round_chunks;
+    if (t->store_align64 >= 0) w.store_align64 = t->store_align64 != 0;
     return TG_OK;
 }
 

@@ -243,17 +243,17 @@ __global__ void __launch_bounds__(64 * PART_SLOT_EMIT_WAVES) part_slot_emit_kern
             if (u < wave) ea += wave_tot[u];
             round_total += wave_tot[u];
         }
-        // the four streams; an element at an address that is not 16-byte aligned is stored alone, the rest as 16-byte pairs
-        const uint32_t head = (uint32_t)(((uintptr_t)(rows + ea) >> 3) & 1);
-        const uint32_t head_s = (uint32_t)(((uintptr_t)(samples + n_seeds + ea) >> 3) & 1);
-        if (lane == 0 && total > 0) {
-            if (head) {
-                __builtin_nontemporal_store(n_seeds + ea, &rows[ea]);                       // :217
-                __builtin_nontemporal_store(i0 + (int64_t)slane[0], &cols[ea]);
-                __builtin_nontemporal_store(ebase[slane[0]] + (int64_t)sptr[0], &eidx[ea]);
-            }
-            if (head_s) samples[n_seeds + ea] = (int64_t)sval[0];                           // :215 (the next hop's frontier)
+        // the four streams; the elements up to the next 64-byte boundary are stored alone, the rest as 16-byte pairs: every
+        // store instruction of the wavefront then covers whole aligned 64-byte chunks (ns_homo_stage.inl's emit pass)
+        const uint32_t head = (uint32_t)((8u - (uint32_t)(((uintptr_t)(rows + ea) >> 3) & 7u)) & 7u);
+        const uint32_t head_s = (uint32_t)((8u - (uint32_t)(((uintptr_t)(samples + n_seeds + ea) >> 3) & 7u)) & 7u);
+        if ((uint32_t)lane < head && (uint32_t)lane < total) {
+            __builtin_nontemporal_store(n_seeds + ea + (int64_t)lane, &rows[ea + lane]);                       // :217
+            __builtin_nontemporal_store(i0 + (int64_t)slane[lane], &cols[ea + lane]);
+            __builtin_nontemporal_store(ebase[slane[lane]] + (int64_t)sptr[lane], &eidx[ea + lane]);
         }
+        if ((uint32_t)lane < head_s && (uint32_t)lane < total)
+            samples[n_seeds + ea + lane] = (int64_t)sval[lane];                                               // :215 (the next hop's frontier)
         for (uint32_t q = head_s + 2u * lane; q < total; q += 128) {
             const int64_t e = ea + q;
             if (q + 1 < total) {
