@@ -1165,7 +1165,14 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             hipLaunchKernelGGL(win_basescan_kernel, dim3(1), dim3(1024), 0, ps, p);
             TG_LAUNCH_CHECK();
             clk.mark("scans", h, stream);
-            hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, ps, p);
+            {
+                static const int tiled = win_env_int("TG_WIN_SCATTER_TILED", 1);
+                if (tiled && p.n_buckets <= WIN_PART_THREADS && win_scatter8_tiled_lds(p.n_buckets, p.n_windows) <= 64 * 1024)
+                    hipLaunchKernelGGL(win_scatter8_tiled_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS),
+                                       win_scatter8_tiled_lds(p.n_buckets, p.n_windows), ps, p);
+                else
+                    hipLaunchKernelGGL(win_scatter8_kernel, dim3((unsigned)p.n_rows), dim3(WIN_PART_THREADS), tables, ps, p);
+            }
             TG_LAUNCH_CHECK();
             clk.mark("scatter", h, stream);
             if (t.stage_fine) {
