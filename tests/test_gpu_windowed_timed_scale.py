@@ -328,3 +328,33 @@ def test_slot_draw_fallback_runs_on_the_device(cabi):
         assert orc.slot_fallback_count() >= 3
         m = int(offsets[-1])
         assert m == len(o[3]) and np.array_equal(ep[:m].cpu().numpy(), o[3]) and np.array_equal(nbr[:m].cpu().numpy(), o[0][2048:])
+
+
+@pytest.mark.parametrize("align64", [1, 0])
+def test_frontiers_of_several_scatter_tiles_and_both_store_alignments(cabi, align64):
+    """sort level 1 works through LDS tiles of 4 096 items: seeds on the graph's heaviest columns give every batch a second
+    hop's frontier of > 12 000 items (three to four tiles per batch, the last one ragged); the emit passes' store
+    instructions start on 64-byte boundaries (store_align64 = 1, the default) or on 16-byte ones -- the same outputs as
+    the fused kernel and the oracle either way, odd pitches included (B = 1 023: slabs of odd batches start on an odd
+    element)"""
+    dev = torch.device(DEV)
+    n, ptrs, idx, g = _rmat(cabi, 16)
+    deg = ptrs[1:] - ptrs[:-1]
+    heavy = torch.argsort(deg, descending=True)[:4096]
+    nb, fan = 12, [15, 10]
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for B in (1024, 1023):
+        seeds = heavy[torch.randint(0, heavy.numel(), (nb, B), device=dev, generator=gen)].contiguous()
+        before = cabi.ns_win_tuning_set(staged=1, window_bytes=1 << 16, store_align64=align64)
+        try:
+            a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+            ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True, graph=g)
+            assert cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=ws, form=WINDOWED)
+            cabi.ns_homo_batched(g, seeds, fan, 3, 700, a, ws=ws, form=WINDOWED)
+            cabi.ns_homo_batched(g, seeds, fan, 3, 700, b, form=FUSED)
+            torch.cuda.synchronize()
+            assert int(a.layer_offsets[:, 1, 0].min()) - B > 12000      # every batch's second frontier spans several tiles
+            assert_equal_on_device(a, b)
+            assert_oracle(cabi, a, ptrs, idx, seeds, fan, 3, 700, (0, nb - 1))
+        finally:
+            cabi.ns_win_tuning_set(**before)
