@@ -624,7 +624,7 @@ def launch_size_sweep(torch, _cabi, graph, dev, B, fanout, n_nodes, first, sizes
     per-batch kernel and the window-ordered form forced -- sampled edges/s and roofline fraction each (HIP events)."""
     res = {}
     base = _cabi.ns_win_tuning()
-    _cabi.ns_win_tuning_set(staged=0, stage_parts=1)   # "auto" = the library's own defaults, not the headline's pick
+    _cabi.ns_win_tuning_set(staged=2, stage_parts=1)   # "auto" = the library's own defaults, not the headline's pick
     defaults = _cabi.ns_win_tuning()
     for G in sizes:
         out = _cabi.NsBatchedOut(G, B, fanout, dev)

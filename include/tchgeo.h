@@ -190,9 +190,11 @@ typedef struct {
     int32_t fold_hist;       /* emit kernels persistent, window histogram of the items kept in LDS instead of a pass of its
                                 own over the items (default 1; needs the two flags above and >= 2 hops) */
     int32_t emit_blocks;     /* workgroups of the persistent emit kernels (default 768, at most 1024) */
-    int32_t staged;          /* gather first, emit afterwards through 64-byte stage slots (default 0: measured slower than
-                                the push form; launches it does not fit -- ordered fan-outs > 30, ids beyond
-                                32 bits -- take the push form anyway) */
+    int32_t staged;          /* gather first, emit afterwards through packed 64-byte stage slots: 0 = never,
+                                1 = whenever it applies, 2 (default) = where it measures faster than the push form: launches
+                                of >= 12 288 batches whose slots are one chunk; launches it does not fit -- ordered fan-outs
+                                > 30, ids beyond 32 bits, a workspace without the slots -- take the push form anyway;
+                                < 0 in _set keeps */
     int32_t stage_round_chunks;   /* staged emit kernel: 64-slot chunks per round (default 2: the smaller tile lets five workgroups share a CU, emit 3.15 -> 3.07 ms; at most 16) */
     int32_t stage_gather_threads; /* staged gather kernel: workgroup size (default 512) */
     int32_t stage_gather_blocks;  /* ... and workgroups (default 512) */

@@ -789,7 +789,7 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_FUSE_FIRST_HOPS", 1),
         win_env_int("TG_WIN_FOLD_HIST", 1),
         win_env_int("TG_WIN_EMIT_BLOCKS", 768),
-        win_env_int("TG_WIN_STAGED", 0),
+        win_env_int("TG_WIN_STAGED", 2),
         win_env_int("TG_WIN_STAGE_ROUND_CHUNKS", 2),
         win_env_int("TG_WIN_STAGE_GATHER_THREADS", 512),
         win_env_int("TG_WIN_STAGE_GATHER_BLOCKS", 512),
@@ -990,9 +990,17 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
 }
 
 // ---------------------------------------------------------------- staged form: host side
+// tg_ns_win_tuning.staged: 0 = never, 1 = whenever it applies, 2 (default) = where it measures faster than the push form:
+// launches of >= 12 288 batches whose stage slots are ONE chunk (RMAT-24, [15, 10]: 7.3 against 7.7-8.15 ms at 16 384
+// batches; level with the push form at 4 096-8 192, profiles/r04/sweep_launch_size.jsonl)
+constexpr int64_t WIN_STAGED_AUTO_MIN_BATCHES = 12288;
+static bool win_staged_wanted(const WinTuning &t, int64_t n_batches, int stage_words) {
+    if (t.staged == 2) return n_batches >= WIN_STAGED_AUTO_MIN_BATCHES && stage_words == 16;
+    return t.staged != 0;
+}
 static bool win_staged_applicable(const WinParams &p, const WinTuning &t, const tg_graph *csc, int64_t n_batches,
                                   const int64_t *fanout, int32_t n_hops, int stage_words) {
-    if (!t.staged || !t.direct_hop0 || n_hops < 2 || stage_words == 0) return false;
+    if (!win_staged_wanted(t, n_batches, stage_words) || !t.direct_hop0 || n_hops < 2 || stage_words == 0) return false;
     if (csc->n_major >= ((int64_t)1 << 32) || csc->n_edges >= ((int64_t)1 << 32)) return false; // 32-bit items / slots
     int64_t pitch = p.n_seeds;
     for (int h = 1; h < n_hops; ++h) {
@@ -1287,10 +1295,11 @@ extern "C" int tg_ns_homo_workspace_bytes_for(const tg_graph *csc, int64_t n_bat
                "tg_ns_homo_workspace_bytes: bad arguments");
     for (int h = 0; h < n_hops; ++h)
         TG_REQUIRE(fanout[h] >= 1 && fanout[h] <= 255, "tg_ns_homo_workspace_bytes: fanout[%d] outside [1, 255]", h);
-    // the staged pipeline's stage slots (16 GB for the 16 384-batch bench launch) only when that pipeline is switched on
-    // (tg_ns_win_tuning.staged) at the time of the query; a launch whose workspace lacks them takes the push form
+    // the staged pipeline's stage slots (2.9 GB for the 16 384-batch bench launch with one-chunk slots) only when that
+    // pipeline would be taken (tg_ns_win_tuning.staged) at the time of the query; a launch whose workspace lacks them takes
+    // the push form
     const tg::WinLayout L = tg::win_layout(csc, n_batches, n_seeds, fanout, n_hops);
-    *n_bytes = (int64_t)(tg::win_tuning().staged ? L.total : L.total_push);
+    *n_bytes = (int64_t)(tg::win_staged_wanted(tg::win_tuning(), n_batches, L.stage_words) ? L.total : L.total_push);
     return TG_OK;
 }
 extern "C" int tg_ns_homo_workspace_bytes(int64_t n_batches, int64_t n_seeds, const int64_t *fanout, int32_t n_hops,
@@ -1429,7 +1438,7 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->fuse_first_hops >= 0) w.fuse_first_hops = t->fuse_first_hops != 0;
     if (t->fold_hist >= 0) w.fold_hist = t->fold_hist != 0;
     if (t->emit_blocks > 0) w.emit_blocks = t->emit_blocks;
-    if (t->staged >= 0) w.staged = t->staged != 0;
+    if (t->staged >= 0) w.staged = t->staged > 2 ? 1 : t->staged;
     if (t->stage_round_chunks > 0) w.stage_round_chunks = t->stage_round_chunks;
     if (t->stage_gather_threads >= 64 && t->stage_gather_threads <= 1024) w.stage_gather_threads = t->stage_gather_threads & ~63;
     if (t->stage_gather_blocks > 0) w.stage_gather_blocks = t->stage_gather_blocks;

@@ -358,3 +358,25 @@ def test_frontiers_of_several_scatter_tiles_and_both_store_alignments(cabi, alig
             assert_oracle(cabi, a, ptrs, idx, seeds, fan, 3, 700, (0, nb - 1))
         finally:
             cabi.ns_win_tuning_set(**before)
+
+
+def test_pipeline_is_chosen_by_launch_size_by_default(cabi):
+    """tg_ns_win_tuning.staged = 2 (the default): the staged pipeline from 12 288 batches on when the stage slots are one
+    chunk, the push pipeline below that and for two-chunk slots; the workspace query follows the same rule; both equal the
+    fused kernel"""
+    dev = torch.device(DEV)
+    n, ptrs, idx, g = _rmat(cabi, 12)
+    assert cabi.ns_win_tuning()["staged"] == 2
+    B = 4
+    for nb, fan, want in ((12288, [15, 10], True), (12287, [15, 10], False), (12288, [4, 20], False)):
+        ws = cabi.ns_homo_workspace(nb, B, fan, dev, graph=g)                     # sized as the rule says
+        push_only = cabi.ns_homo_workspace(nb, B, fan, dev, staged=False, graph=g)
+        assert (ws.numel() > push_only.numel()) == want
+        a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
+        assert bool(cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=ws, form=WINDOWED)) == want
+        seeds = cabi.seed_batches(0xBA7C4, 0, nb, B, n, dev)
+        cabi.ns_homo_batched(g, seeds, fan, 1, 0, a, ws=ws, form=WINDOWED)
+        cabi.ns_homo_batched(g, seeds, fan, 1, 0, b, form=FUSED)
+        torch.cuda.synchronize()
+        assert_equal_on_device(a, b)
+        del a, b, ws, push_only
