@@ -413,16 +413,23 @@ def test_filters_and_weights_equal_the_replicated_launch(case, world, packed):
 
 
 # ---------------------------------------------------------------- the multi-rank protocol over RCCL itself, one rank
-def _rccl_worker(port, q):
+def _rccl_worker(ports, q):
     for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tch-geometric_amd")):
         sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
         from tch_geometric import _cabi, partitioned
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        for attempt, port in enumerate(ports):      # a port probed free can be taken again before the store binds it
+            os.environ["MASTER_PORT"] = str(port)
+            try:
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                break
+            except Exception:  # noqa: BLE001
+                if attempt + 1 == len(ports):
+                    raise
         ok, calls = True, 0
         errs = []
 
@@ -506,7 +513,7 @@ def test_protocol_over_rccl_with_one_rank():
     RCCL (`backend="nccl"`) with device tensors: one rank exchanging with itself -- the transport a one-GPU box can run"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_rccl_worker, args=([_free_port() for _ in range(3)], q))
     p.start()
     status, calls, backend = q.get(timeout=300)
     p.join(timeout=120)
