@@ -216,6 +216,15 @@ typedef struct {
     int32_t store_align64;          /* the emit passes' store instructions start on 64-byte boundaries (the elements before the
                                        first boundary are stored alone): non-temporal stores of a chunk that two instructions
                                        share go out as two partial writes (default 1; 0: 16-byte boundaries; < 0 in _set keeps) */
+    int32_t stage_gather_mode;      /* staged form, variants of the gather kernel (experiments; 0 = the default kernel): bits 0-1 =
+                                       log2 of the slices a wavefront takes between two barriers, bit 2 = 16-byte slot stores,
+                                       bit 3 = column bounds as one 8-byte load, bit 4 = non-temporal item loads and slot stores
+                                       (< 0 in _set keeps) */
+    int32_t stage_fine_sub_bits;    /* staged form: the second sort level orders a window's vertices into 1 << this many sub-ranges
+                                       (4 .. 7, default 7: the finer the order, the fewer columns a gather workgroup's slice touches --
+                                       gather 2.39 / 2.26 / 2.11 / 2.01 ms at 4 / 5 / 6 / 7, the sort 0.46 / 0.47 / 0.52 / 0.56; 0 in _set keeps) */
+    int32_t stage_fine_blocks;      /* staged form: workgroups of the second sort level's two passes (default 2048, rounded up to a
+                                       multiple of 8; 0 in _set keeps) */
 } tg_ns_win_tuning;
 TG_API int tg_ns_win_tuning_get(tg_ns_win_tuning *t);
 TG_API int tg_ns_win_tuning_set(const tg_ns_win_tuning *t);

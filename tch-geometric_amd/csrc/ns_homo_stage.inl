@@ -32,15 +32,17 @@ static_assert(sizeof(WinItem8) == 8, "item layout");
 //   coarse = window bucket / 8      (<= 1 024 coarse buckets: one counting-sort pass whose open destination lines -- rows x
 //            coarse buckets -- stay in the L2s, so the 8-byte items leave as whole chunks; the round-3 sort scattered them
 //            over rows x 2 048 buckets = 134 MB of open lines and paid a partial-chunk write per item)
-//   fine   = (window bucket % 8) * 16 + sub-bucket of the vertex inside its window's vertex range (16 by a shift)
+//   fine   = (window bucket % 8) * S + sub-bucket of the vertex inside its window's vertex range (S = 16 .. 64 by a shift:
+//            tg_ns_win_tuning.stage_fine_sub_bits)
 //            (a pass of its own INSIDE each coarse bucket, whose ~1 MB segment is L2-resident).
 // Items of one vertex end up adjacent and the vertices of a window in ascending order: a gather workgroup's slice then
 // lies in one or two columns, which its L1 holds (760 G gathers/s against 260 from L2: profiles/r04/probe_gather_small.json).
 struct StageKey {
     uint32_t coarse, fine;
 };
-constexpr int WIN_FINE_PER_COARSE = 128;
-__device__ __forceinline__ StageKey win_stage_key(const uint32_t *vtab, int n_windows, int n_wbuckets, uint32_t v) {
+constexpr int WIN_FINE_SUB_BITS_MAX = 7;                              // sub-ranges of a window's vertex range: 16 .. 128 (default)
+constexpr int WIN_FINE_PER_COARSE_MAX = 8 << WIN_FINE_SUB_BITS_MAX; // fine keys per coarse bucket, at most
+__device__ __forceinline__ StageKey win_stage_key(const uint32_t *vtab, int n_windows, int n_wbuckets, uint32_t v, int sub_bits) {
     int lo = 0, hi = n_windows;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -51,9 +53,9 @@ __device__ __forceinline__ StageKey win_stage_key(const uint32_t *vtab, int n_wi
     }
     const uint32_t wb = ((uint32_t)lo & 7u) * (uint32_t)(n_wbuckets >> 3) + ((uint32_t)lo >> 3);
     const uint32_t v0 = vtab[lo], range = vtab[lo + 1] - v0; // >= 1 for a vertex of the graph
-    const int sh = max(0, 28 - (int)__clz((int)((range - 1u) | 1u))); // (range - 1) >> sh < 16
-    const uint32_t sub = min(15u, (v - v0) >> sh);
-    return StageKey{wb >> 3, ((wb & 7u) << 4) | sub};
+    const int sh = max(0, 32 - sub_bits - (int)__clz((int)((range - 1u) | 1u))); // (range - 1) >> sh < 1 << sub_bits
+    const uint32_t sub = min((1u << sub_bits) - 1u, (v - v0) >> sh);
+    return StageKey{wb >> 3, ((wb & 7u) << sub_bits) | sub};
 }
 
 __global__ void win_vtab_kernel(const WinParams p, int64_t n_major) {
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_kernel(const Wi
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (ok[u])
-                    sorted[atomicAdd(&cur[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v).coarse], 1u)] = it[u];
+                    sorted[atomicAdd(&cur[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v, 4).coarse], 1u)] = it[u];
         }
     }
 }
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_tiled_kernel(co
                 key[u] = 0xffffffffu;
                 if (j < nt) {
                     it[u] = src[t0 + j];
-                    key[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v).coarse;
+                    key[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v, 4).coarse;
                 }
             }
 #pragma unroll
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinPa
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) atomicAdd(&h[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u]).coarse], 1u);
+                if (ok[u]) atomicAdd(&h[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u], 4).coarse], 1u);
         }
     }
     __syncthreads();
@@ -279,22 +281,31 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinPa
 // key's run depends on which tile's atomic came first; it does not matter (outputs are addressed by the item's own slot).
 // Bins beyond the tile's first two coarse buckets are clamped into the last bin of the second (possible only when coarse
 // buckets hold fewer items than a tile): the order only matters for speed, and COUNT and PLACE clamp alike.
-constexpr int WIN_FINE_TILE = 4096, WIN_FINE_THREADS = 512, WIN_FINE_BINS = 2 * WIN_FINE_PER_COARSE;
+constexpr int WIN_FINE_TILE = 4096, WIN_FINE_THREADS = 512, WIN_FINE_BINS_MAX = 2 * WIN_FINE_PER_COARSE_MAX;
 template <bool PLACE>
 __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const WinParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t h[WIN_FINE_BINS];
+    __shared__ uint32_t h[WIN_FINE_BINS_MAX];
     __shared__ uint32_t c0_s;
     uint32_t *lvtab = reinterpret_cast<uint32_t *>(smem);
     const WinItem8 *src = static_cast<const WinItem8 *>(p.items_sorted);
     WinItem8 *dst = static_cast<WinItem8 *>(p.items_fine);
     const int tid = threadIdx.x;
+    const int sub_bits = p.fine_sub_bits, per_coarse = 8 << sub_bits, bins = 2 * per_coarse;
     for (int i = tid; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
     const uint32_t n = p.base[p.n_buckets];
     constexpr int U = WIN_FINE_TILE / WIN_FINE_THREADS;
-    for (uint32_t tile = blockIdx.x; (uint64_t)tile * WIN_FINE_TILE < n; tile += gridDim.x) {
+    // tile -> workgroup: XCD x (= blockIdx & 7) takes the x-th eighth of the tiles, its workgroups walk it together -- the runs
+    // the resident tiles write into then lie in a few coarse segments PER XCD, whose L2 merges the 8-byte writes
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)n + WIN_FINE_TILE - 1) / WIN_FINE_TILE);
+    const bool by_xcd = p.fine_by_xcd && (gridDim.x & 7) == 0;
+    const uint32_t per_xcd = by_xcd ? (n_tiles + 7) / 8 : n_tiles;
+    const uint32_t tile_lo = by_xcd ? (blockIdx.x & 7) * per_xcd : 0u;
+    const uint32_t tile_hi = min(n_tiles, tile_lo + per_xcd);
+    const uint32_t tile_step = by_xcd ? gridDim.x >> 3 : gridDim.x;
+    for (uint32_t tile = tile_lo + (by_xcd ? blockIdx.x >> 3 : blockIdx.x); tile < tile_hi; tile += tile_step) {
         const uint32_t t0 = tile * WIN_FINE_TILE;
-        uint32_t *tile_off = p.fine_tile_off + (size_t)tile * WIN_FINE_BINS;
+        uint32_t *tile_off = p.fine_tile_off + (size_t)tile * bins;
         WinItem8 it[U];
         uint32_t key[U], rank[U];
         bool ok[U];
@@ -304,30 +315,30 @@ __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const W
             ok[u] = j < n;
             if (ok[u]) it[u] = src[j];
         }
-        if (tid < WIN_FINE_BINS) h[tid] = PLACE ? tile_off[tid] : 0u; // PLACE: the tile's reserved offsets, then cursors
+        for (int i = tid; i < bins; i += WIN_FINE_THREADS) h[i] = PLACE ? tile_off[i] : 0u; // PLACE: the tile's reserved offsets, then cursors
         __syncthreads(); // also: the vertex table is loaded
         StageKey sk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (ok[u]) sk[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v);
+            if (ok[u]) sk[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v, sub_bits);
         if (tid == 0) c0_s = sk[0].coarse; // the tile's first item lies in its smallest coarse bucket
         __syncthreads();
         const uint32_t c0 = c0_s;
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (ok[u]) {
-                key[u] = min((uint32_t)WIN_FINE_BINS - 1u, (sk[u].coarse - c0) * WIN_FINE_PER_COARSE + sk[u].fine);
+                key[u] = min((uint32_t)bins - 1u, (sk[u].coarse - c0) * per_coarse + sk[u].fine);
                 rank[u] = atomicAdd(&h[key[u]], 1u);
             }
         if (PLACE) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) dst[p.fine_start[(size_t)c0 * WIN_FINE_PER_COARSE + key[u]] + rank[u]] = it[u];
+                if (ok[u]) dst[p.fine_start[(size_t)c0 * per_coarse + key[u]] + rank[u]] = it[u];
         } else {
             __syncthreads();
-            if (tid < WIN_FINE_BINS) {
-                const uint32_t cnt = h[tid];
-                tile_off[tid] = cnt ? atomicAdd(&p.fine_tot[(size_t)c0 * WIN_FINE_PER_COARSE + tid], cnt) : 0u;
+            for (int i = tid; i < bins; i += WIN_FINE_THREADS) {
+                const uint32_t cnt = h[i];
+                tile_off[i] = cnt ? atomicAdd(&p.fine_tot[(size_t)c0 * per_coarse + i], cnt) : 0u;
             }
         }
         __syncthreads();
@@ -339,21 +350,28 @@ __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const W
 // bins count under a neighbouring key, and only a prefix over everything keeps the runs disjoint whatever was counted
 // where.  One workgroup: a wavefront sums a bucket's 128 keys, the bucket totals are scanned in LDS, then the same
 // wavefronts write their bucket's starts.
+// Two launches: the keys' totals per coarse bucket (a wavefront per bucket), then every workgroup scans the bucket totals for
+// itself (a thousand values) and its 16 wavefronts write their buckets' starts.  (One workgroup doing all of it took 124 us
+// at 512 keys per bucket.)
+__global__ void __launch_bounds__(1024) win_fine_rowsum_kernel(const WinParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = p.n_buckets + 1, c = blockIdx.x * 16 + wave;
+    if (c >= rows) return;
+    const int per_coarse = 8 << p.fine_sub_bits, per_lane = per_coarse >> 6;
+    uint32_t mine = 0;
+    for (int i = 0; i < per_lane; ++i) mine += p.fine_tot[(size_t)c * per_coarse + per_lane * lane + i];
+    const uint32_t t = wave_sum(mine);
+    if (lane == 0) p.fine_rowtot[c] = t;
+}
 __global__ void __launch_bounds__(1024) win_fine_starts_kernel(const WinParams p) {
     __shared__ uint32_t tot[WIN_MAX_BUCKETS / 8 + 8], wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows = p.n_buckets + 1;
-    for (int c = wave; c < rows; c += 16) {
-        const uint32_t a = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane];
-        const uint32_t b = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane + 1];
-        const uint32_t t = wave_sum(a + b);
-        if (lane == 0) tot[c] = t;
-    }
-    __syncthreads();
+    const int per_coarse = 8 << p.fine_sub_bits, per_lane = per_coarse >> 6; // 2 .. 32 consecutive keys per lane
     uint32_t carry = 0;
     for (int c0 = 0; c0 < rows; c0 += 1024) { // exclusive scan of the bucket totals, 1 024 at a time
         const int c = c0 + tid;
-        const uint32_t v = c < rows ? tot[c] : 0u;
+        const uint32_t v = c < rows ? p.fine_rowtot[c] : 0u;
         const uint32_t incl = wave_inclusive_scan(v);
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
@@ -365,12 +383,16 @@ __global__ void __launch_bounds__(1024) win_fine_starts_kernel(const WinParams p
         carry += all;
         __syncthreads();
     }
-    for (int c = wave; c < rows; c += 16) {
-        const uint32_t a = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane];
-        const uint32_t b = p.fine_tot[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane + 1];
-        const uint32_t incl = wave_inclusive_scan(a + b);
-        p.fine_start[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane] = tot[c] + incl - (a + b);
-        p.fine_start[(size_t)c * WIN_FINE_PER_COARSE + 2 * lane + 1] = tot[c] + incl - b;
+    const int c = blockIdx.x * 16 + wave;
+    if (c < rows) {
+        uint32_t mine = 0;
+        for (int i = 0; i < per_lane; ++i) mine += p.fine_tot[(size_t)c * per_coarse + per_lane * lane + i];
+        const uint32_t incl = wave_inclusive_scan(mine);
+        uint32_t at = tot[c] + incl - mine;
+        for (int i = 0; i < per_lane; ++i) {
+            p.fine_start[(size_t)c * per_coarse + per_lane * lane + i] = at;
+            at += p.fine_tot[(size_t)c * per_coarse + per_lane * lane + i];
+        }
     }
 }
 
@@ -480,6 +502,151 @@ __global__ void win_stage_gather_kernel(const WinParams p, const StageBits sb) {
             const int item_l = r * PER + lane / W, word = lane % W;
             const uint32_t sj = jrow[item_l];
             if (sj != 0xffffffffu) p.stage[(size_t)sj * W + word] = tile[item_l * (W + 1) + word];
+        }
+        if (tid == 0) slice_lo[buf ^ 1] = nxt;
+        __syncthreads();
+    }
+}
+
+// Variants of the pass above behind tg_ns_win_tuning.stage_gather_mode (experiments; outputs never depend on them):
+//   bits 0-1  S = 1 << bits: a workgroup takes S slices per wavefront from the queue at a time and meets at the barrier once
+//             per S slices; between barriers its wavefronts run free (slice u of wavefront w = the chunk's slice u * n_waves + w)
+//   bit 2     the slot leaves as 16-byte stores (W / 4 store instructions per 64 items instead of W)
+//   bit 3     the column bounds as ONE 8-byte load of ptrs32[v], ptrs32[v + 1]
+//   bit 4     items read and slots stored non-temporally
+// Tried and dropped: no queue at all (the XCD's range cut into one contiguous range per workgroup: 4.2 ms against 2.4, its
+// L2 must hold 64 windows at once; chunks dealt out round-robin: 3.9 ms -- the workgroups drift apart and out of each other's
+// windows; the queue keeps them together).
+template <int W, int KMAX, bool REPLACE>
+__global__ void win_stage_gather_flex_kernel(const WinParams p, const StageBits sb, const int mode) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned long long slice_lo[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * (64 * (W + 1) + 64);
+    uint32_t *jrow = tile + 64 * (W + 1);
+    const WinItem8 *items = static_cast<const WinItem8 *>(p.items_fine);
+    const int k = p.k;
+    WinQueues::Q *Q = &p.queues->q[blockIdx.x & 7];
+    const unsigned long long qend = Q->end;
+    const int S = 1 << (mode & 3);
+    const bool wide_stores = mode & 4, ptr_pair = (mode & 8) && p.ptrs32, nt = mode & 16;
+    const unsigned long long chunk = (unsigned long long)blockDim.x * S;
+    const uint32_t idx_mask = (1u << p.idx_bits) - 1u;
+
+    if (tid == 0) slice_lo[0] = atomicAdd(&Q->head, chunk);
+    __syncthreads();
+    for (int buf = 0;; buf ^= 1) {
+        const unsigned long long lo = slice_lo[buf];
+        if (lo >= qend) break;
+        unsigned long long nxt = 0;
+        if (tid == 0) nxt = atomicAdd(&Q->head, chunk);
+        for (int u = 0; u < S; ++u) {
+            const unsigned long long j = lo + ((unsigned long long)u * n_waves + wave) * 64 + lane;
+            if (j - lane >= qend) break; // wave-uniform
+            const bool live = j < qend;
+            uint32_t slot_index = 0xffffffffu, e0w = 0, cnt = 0;
+            uint32_t pos[KMAX], nbr[KMAX];
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) pos[s] = nbr[s] = 0u;
+            if (live) {
+                WinItem8 it;
+                if (nt) {
+                    const u32x2 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + j));
+                    it = WinItem8{raw.x, raw.y};
+                } else
+                    it = items[j];
+                TG_CHECK_VERTEX(p, it.v);
+                const uint32_t b = it.bs >> p.idx_bits, idx = it.bs & idx_mask;
+                uint64_t e0, e1;
+                if (ptr_pair) {
+                    u32x2 pr;
+                    __builtin_memcpy(&pr, p.ptrs32 + it.v, 8); // 4-byte aligned
+                    e0 = pr.x;
+                    e1 = pr.y;
+                } else if (p.ptrs32) {
+                    e0 = p.ptrs32[it.v];
+                    e1 = p.ptrs32[it.v + 1];
+                } else {
+                    e0 = (uint64_t)p.ptrs[it.v];
+                    e1 = (uint64_t)p.ptrs[(int64_t)it.v + 1];
+                }
+                const uint32_t n = (uint32_t)(e1 - e0);
+                cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
+                slot_index = (uint32_t)((int64_t)b * p.item_pitch + idx);
+                e0w = (uint32_t)e0;
+                if (cnt > 0) {
+                    if (REPLACE || n > (uint32_t)k) {
+                        const CallKey ck = p.call_keys[b];
+                        const int64_t fbegin = p.hop == 1 ? p.n_seeds : p.state[b].begin;
+                        const uint64_t did = (uint64_t)(p.id_base + fbegin + (int64_t)idx);
+                        if (REPLACE) // sampling.rs:57-69
+                            slot_draws<KMAX, true>(ck, did, n, k, pos);
+                        else
+                            sample_tickets_reg<KMAX>(ck, did, n, k, pos);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KMAX; ++s) pos[s] = (uint32_t)s; // sampling.rs:12-15: the reservoir is just filled
+                    }
+                    if (p.indices32) {
+#pragma unroll
+                        for (int s = 0; s < KMAX; ++s)
+                            if ((uint32_t)s < cnt) nbr[s] = p.indices32[e0 + pos[s]];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < KMAX; ++s)
+                            if ((uint32_t)s < cnt) nbr[s] = (uint32_t)p.indices[e0 + pos[s]];
+                    }
+                }
+            }
+            { // the slot as a bit stream into this lane's row of the tile
+                BitWriter bw{tile + lane * (W + 1), (uint64_t)e0w | ((uint64_t)cnt << 32), 8, 1};
+                tile[lane * (W + 1)] = e0w;
+                bw.acc >>= 32;
+#pragma unroll
+                for (int s = 0; s < KMAX; ++s) {
+                    if (s < k) {
+                        const bool on = (uint32_t)s < cnt;
+                        bw.push(on ? nbr[s] : 0u, sb.bv);
+                        bw.push(on ? pos[s] : 0u, sb.bp);
+                    }
+                }
+                bw.finish(W);
+            }
+            jrow[lane] = slot_index;
+            wave_lds_handoff();
+            if (wide_stores) { // 4 lanes (W = 16) or 8 (W = 32) write one item's slot as 16-byte pieces
+                constexpr int PIECES = W / 4, PER = 64 / PIECES;
+#pragma unroll
+                for (int r = 0; r < PIECES; ++r) {
+                    const int item_l = r * PER + lane / PIECES, piece = lane % PIECES;
+                    const uint32_t sj = jrow[item_l];
+                    const uint32_t *t = tile + item_l * (W + 1) + piece * 4;
+                    const u32x4 v = {t[0], t[1], t[2], t[3]};
+                    if (sj != 0xffffffffu) {
+                        u32x4 *dst = reinterpret_cast<u32x4 *>(p.stage + (size_t)sj * W + piece * 4);
+                        if (nt)
+                            __builtin_nontemporal_store(v, dst);
+                        else
+                            *dst = v;
+                    }
+                }
+            } else {
+                constexpr int PER = 64 / W;
+#pragma unroll
+                for (int r = 0; r < W; ++r) {
+                    const int item_l = r * PER + lane / W, word = lane % W;
+                    const uint32_t sj = jrow[item_l];
+                    if (sj != 0xffffffffu) {
+                        if (nt)
+                            __builtin_nontemporal_store(tile[item_l * (W + 1) + word], &p.stage[(size_t)sj * W + word]);
+                        else
+                            p.stage[(size_t)sj * W + word] = tile[item_l * (W + 1) + word];
+                    }
+                }
+            }
+            wave_lds_handoff(); // the tile is read out before the next slice's rows are written
         }
         if (tid == 0) slice_lo[buf ^ 1] = nxt;
         __syncthreads();

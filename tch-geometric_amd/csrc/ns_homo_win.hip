@@ -87,10 +87,13 @@ struct WinParams {
     int32_t n_wbuckets; // window buckets (multiple of 64); the staged form sorts by n_buckets = n_wbuckets / 8 COARSE buckets first
     uint32_t store_align; // 7: the emit passes' store instructions start on 64-byte boundaries; 1: on 16-byte ones (round 3)
     void *items_fine;   // staged form: the items after the second sort level (what the gather kernel reads)
+    uint32_t *fine_rowtot;           // [n_buckets + 1] items per coarse bucket as the second level counted them
     uint32_t *fine_tot, *fine_start; // [(n_buckets + 1) * 128] items per absolute fine key / start of each key's run
     uint32_t *fine_tile_off;         // [tiles][256] offset of a tile's items inside each key's run
     int64_t next_pitch;
     int64_t b0; // staged form in parts: the kernels of a part walk batches [b0, b0 + n_batches)
+    int32_t fine_by_xcd;
+    int32_t fine_sub_bits; // staged form: log2 of the sub-ranges a window's vertices are ordered into by the second sort level
     TG_BOUNDS_FIELDS
 };
 
@@ -763,7 +766,7 @@ __global__ void win_gather_kernel(const WinParams p) {
 // lhist (first kernel): the workgroup's coarse histogram in LDS, its vertex table right behind it
 __device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v, uint32_t *lhist) {
     static_cast<WinItem8 *>(p.items_in)[b * p.next_pitch + rel] = WinItem8{v, ((uint32_t)b << p.next_idx_bits) | rel};
-    if (lhist) atomicAdd(&lhist[win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v).coarse], 1u);
+    if (lhist) atomicAdd(&lhist[win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v, 4).coarse], 1u);
 }
 
 static int win_env_int(const char *name, int dflt) {
@@ -777,7 +780,7 @@ struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
     int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches, stage_sort_blocks;
-    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks, store_align64;
+    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks, store_align64, stage_gather_mode, stage_fine_sub_bits, stage_fine_blocks;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -802,6 +805,9 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_SPLIT", 0),
         win_env_int("TG_WIN_STAGE_SPLIT_ROUND_CHUNKS", 4),
         win_env_int("TG_WIN_STORE_ALIGN64", 1),
+        win_env_int("TG_WIN_STAGE_GATHER_MODE", 0),
+        win_env_int("TG_WIN_STAGE_FINE_SUB_BITS", 7),
+        win_env_int("TG_WIN_STAGE_FINE_BLOCKS", 2048),
     };
     return t;
 }
@@ -886,9 +892,9 @@ static WinLayout win_layout(const tg_graph *csc, int64_t n_batches, int64_t n_se
     L.items_sorted = take((size_t)L.max_items * sizeof(WinItemW));
     L.vtab = take((size_t)(WIN_MAX_BUCKETS + 8) * sizeof(uint32_t));
     L.total_push = at; // what the push form needs; the staged form's tables and slots come after it
-    L.fine_tot = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * 128 * sizeof(uint32_t));
-    L.fine_start = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * 128 * sizeof(uint32_t));
-    L.fine_tile_off = take(((size_t)L.max_items / 4096 + WIN_MAX_PARTS + 1) * 256 * sizeof(uint32_t));
+    L.fine_tot = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX * sizeof(uint32_t));
+    L.fine_start = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX * sizeof(uint32_t));
+    L.fine_tile_off = take(((size_t)L.max_items / WIN_FINE_TILE + WIN_MAX_PARTS + 1) * WIN_FINE_BINS_MAX * sizeof(uint32_t));
     L.stage_words = win_stage_words(csc, fanout, n_hops);
     L.stage = take((size_t)L.max_items * L.stage_words * sizeof(uint32_t));
     L.total = at;
@@ -1153,7 +1159,17 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             const size_t elds = win_stage_emit_lds_bytes(W, p.k, ethreads / 64, rc, split);
             int gthreads = t.stage_gather_threads;
             const size_t per_wave = (size_t)(64 * (W + 1) + 64) * sizeof(uint32_t);
-            while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 64 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
+            while (gthreads > 64 && (size_t)(gthreads / 64) * per_wave > 128 * 1024) gthreads = ((gthreads >> 1) + 63) & ~63;
+            if ((size_t)(gthreads / 64) * per_wave > 64 * 1024) { // gfx950: 160 KB of LDS per CU, a workgroup may take it all when asked
+                static bool raised = false; // per instantiation of this function template = per gather kernel
+                if (!raised) {
+                    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&win_stage_gather_kernel<W, KMAX, REPLACE>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&win_stage_gather_flex_kernel<W, KMAX, REPLACE>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    raised = true;
+                }
+            }
             const int gblocks = (std::max(t.stage_gather_blocks, 8) + 7) & ~7;
             part_tables(part);
             p.b0 = b0;
@@ -1186,15 +1202,21 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             if (t.stage_fine) {
                 const int64_t worst = p.n_batches * p.item_pitch; // the item count itself lives on the device
                 const size_t vt = (size_t)(p.n_windows + 1) * sizeof(uint32_t);
-                const size_t keys = (size_t)(p.n_buckets + 1) * WIN_FINE_PER_COARSE;
-                p.fine_tot = fine_tot0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE;
-                p.fine_start = fine_start0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE;
-                p.fine_tile_off = fine_tile_off0 + ((size_t)(p.b0 * p.item_pitch) / WIN_FINE_TILE + (size_t)part) * WIN_FINE_BINS;
-                const unsigned tiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>((worst + WIN_FINE_TILE - 1) / WIN_FINE_TILE, 2048));
+                p.fine_sub_bits = std::min(std::max(t.stage_fine_sub_bits, 4), WIN_FINE_SUB_BITS_MAX);
+                p.fine_by_xcd = (t.stage_gather_mode >> 5) & 1;
+                const int per_coarse = 8 << p.fine_sub_bits;
+                const size_t keys = (size_t)(p.n_buckets + 1) * per_coarse;
+                p.fine_tot = fine_tot0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX;
+                p.fine_start = fine_start0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX;
+                p.fine_tile_off = fine_tile_off0 + ((size_t)(p.b0 * p.item_pitch) / WIN_FINE_TILE + (size_t)part) * WIN_FINE_BINS_MAX;
+                p.fine_rowtot = p.fine_start + (size_t)(WIN_MAX_BUCKETS / 8 + 1) * WIN_FINE_PER_COARSE_MAX; // the slack rows behind the starts
+                const unsigned tiles = (unsigned)std::max<int64_t>(1, std::min<int64_t>((worst + WIN_FINE_TILE - 1) / WIN_FINE_TILE, t.stage_fine_blocks));
                 TG_HIP(hipMemsetAsync(p.fine_tot, 0, keys * sizeof(uint32_t), ps));
                 hipLaunchKernelGGL(win_sort_fine_kernel<false>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, ps, p);
                 TG_LAUNCH_CHECK();
-                hipLaunchKernelGGL(win_fine_starts_kernel, dim3(1), dim3(1024), 0, ps, p);
+                hipLaunchKernelGGL(win_fine_rowsum_kernel, dim3((p.n_buckets + 16) / 16), dim3(1024), 0, ps, p);
+                TG_LAUNCH_CHECK();
+                hipLaunchKernelGGL(win_fine_starts_kernel, dim3((p.n_buckets + 16) / 16), dim3(1024), 0, ps, p);
                 TG_LAUNCH_CHECK();
                 hipLaunchKernelGGL(win_sort_fine_kernel<true>, dim3(tiles), dim3(WIN_FINE_THREADS), vt, ps, p);
                 TG_LAUNCH_CHECK();
@@ -1202,8 +1224,12 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             } else
                 p.items_fine = p.items_sorted; // the gather kernel reads the coarse-sorted items
             if (split) TG_HIP(hipEventRecord(side.gathered[h & (WIN_MAX_PARTS - 1)], ps)); // fork point: before the gather
-            hipLaunchKernelGGL((win_stage_gather_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
-                               (size_t)(gthreads / 64) * per_wave, ps, p, sb);
+            if (t.stage_gather_mode & 31)
+                hipLaunchKernelGGL((win_stage_gather_flex_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
+                                   (size_t)(gthreads / 64) * per_wave, ps, p, sb, t.stage_gather_mode);
+            else
+                hipLaunchKernelGGL((win_stage_gather_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
+                                   (size_t)(gthreads / 64) * per_wave, ps, p, sb);
             TG_LAUNCH_CHECK();
             if (split) { // fork: the side pass starts beside the GATHER (beside the sort it slowed the sort's passes 2.5x: they
                          // hang on the latency of their few HBM accesses, which the side pass's streams stretch)
@@ -1417,6 +1443,9 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_split = w.stage_split;
     t->stage_split_round_chunks = w.stage_split_round_chunks;
     t->store_align64 = w.store_align64;
+    t->stage_gather_mode = w.stage_gather_mode;
+    t->stage_fine_sub_bits = w.stage_fine_sub_bits;
+    t->stage_fine_blocks = w.stage_fine_blocks;
     return TG_OK;
 }
 
@@ -1451,6 +1480,9 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_split >= 0) w.stage_split = t->stage_split != 0;
     if (t->stage_split_round_chunks > 0) w.stage_split_round_chunks = t->stage_split_round_chunks;
     if (t->store_align64 >= 0) w.store_align64 = t->store_align64 != 0;
+    if (t->stage_gather_mode >= 0) w.stage_gather_mode = t->stage_gather_mode & 63;
+    if (t->stage_fine_sub_bits > 0) w.stage_fine_sub_bits = std::min(std::max(t->stage_fine_sub_bits, 4), tg::WIN_FINE_SUB_BITS_MAX);
+    if (t->stage_fine_blocks > 0) w.stage_fine_blocks = std::min((t->stage_fine_blocks + 7) & ~7, 8192);
     return TG_OK;
 }
 

@@ -94,7 +94,8 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
     # variants of the push form (separate histogram pass, un-fused first hops: round 2's pipeline) and the staged form
     # (gather first into 64-byte stage slots, emit afterwards), in one stream and in parts on two
     for knobs in (dict(fold_hist=0), dict(fuse_first_hops=0), dict(staged=1, stage_parts=1), dict(staged=1, stage_parts=2),
-                  dict(staged=1, stage_split=1), dict(staged=1, stage_fine=0), dict(staged=1, stage_parts=2, stage_concurrent=1)):
+                  dict(staged=1, stage_split=1), dict(staged=1, stage_fine=0), dict(staged=1, stage_parts=2, stage_concurrent=1),
+                  dict(staged=1, stage_gather_mode=2), dict(staged=1, stage_gather_mode=29), dict(staged=1, stage_fine_sub_bits=4)):
         before = cabi.ns_win_tuning_set(**knobs)
         try:
             d = _poisoned(cabi, nb, B, fan)
@@ -135,7 +136,11 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
                       dict(staged=1, stage_parts=16, stage_part_min_batches=1), dict(staged=1, stage_parts=1),
                       dict(staged=1, stage_split=1), dict(staged=1, stage_split=1, emit_threads=128, stage_fine=0),
                       dict(staged=1, stage_parts=4, stage_part_min_batches=2, stage_concurrent=1),
-                      dict(staged=1, stage_sort_blocks=3), dict(staged=1, stage_sort_blocks=1024)):
+                      dict(staged=1, stage_sort_blocks=3), dict(staged=1, stage_sort_blocks=1024),
+                      dict(staged=1, stage_gather_mode=1), dict(staged=1, stage_gather_mode=31, stage_gather_threads=192, stage_gather_blocks=24),
+                      dict(staged=1, stage_gather_mode=14, stage_parts=3, stage_part_min_batches=8),
+                      dict(staged=1, stage_fine_sub_bits=4), dict(staged=1, stage_fine_sub_bits=5, stage_fine_blocks=8),
+                      dict(staged=1, stage_fine_sub_bits=6, stage_parts=3, stage_part_min_batches=8)):
             prev = cabi.ns_win_tuning_set(**knobs)
             try:
                 c = _poisoned(cabi, nb, B, fan)
@@ -256,8 +261,8 @@ def test_staged_slot_formats(cabi, fan, hint, sampler):
     seeds[:, 0] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))
     before = cabi.ns_win_tuning_set(staged=1, window_bytes=2048)
     try:
-        for parts, split in ((1, 0), (3, 0), (1, 1)):
-            cabi.ns_win_tuning_set(stage_parts=parts, stage_part_min_batches=4, stage_split=split)
+        for parts, split, gmode in ((1, 0, 0), (3, 0, 0), (1, 1, 0), (1, 0, 4), (1, 0, 26), (3, 0, 31)):
+            cabi.ns_win_tuning_set(stage_parts=parts, stage_part_min_batches=4, stage_split=split, stage_gather_mode=gmode)
             a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
             ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True, graph=g)
             assert cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler)
