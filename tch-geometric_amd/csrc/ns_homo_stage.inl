@@ -43,13 +43,19 @@ struct StageKey {
 constexpr int WIN_FINE_SUB_BITS_MAX = 7;                              // sub-ranges of a window's vertex range: 16 .. 128 (default)
 constexpr int WIN_FINE_PER_COARSE_MAX = 8 << WIN_FINE_SUB_BITS_MAX; // fine keys per coarse bucket, at most
 __device__ __forceinline__ StageKey win_stage_key(const uint32_t *vtab, int n_windows, int n_wbuckets, uint32_t v, int sub_bits) {
+    const int repeat = sub_bits >> 8; // TIMING EXPERIMENT ONLY (TG_WIN_KEY_REPEAT): the search done 1 + repeat times
+    sub_bits &= 255;
     int lo = 0, hi = n_windows;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (vtab[mid] <= v)
-            lo = mid;
-        else
-            hi = mid;
+    for (int r = 0; r <= repeat; ++r) {
+        lo = 0, hi = n_windows;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (vtab[mid] <= v)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        asm volatile("" : "+v"(v), "+v"(lo));
     }
     const uint32_t wb = ((uint32_t)lo & 7u) * (uint32_t)(n_wbuckets >> 3) + ((uint32_t)lo >> 3);
     const uint32_t v0 = vtab[lo], range = vtab[lo + 1] - v0; // >= 1 for a vertex of the graph
@@ -150,8 +156,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_kernel(const Wi
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u])
-                    sorted[atomicAdd(&cur[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v, 4).coarse], 1u)] = it[u];
+                if (ok[u]) sorted[atomicAdd(&cur[p.item_keys[b * p.item_pitch + t0 + (int64_t)u * blockDim.x + threadIdx.x]], 1u)] = it[u];
         }
     }
 }
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_scatter8_tiled_kernel(co
                 key[u] = 0xffffffffu;
                 if (j < nt) {
                     it[u] = src[t0 + j];
-                    key[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v, 4).coarse;
+                    key[u] = p.item_keys[b * p.item_pitch + t0 + j]; // found once, by whoever counted the item
                 }
             }
 #pragma unroll
@@ -263,7 +268,11 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinPa
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (ok[u]) atomicAdd(&h[win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u], 4).coarse], 1u);
+                if (ok[u]) {
+                    const uint32_t c = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u], 4 | p.key_fake).coarse;
+                    atomicAdd(&h[c], 1u);
+                    p.item_keys[b * p.item_pitch + t0 + (int64_t)u * blockDim.x + threadIdx.x] = (uint16_t)c;
+                }
         }
     }
     __syncthreads();
@@ -292,7 +301,9 @@ __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const W
     WinItem8 *dst = static_cast<WinItem8 *>(p.items_fine);
     const int tid = threadIdx.x;
     const int sub_bits = p.fine_sub_bits, per_coarse = 8 << sub_bits, bins = 2 * per_coarse;
+    uint32_t *lbase = lvtab + p.n_windows + 1; // the coarse buckets' starts in the level-1 output
     for (int i = tid; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
+    for (int i = tid; i <= p.n_buckets; i += blockDim.x) lbase[i] = p.base[i];
     const uint32_t n = p.base[p.n_buckets];
     constexpr int U = WIN_FINE_TILE / WIN_FINE_THREADS;
     // tile -> workgroup: XCD x (= blockIdx & 7) takes the x-th eighth of the tiles, its workgroups walk it together -- the runs
@@ -316,18 +327,41 @@ __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const W
             if (ok[u]) it[u] = src[j];
         }
         for (int i = tid; i < bins; i += WIN_FINE_THREADS) h[i] = PLACE ? tile_off[i] : 0u; // PLACE: the tile's reserved offsets, then cursors
-        __syncthreads(); // also: the vertex table is loaded
-        StageKey sk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (ok[u]) sk[u] = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, it[u].v, sub_bits);
-        if (tid == 0) c0_s = sk[0].coarse; // the tile's first item lies in its smallest coarse bucket
-        __syncthreads();
+        // No search of the vertex table here: the level-1 output is ordered by coarse bucket, so an item's coarse bucket
+        // follows from its POSITION (the bucket starts `base`), and inside a coarse bucket the window is one of 8 known
+        // ones -- 7 comparisons against splitters that are the same for the whole tile.
+        for (int c = tid; c < p.n_buckets; c += WIN_FINE_THREADS)
+            if (lbase[c] <= t0 && t0 < lbase[c + 1]) c0_s = (uint32_t)c; // exactly one: the tile's first item exists
+        __syncthreads(); // also: the tables are loaded
         const uint32_t c0 = c0_s;
+        // splitters: the first vertices of the 8 windows of coarse bucket c0 (s0) and c0 + 1 (s1), uniform over the tile;
+        // window r of coarse bucket c = window lo0(c) + 8 r (window buckets are XCD-major: bucket wb holds window (wb % wq) * 8 + wb / wq)
+        const uint32_t wq = (uint32_t)(p.n_wbuckets >> 3);
+        const uint32_t lo0 = ((c0 * 8u) % wq) * 8u + (c0 * 8u) / wq, lo1 = (((c0 + 1u) * 8u) % wq) * 8u + ((c0 + 1u) * 8u) / wq;
+        uint32_t s0[8], s1[8];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+            s0[q] = lo0 + 8u * q < (uint32_t)p.n_windows ? lvtab[lo0 + 8u * q] : 0xffffffffu;
+            s1[q] = (c0 + 1u < (uint32_t)p.n_buckets && lo1 + 8u * q < (uint32_t)p.n_windows) ? lvtab[lo1 + 8u * q] : 0xffffffffu;
+        }
+        const uint32_t bnd1 = lbase[min(c0 + 1u, (uint32_t)p.n_buckets)], bnd2 = lbase[min(c0 + 2u, (uint32_t)p.n_buckets)];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (ok[u]) {
-                key[u] = min((uint32_t)bins - 1u, (sk[u].coarse - c0) * per_coarse + sk[u].fine);
+                const uint32_t j = t0 + (uint32_t)u * WIN_FINE_THREADS + tid;
+                const bool second = j >= bnd1;
+                key[u] = (uint32_t)bins - 1u; // beyond the tile's first two coarse buckets: clamped, COUNT and PLACE alike
+                if (j < bnd2 || !second) {
+                    const uint32_t v = it[u].v;
+                    uint32_t r = 0;
+#pragma unroll
+                    for (int q = 1; q < 8; ++q) r += (uint32_t)(v >= (second ? s1[q] : s0[q]));
+                    const uint32_t lo = (second ? lo1 : lo0) + 8u * r;
+                    const uint32_t v0 = lvtab[lo], range = lvtab[lo + 1] - v0;
+                    const int sh = max(0, 32 - sub_bits - (int)__clz((int)((range - 1u) | 1u)));
+                    const uint32_t sub = min((1u << sub_bits) - 1u, (v - v0) >> sh);
+                    key[u] = min((uint32_t)bins - 1u, (second ? (uint32_t)per_coarse : 0u) + ((r << sub_bits) | sub));
+                }
                 rank[u] = atomicAdd(&h[key[u]], 1u);
             }
         if (PLACE) {

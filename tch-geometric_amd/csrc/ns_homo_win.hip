@@ -87,12 +87,14 @@ struct WinParams {
     int32_t n_wbuckets; // window buckets (multiple of 64); the staged form sorts by n_buckets = n_wbuckets / 8 COARSE buckets first
     uint32_t store_align; // 7: the emit passes' store instructions start on 64-byte boundaries; 1: on 16-byte ones (round 3)
     void *items_fine;   // staged form: the items after the second sort level (what the gather kernel reads)
+    uint16_t *item_keys;             // [max_items] staged form: an item's COARSE sort key, at the item's own index (written by whoever
+                                     // counts the item: the first kernel or the histogram pass; read by the level-1 scatter)
     uint32_t *fine_rowtot;           // [n_buckets + 1] items per coarse bucket as the second level counted them
     uint32_t *fine_tot, *fine_start; // [(n_buckets + 1) * 128] items per absolute fine key / start of each key's run
     uint32_t *fine_tile_off;         // [tiles][256] offset of a tile's items inside each key's run
     int64_t next_pitch;
     int64_t b0; // staged form in parts: the kernels of a part walk batches [b0, b0 + n_batches)
-    int32_t fine_by_xcd;
+    int32_t fine_by_xcd, key_fake;
     int32_t fine_sub_bits; // staged form: log2 of the sub-ranges a window's vertices are ordered into by the second sort level
     TG_BOUNDS_FIELDS
 };
@@ -766,7 +768,11 @@ __global__ void win_gather_kernel(const WinParams p) {
 // lhist (first kernel): the workgroup's coarse histogram in LDS, its vertex table right behind it
 __device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v, uint32_t *lhist) {
     static_cast<WinItem8 *>(p.items_in)[b * p.next_pitch + rel] = WinItem8{v, ((uint32_t)b << p.next_idx_bits) | rel};
-    if (lhist) atomicAdd(&lhist[win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v, 4).coarse], 1u);
+    if (lhist) { // the one search of the vertex table this item costs: the key is kept for the level-1 scatter
+        const uint32_t c = win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v, 4 | p.key_fake).coarse;
+        atomicAdd(&lhist[c], 1u);
+        p.item_keys[b * p.next_pitch + rel] = (uint16_t)c;
+    }
 }
 
 static int win_env_int(const char *name, int dflt) {
@@ -840,7 +846,7 @@ static WinStageClock &win_clock() {
 }
 
 struct WinLayout {
-    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, fine_tot, fine_start, fine_tile_off, stage, total, total_push;
+    size_t state, call_keys, n_items, queues, hist, base, items_in, items_sorted, vtab, fine_tot, fine_start, fine_tile_off, item_keys, stage, total, total_push;
     int64_t max_items;
     int stage_words; // 16 / 32: words per stage slot of the staged form; 0: fan-outs beyond it (push form only)
 };
@@ -895,6 +901,7 @@ static WinLayout win_layout(const tg_graph *csc, int64_t n_batches, int64_t n_se
     L.fine_tot = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX * sizeof(uint32_t));
     L.fine_start = take((size_t)WIN_MAX_PARTS * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX * sizeof(uint32_t));
     L.fine_tile_off = take(((size_t)L.max_items / WIN_FINE_TILE + WIN_MAX_PARTS + 1) * WIN_FINE_BINS_MAX * sizeof(uint32_t));
+    L.item_keys = take((size_t)L.max_items * sizeof(uint16_t));
     L.stage_words = win_stage_words(csc, fanout, n_hops);
     L.stage = take((size_t)L.max_items * L.stage_words * sizeof(uint32_t));
     L.total = at;
@@ -1201,7 +1208,7 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             clk.mark("scatter", h, stream);
             if (t.stage_fine) {
                 const int64_t worst = p.n_batches * p.item_pitch; // the item count itself lives on the device
-                const size_t vt = (size_t)(p.n_windows + 1) * sizeof(uint32_t);
+                const size_t vt = (size_t)(p.n_windows + 1 + p.n_buckets + 1) * sizeof(uint32_t); // vertex table + coarse starts
                 p.fine_sub_bits = std::min(std::max(t.stage_fine_sub_bits, 4), WIN_FINE_SUB_BITS_MAX);
                 p.fine_by_xcd = (t.stage_gather_mode >> 5) & 1;
                 const int per_coarse = 8 << p.fine_sub_bits;
@@ -1364,6 +1371,10 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     TG_REQUIRE(((uintptr_t)ws & 255) == 0, "tg_ns_homo_batched_ws: workspace must be 256-byte aligned");
     WinParams p;
     p.store_align = win_tuning().store_align64 ? 7u : 1u;
+    {
+        static const int fake = win_env_int("TG_WIN_KEY_REPEAT", 0);
+        p.key_fake = fake << 8;
+    }
     p.ptrs = csc->ptrs;
     p.indices = csc->indices;
     p.indices32 = csc->indices32;
@@ -1410,6 +1421,7 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     p.fine_tot = reinterpret_cast<uint32_t *>(w + L.fine_tot);
     p.fine_start = reinterpret_cast<uint32_t *>(w + L.fine_start);
     p.fine_tile_off = reinterpret_cast<uint32_t *>(w + L.fine_tile_off);
+    p.item_keys = reinterpret_cast<uint16_t *>(w + L.item_keys);
     p.stage = reinterpret_cast<uint32_t *>(w + L.stage);
     if (narrow && !force_wide && ws_bytes >= (int64_t)L.total &&
         win_staged_applicable(p, win_tuning(), csc, n_batches, fanout, n_hops, L.stage_words))

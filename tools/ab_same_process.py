@@ -18,12 +18,12 @@ dev = torch.device("cuda:0")
 G, B, fan, scale = int(os.environ.get("G", 16384)), 1024, [15, 10], 24
 n = 1 << scale
 out = _cabi.NsBatchedOut(G, B, fan, dev)
-ws = _cabi.ns_homo_workspace(G, B, fan, dev)
-ws = torch.empty(ws.numel() + (16 << 20), dtype=torch.int64, device=dev)   # slack: a variant may lay its workspace out larger
 row, col = _cabi.rmat_edges(scale, n * 16, 0x5EED0000 + scale, dev)
 ptrs, idx, _ = _cabi.coo_to_csx(row, col, n, n, True)
 del row, col
-g = _cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32))
+g = _cabi.graph_view(ptrs, idx, indices32=idx.to(torch.int32), ptrs32=ptrs.to(torch.int32), max_degree="auto")
+ws = _cabi.ns_homo_workspace(G, B, fan, dev, staged=True, graph=g)   # sized for the staged pipeline (what the launch takes at this size)
+ws = torch.empty(ws.numel() + (128 << 20), dtype=torch.int64, device=dev)   # slack: a variant may lay its workspace out larger
 seeds = _cabi.seed_batches(0xBA7C4, 0, G, B, n, dev)
 default = _cabi.lib
 libs = []
