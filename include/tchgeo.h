@@ -192,7 +192,7 @@ typedef struct {
     int32_t emit_blocks;     /* workgroups of the persistent emit kernels (default 768, at most 1024) */
     int32_t staged;          /* gather first, emit afterwards through packed 64-byte stage slots: 0 = never,
                                 1 = whenever it applies, 2 (default) = where it measures faster than the push form: launches
-                                of >= 12 288 batches whose slots are one chunk; launches it does not fit -- ordered fan-outs
+                                of >= 4 096 batches whose slots are one chunk; launches it does not fit -- ordered fan-outs
                                 > 30, ids beyond 32 bits, a workspace without the slots -- take the push form anyway;
                                 < 0 in _set keeps */
     int32_t stage_round_chunks;   /* staged emit kernel: 64-slot chunks per round (default 2: the smaller tile lets five workgroups share a CU, emit 3.15 -> 3.07 ms; at most 16) */
@@ -216,10 +216,6 @@ typedef struct {
     int32_t store_align64;          /* the emit passes' store instructions start on 64-byte boundaries (the elements before the
                                        first boundary are stored alone): non-temporal stores of a chunk that two instructions
                                        share go out as two partial writes (default 1; 0: 16-byte boundaries; < 0 in _set keeps) */
-    int32_t stage_gather_mode;      /* staged form, variants of the gather kernel (experiments; 0 = the default kernel): bits 0-1 =
-                                       log2 of the slices a wavefront takes between two barriers, bit 2 = 16-byte slot stores,
-                                       bit 3 = column bounds as one 8-byte load, bit 4 = non-temporal item loads and slot stores
-                                       (< 0 in _set keeps) */
     int32_t stage_fine_sub_bits;    /* staged form: the second sort level orders a window's vertices into 1 << this many sub-ranges
                                        (4 .. 7, default 7: the finer the order, the fewer columns a gather workgroup's slice touches --
                                        gather 2.39 / 2.26 / 2.11 / 2.01 ms at 4 / 5 / 6 / 7, the sort 0.46 / 0.47 / 0.52 / 0.56; 0 in _set keeps) */

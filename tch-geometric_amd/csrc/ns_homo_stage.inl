@@ -43,19 +43,13 @@ struct StageKey {
 constexpr int WIN_FINE_SUB_BITS_MAX = 7;                              // sub-ranges of a window's vertex range: 16 .. 128 (default)
 constexpr int WIN_FINE_PER_COARSE_MAX = 8 << WIN_FINE_SUB_BITS_MAX; // fine keys per coarse bucket, at most
 __device__ __forceinline__ StageKey win_stage_key(const uint32_t *vtab, int n_windows, int n_wbuckets, uint32_t v, int sub_bits) {
-    const int repeat = sub_bits >> 8; // TIMING EXPERIMENT ONLY (TG_WIN_KEY_REPEAT): the search done 1 + repeat times
-    sub_bits &= 255;
     int lo = 0, hi = n_windows;
-    for (int r = 0; r <= repeat; ++r) {
-        lo = 0, hi = n_windows;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (vtab[mid] <= v)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        asm volatile("" : "+v"(v), "+v"(lo));
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (vtab[mid] <= v)
+            lo = mid;
+        else
+            hi = mid;
     }
     const uint32_t wb = ((uint32_t)lo & 7u) * (uint32_t)(n_wbuckets >> 3) + ((uint32_t)lo >> 3);
     const uint32_t v0 = vtab[lo], range = vtab[lo + 1] - v0; // >= 1 for a vertex of the graph
@@ -269,7 +263,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinPa
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (ok[u]) {
-                    const uint32_t c = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u], 4 | p.key_fake).coarse;
+                    const uint32_t c = win_stage_key(lvtab, p.n_windows, p.n_wbuckets, v[u], 4).coarse;
                     atomicAdd(&h[c], 1u);
                     p.item_keys[b * p.item_pitch + t0 + (int64_t)u * blockDim.x + threadIdx.x] = (uint16_t)c;
                 }
@@ -304,17 +298,10 @@ __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const W
     uint32_t *lbase = lvtab + p.n_windows + 1; // the coarse buckets' starts in the level-1 output
     for (int i = tid; i <= p.n_windows; i += blockDim.x) lvtab[i] = p.vtab[i];
     for (int i = tid; i <= p.n_buckets; i += blockDim.x) lbase[i] = p.base[i];
+    __syncthreads(); // the tables are read by every thread from the first tile on
     const uint32_t n = p.base[p.n_buckets];
     constexpr int U = WIN_FINE_TILE / WIN_FINE_THREADS;
-    // tile -> workgroup: XCD x (= blockIdx & 7) takes the x-th eighth of the tiles, its workgroups walk it together -- the runs
-    // the resident tiles write into then lie in a few coarse segments PER XCD, whose L2 merges the 8-byte writes
-    const uint32_t n_tiles = (uint32_t)(((uint64_t)n + WIN_FINE_TILE - 1) / WIN_FINE_TILE);
-    const bool by_xcd = p.fine_by_xcd && (gridDim.x & 7) == 0;
-    const uint32_t per_xcd = by_xcd ? (n_tiles + 7) / 8 : n_tiles;
-    const uint32_t tile_lo = by_xcd ? (blockIdx.x & 7) * per_xcd : 0u;
-    const uint32_t tile_hi = min(n_tiles, tile_lo + per_xcd);
-    const uint32_t tile_step = by_xcd ? gridDim.x >> 3 : gridDim.x;
-    for (uint32_t tile = tile_lo + (by_xcd ? blockIdx.x >> 3 : blockIdx.x); tile < tile_hi; tile += tile_step) {
+    for (uint32_t tile = blockIdx.x; (uint64_t)tile * WIN_FINE_TILE < n; tile += gridDim.x) {
         const uint32_t t0 = tile * WIN_FINE_TILE;
         uint32_t *tile_off = p.fine_tile_off + (size_t)tile * bins;
         WinItem8 it[U];
@@ -332,8 +319,8 @@ __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const W
         // ones -- 7 comparisons against splitters that are the same for the whole tile.
         for (int c = tid; c < p.n_buckets; c += WIN_FINE_THREADS)
             if (lbase[c] <= t0 && t0 < lbase[c + 1]) c0_s = (uint32_t)c; // exactly one: the tile's first item exists
-        __syncthreads(); // also: the tables are loaded
-        const uint32_t c0 = c0_s;
+        __syncthreads();
+        const uint32_t c0 = min(c0_s, (uint32_t)p.n_buckets - 1u);
         // splitters: the first vertices of the 8 windows of coarse bucket c0 (s0) and c0 + 1 (s1), uniform over the tile;
         // window r of coarse bucket c = window lo0(c) + 8 r (window buckets are XCD-major: bucket wb holds window (wb % wq) * 8 + wb / wq)
         const uint32_t wq = (uint32_t)(p.n_wbuckets >> 3);
@@ -536,151 +523,6 @@ __global__ void win_stage_gather_kernel(const WinParams p, const StageBits sb) {
             const int item_l = r * PER + lane / W, word = lane % W;
             const uint32_t sj = jrow[item_l];
             if (sj != 0xffffffffu) p.stage[(size_t)sj * W + word] = tile[item_l * (W + 1) + word];
-        }
-        if (tid == 0) slice_lo[buf ^ 1] = nxt;
-        __syncthreads();
-    }
-}
-
-// Variants of the pass above behind tg_ns_win_tuning.stage_gather_mode (experiments; outputs never depend on them):
-//   bits 0-1  S = 1 << bits: a workgroup takes S slices per wavefront from the queue at a time and meets at the barrier once
-//             per S slices; between barriers its wavefronts run free (slice u of wavefront w = the chunk's slice u * n_waves + w)
-//   bit 2     the slot leaves as 16-byte stores (W / 4 store instructions per 64 items instead of W)
-//   bit 3     the column bounds as ONE 8-byte load of ptrs32[v], ptrs32[v + 1]
-//   bit 4     items read and slots stored non-temporally
-// Tried and dropped: no queue at all (the XCD's range cut into one contiguous range per workgroup: 4.2 ms against 2.4, its
-// L2 must hold 64 windows at once; chunks dealt out round-robin: 3.9 ms -- the workgroups drift apart and out of each other's
-// windows; the queue keeps them together).
-template <int W, int KMAX, bool REPLACE>
-__global__ void win_stage_gather_flex_kernel(const WinParams p, const StageBits sb, const int mode) {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ unsigned long long slice_lo[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    uint32_t *tile = reinterpret_cast<uint32_t *>(smem) + (size_t)wave * (64 * (W + 1) + 64);
-    uint32_t *jrow = tile + 64 * (W + 1);
-    const WinItem8 *items = static_cast<const WinItem8 *>(p.items_fine);
-    const int k = p.k;
-    WinQueues::Q *Q = &p.queues->q[blockIdx.x & 7];
-    const unsigned long long qend = Q->end;
-    const int S = 1 << (mode & 3);
-    const bool wide_stores = mode & 4, ptr_pair = (mode & 8) && p.ptrs32, nt = mode & 16;
-    const unsigned long long chunk = (unsigned long long)blockDim.x * S;
-    const uint32_t idx_mask = (1u << p.idx_bits) - 1u;
-
-    if (tid == 0) slice_lo[0] = atomicAdd(&Q->head, chunk);
-    __syncthreads();
-    for (int buf = 0;; buf ^= 1) {
-        const unsigned long long lo = slice_lo[buf];
-        if (lo >= qend) break;
-        unsigned long long nxt = 0;
-        if (tid == 0) nxt = atomicAdd(&Q->head, chunk);
-        for (int u = 0; u < S; ++u) {
-            const unsigned long long j = lo + ((unsigned long long)u * n_waves + wave) * 64 + lane;
-            if (j - lane >= qend) break; // wave-uniform
-            const bool live = j < qend;
-            uint32_t slot_index = 0xffffffffu, e0w = 0, cnt = 0;
-            uint32_t pos[KMAX], nbr[KMAX];
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s) pos[s] = nbr[s] = 0u;
-            if (live) {
-                WinItem8 it;
-                if (nt) {
-                    const u32x2 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(items + j));
-                    it = WinItem8{raw.x, raw.y};
-                } else
-                    it = items[j];
-                TG_CHECK_VERTEX(p, it.v);
-                const uint32_t b = it.bs >> p.idx_bits, idx = it.bs & idx_mask;
-                uint64_t e0, e1;
-                if (ptr_pair) {
-                    u32x2 pr;
-                    __builtin_memcpy(&pr, p.ptrs32 + it.v, 8); // 4-byte aligned
-                    e0 = pr.x;
-                    e1 = pr.y;
-                } else if (p.ptrs32) {
-                    e0 = p.ptrs32[it.v];
-                    e1 = p.ptrs32[it.v + 1];
-                } else {
-                    e0 = (uint64_t)p.ptrs[it.v];
-                    e1 = (uint64_t)p.ptrs[(int64_t)it.v + 1];
-                }
-                const uint32_t n = (uint32_t)(e1 - e0);
-                cnt = (n == 0) ? 0u : (REPLACE ? (uint32_t)k : min(n, (uint32_t)k));
-                slot_index = (uint32_t)((int64_t)b * p.item_pitch + idx);
-                e0w = (uint32_t)e0;
-                if (cnt > 0) {
-                    if (REPLACE || n > (uint32_t)k) {
-                        const CallKey ck = p.call_keys[b];
-                        const int64_t fbegin = p.hop == 1 ? p.n_seeds : p.state[b].begin;
-                        const uint64_t did = (uint64_t)(p.id_base + fbegin + (int64_t)idx);
-                        if (REPLACE) // sampling.rs:57-69
-                            slot_draws<KMAX, true>(ck, did, n, k, pos);
-                        else
-                            sample_tickets_reg<KMAX>(ck, did, n, k, pos);
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < KMAX; ++s) pos[s] = (uint32_t)s; // sampling.rs:12-15: the reservoir is just filled
-                    }
-                    if (p.indices32) {
-#pragma unroll
-                        for (int s = 0; s < KMAX; ++s)
-                            if ((uint32_t)s < cnt) nbr[s] = p.indices32[e0 + pos[s]];
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < KMAX; ++s)
-                            if ((uint32_t)s < cnt) nbr[s] = (uint32_t)p.indices[e0 + pos[s]];
-                    }
-                }
-            }
-            { // the slot as a bit stream into this lane's row of the tile
-                BitWriter bw{tile + lane * (W + 1), (uint64_t)e0w | ((uint64_t)cnt << 32), 8, 1};
-                tile[lane * (W + 1)] = e0w;
-                bw.acc >>= 32;
-#pragma unroll
-                for (int s = 0; s < KMAX; ++s) {
-                    if (s < k) {
-                        const bool on = (uint32_t)s < cnt;
-                        bw.push(on ? nbr[s] : 0u, sb.bv);
-                        bw.push(on ? pos[s] : 0u, sb.bp);
-                    }
-                }
-                bw.finish(W);
-            }
-            jrow[lane] = slot_index;
-            wave_lds_handoff();
-            if (wide_stores) { // 4 lanes (W = 16) or 8 (W = 32) write one item's slot as 16-byte pieces
-                constexpr int PIECES = W / 4, PER = 64 / PIECES;
-#pragma unroll
-                for (int r = 0; r < PIECES; ++r) {
-                    const int item_l = r * PER + lane / PIECES, piece = lane % PIECES;
-                    const uint32_t sj = jrow[item_l];
-                    const uint32_t *t = tile + item_l * (W + 1) + piece * 4;
-                    const u32x4 v = {t[0], t[1], t[2], t[3]};
-                    if (sj != 0xffffffffu) {
-                        u32x4 *dst = reinterpret_cast<u32x4 *>(p.stage + (size_t)sj * W + piece * 4);
-                        if (nt)
-                            __builtin_nontemporal_store(v, dst);
-                        else
-                            *dst = v;
-                    }
-                }
-            } else {
-                constexpr int PER = 64 / W;
-#pragma unroll
-                for (int r = 0; r < W; ++r) {
-                    const int item_l = r * PER + lane / W, word = lane % W;
-                    const uint32_t sj = jrow[item_l];
-                    if (sj != 0xffffffffu) {
-                        if (nt)
-                            __builtin_nontemporal_store(tile[item_l * (W + 1) + word], &p.stage[(size_t)sj * W + word]);
-                        else
-                            p.stage[(size_t)sj * W + word] = tile[item_l * (W + 1) + word];
-                    }
-                }
-            }
-            wave_lds_handoff(); // the tile is read out before the next slice's rows are written
         }
         if (tid == 0) slice_lo[buf ^ 1] = nxt;
         __syncthreads();

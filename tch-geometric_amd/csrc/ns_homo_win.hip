@@ -94,7 +94,6 @@ struct WinParams {
     uint32_t *fine_tile_off;         // [tiles][256] offset of a tile's items inside each key's run
     int64_t next_pitch;
     int64_t b0; // staged form in parts: the kernels of a part walk batches [b0, b0 + n_batches)
-    int32_t fine_by_xcd, key_fake;
     int32_t fine_sub_bits; // staged form: log2 of the sub-ranges a window's vertices are ordered into by the second sort level
     TG_BOUNDS_FIELDS
 };
@@ -769,7 +768,7 @@ __global__ void win_gather_kernel(const WinParams p) {
 __device__ __forceinline__ void win_next_item(const WinParams &p, int64_t b, uint32_t rel, uint32_t v, uint32_t *lhist) {
     static_cast<WinItem8 *>(p.items_in)[b * p.next_pitch + rel] = WinItem8{v, ((uint32_t)b << p.next_idx_bits) | rel};
     if (lhist) { // the one search of the vertex table this item costs: the key is kept for the level-1 scatter
-        const uint32_t c = win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v, 4 | p.key_fake).coarse;
+        const uint32_t c = win_stage_key(lhist + p.n_buckets, p.n_windows, p.n_wbuckets, v, 4).coarse;
         atomicAdd(&lhist[c], 1u);
         p.item_keys[b * p.next_pitch + rel] = (uint16_t)c;
     }
@@ -786,7 +785,7 @@ struct WinTuning {
     int64_t window_bytes;
     int32_t gather_blocks, gather_threads, emit_threads, direct_hop0, fuse_first_hops, fold_hist, emit_blocks;
     int32_t staged, stage_round_chunks, stage_gather_threads, stage_gather_blocks, stage_emit_threads, stage_parts, stage_part_min_batches, stage_sort_blocks;
-    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks, store_align64, stage_gather_mode, stage_fine_sub_bits, stage_fine_blocks;
+    int32_t stage_fine, stage_concurrent, stage_split, stage_split_round_chunks, store_align64, stage_fine_sub_bits, stage_fine_blocks;
 };
 static WinTuning &win_tuning() {
     static WinTuning t = {
@@ -811,7 +810,6 @@ static WinTuning &win_tuning() {
         win_env_int("TG_WIN_STAGE_SPLIT", 0),
         win_env_int("TG_WIN_STAGE_SPLIT_ROUND_CHUNKS", 4),
         win_env_int("TG_WIN_STORE_ALIGN64", 1),
-        win_env_int("TG_WIN_STAGE_GATHER_MODE", 0),
         win_env_int("TG_WIN_STAGE_FINE_SUB_BITS", 7),
         win_env_int("TG_WIN_STAGE_FINE_BLOCKS", 2048),
     };
@@ -1004,9 +1002,10 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
 
 // ---------------------------------------------------------------- staged form: host side
 // tg_ns_win_tuning.staged: 0 = never, 1 = whenever it applies, 2 (default) = where it measures faster than the push form:
-// launches of >= 12 288 batches whose stage slots are ONE chunk (RMAT-24, [15, 10]: 7.3 against 7.7-8.15 ms at 16 384
-// batches; level with the push form at 4 096-8 192, profiles/r04/sweep_launch_size.jsonl)
-constexpr int64_t WIN_STAGED_AUTO_MIN_BATCHES = 12288;
+// launches of >= 4 096 batches whose stage slots are ONE chunk (RMAT-24, [15, 10], with the 128-sub-range second sort level:
+// 2.13 against 2.21 ms at 4 096 batches, 4.03 against 4.28 at 8 192, 6.9 against 7.7-8.1 at 16 384; level at 2 048;
+// profiles/r04/sweep_launch_size.jsonl)
+constexpr int64_t WIN_STAGED_AUTO_MIN_BATCHES = 4096;
 static bool win_staged_wanted(const WinTuning &t, int64_t n_batches, int stage_words) {
     if (t.staged == 2) return n_batches >= WIN_STAGED_AUTO_MIN_BATCHES && stage_words == 16;
     return t.staged != 0;
@@ -1172,8 +1171,6 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
                 if (!raised) {
                     TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&win_stage_gather_kernel<W, KMAX, REPLACE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&win_stage_gather_flex_kernel<W, KMAX, REPLACE>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                     raised = true;
                 }
             }
@@ -1210,7 +1207,6 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
                 const int64_t worst = p.n_batches * p.item_pitch; // the item count itself lives on the device
                 const size_t vt = (size_t)(p.n_windows + 1 + p.n_buckets + 1) * sizeof(uint32_t); // vertex table + coarse starts
                 p.fine_sub_bits = std::min(std::max(t.stage_fine_sub_bits, 4), WIN_FINE_SUB_BITS_MAX);
-                p.fine_by_xcd = (t.stage_gather_mode >> 5) & 1;
                 const int per_coarse = 8 << p.fine_sub_bits;
                 const size_t keys = (size_t)(p.n_buckets + 1) * per_coarse;
                 p.fine_tot = fine_tot0 + (size_t)part * (WIN_MAX_BUCKETS / 8 + 8) * WIN_FINE_PER_COARSE_MAX;
@@ -1231,12 +1227,8 @@ static int win_run_staged(WinParams p, const tg_graph *csc, int64_t n_batches, c
             } else
                 p.items_fine = p.items_sorted; // the gather kernel reads the coarse-sorted items
             if (split) TG_HIP(hipEventRecord(side.gathered[h & (WIN_MAX_PARTS - 1)], ps)); // fork point: before the gather
-            if (t.stage_gather_mode & 31)
-                hipLaunchKernelGGL((win_stage_gather_flex_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
-                                   (size_t)(gthreads / 64) * per_wave, ps, p, sb, t.stage_gather_mode);
-            else
-                hipLaunchKernelGGL((win_stage_gather_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
-                                   (size_t)(gthreads / 64) * per_wave, ps, p, sb);
+            hipLaunchKernelGGL((win_stage_gather_kernel<W, KMAX, REPLACE>), dim3(gblocks), dim3(gthreads),
+                               (size_t)(gthreads / 64) * per_wave, ps, p, sb);
             TG_LAUNCH_CHECK();
             if (split) { // fork: the side pass starts beside the GATHER (beside the sort it slowed the sort's passes 2.5x: they
                          // hang on the latency of their few HBM accesses, which the side pass's streams stretch)
@@ -1371,10 +1363,7 @@ int tg_ns_homo_windowed_launch(const tg_graph *csc, const int64_t *seeds, int64_
     TG_REQUIRE(((uintptr_t)ws & 255) == 0, "tg_ns_homo_batched_ws: workspace must be 256-byte aligned");
     WinParams p;
     p.store_align = win_tuning().store_align64 ? 7u : 1u;
-    {
-        static const int fake = win_env_int("TG_WIN_KEY_REPEAT", 0);
-        p.key_fake = fake << 8;
-    }
+
     p.ptrs = csc->ptrs;
     p.indices = csc->indices;
     p.indices32 = csc->indices32;
@@ -1455,7 +1444,6 @@ extern "C" int tg_ns_win_tuning_get(tg_ns_win_tuning *t) {
     t->stage_split = w.stage_split;
     t->stage_split_round_chunks = w.stage_split_round_chunks;
     t->store_align64 = w.store_align64;
-    t->stage_gather_mode = w.stage_gather_mode;
     t->stage_fine_sub_bits = w.stage_fine_sub_bits;
     t->stage_fine_blocks = w.stage_fine_blocks;
     return TG_OK;
@@ -1492,7 +1480,6 @@ extern "C" int tg_ns_win_tuning_set(const tg_ns_win_tuning *t) {
     if (t->stage_split >= 0) w.stage_split = t->stage_split != 0;
     if (t->stage_split_round_chunks > 0) w.stage_split_round_chunks = t->stage_split_round_chunks;
     if (t->store_align64 >= 0) w.store_align64 = t->store_align64 != 0;
-    if (t->stage_gather_mode >= 0) w.stage_gather_mode = t->stage_gather_mode & 63;
     if (t->stage_fine_sub_bits > 0) w.stage_fine_sub_bits = std::min(std::max(t->stage_fine_sub_bits, 4), tg::WIN_FINE_SUB_BITS_MAX);
     if (t->stage_fine_blocks > 0) w.stage_fine_blocks = std::min((t->stage_fine_blocks + 7) & ~7, 8192);
     return TG_OK;

@@ -270,7 +270,7 @@ class TgNsWinTuning(C.Structure):
                 ("stage_part_min_batches", C.c_int32), ("stage_sort_blocks", C.c_int32), ("stage_fine", C.c_int32),
                 ("stage_concurrent", C.c_int32), ("stage_split", C.c_int32),
                 ("stage_split_round_chunks", C.c_int32), ("store_align64", C.c_int32),
-                ("stage_gather_mode", C.c_int32), ("stage_fine_sub_bits", C.c_int32),
+                ("stage_fine_sub_bits", C.c_int32),
                 ("stage_fine_blocks", C.c_int32)]
 
 
@@ -283,7 +283,7 @@ def ns_win_tuning():
 def ns_win_tuning_set(**kw):
     """Process-wide tuning of the window-ordered launch (outputs never depend on it); -> the previous values."""
     before = ns_win_tuning()
-    t = TgNsWinTuning(0, 0, 0, 0, -1, -1, -1, 0, -1, 0, 0, 0, 0, 0, 0, 0, -1, -1, -1, 0, -1, -1, 0, 0)
+    t = TgNsWinTuning(0, 0, 0, 0, -1, -1, -1, 0, -1, 0, 0, 0, 0, 0, 0, 0, -1, -1, -1, 0, -1, 0, 0)
     for k, v in kw.items():
         assert k in before, k
         setattr(t, k, int(v))

@@ -95,7 +95,7 @@ def test_bench_shape_rmat24_windowed_equals_fused_and_oracle(cabi):
     # (gather first into 64-byte stage slots, emit afterwards), in one stream and in parts on two
     for knobs in (dict(fold_hist=0), dict(fuse_first_hops=0), dict(staged=1, stage_parts=1), dict(staged=1, stage_parts=2),
                   dict(staged=1, stage_split=1), dict(staged=1, stage_fine=0), dict(staged=1, stage_parts=2, stage_concurrent=1),
-                  dict(staged=1, stage_gather_mode=2), dict(staged=1, stage_gather_mode=29), dict(staged=1, stage_fine_sub_bits=4)):
+                  dict(staged=1, stage_gather_threads=1024, stage_gather_blocks=256), dict(staged=1, stage_fine_sub_bits=4)):
         before = cabi.ns_win_tuning_set(**knobs)
         try:
             d = _poisoned(cabi, nb, B, fan)
@@ -137,8 +137,7 @@ def test_many_windows_mid_size(cabi, sampler, shadows):
                       dict(staged=1, stage_split=1), dict(staged=1, stage_split=1, emit_threads=128, stage_fine=0),
                       dict(staged=1, stage_parts=4, stage_part_min_batches=2, stage_concurrent=1),
                       dict(staged=1, stage_sort_blocks=3), dict(staged=1, stage_sort_blocks=1024),
-                      dict(staged=1, stage_gather_mode=1), dict(staged=1, stage_gather_mode=31, stage_gather_threads=192, stage_gather_blocks=24),
-                      dict(staged=1, stage_gather_mode=14, stage_parts=3, stage_part_min_batches=8),
+                      dict(staged=1, stage_gather_threads=1024, stage_gather_blocks=16),
                       dict(staged=1, stage_fine_sub_bits=4), dict(staged=1, stage_fine_sub_bits=5, stage_fine_blocks=8),
                       dict(staged=1, stage_fine_sub_bits=6, stage_parts=3, stage_part_min_batches=8)):
             prev = cabi.ns_win_tuning_set(**knobs)
@@ -261,8 +260,8 @@ def test_staged_slot_formats(cabi, fan, hint, sampler):
     seeds[:, 0] = int(torch.argmax(ptrs[1:] - ptrs[:-1]))
     before = cabi.ns_win_tuning_set(staged=1, window_bytes=2048)
     try:
-        for parts, split, gmode in ((1, 0, 0), (3, 0, 0), (1, 1, 0), (1, 0, 4), (1, 0, 26), (3, 0, 31)):
-            cabi.ns_win_tuning_set(stage_parts=parts, stage_part_min_batches=4, stage_split=split, stage_gather_mode=gmode)
+        for parts, split, sub in ((1, 0, 7), (3, 0, 7), (1, 1, 7), (1, 0, 4), (3, 0, 5)):
+            cabi.ns_win_tuning_set(stage_parts=parts, stage_part_min_batches=4, stage_split=split, stage_fine_sub_bits=sub)
             a, b = _poisoned(cabi, nb, B, fan), _poisoned(cabi, nb, B, fan)
             ws = cabi.ns_homo_workspace(nb, B, fan, dev, staged=True, graph=g)
             assert cabi.ns_homo_batched_staged(g, a, nb, B, fan, ws=ws, form=WINDOWED, sampler=sampler)
@@ -366,14 +365,14 @@ def test_frontiers_of_several_scatter_tiles_and_both_store_alignments(cabi, alig
 
 
 def test_pipeline_is_chosen_by_launch_size_by_default(cabi):
-    """tg_ns_win_tuning.staged = 2 (the default): the staged pipeline from 12 288 batches on when the stage slots are one
+    """tg_ns_win_tuning.staged = 2 (the default): the staged pipeline from 4 096 batches on when the stage slots are one
     chunk, the push pipeline below that and for two-chunk slots; the workspace query follows the same rule; both equal the
     fused kernel"""
     dev = torch.device(DEV)
     n, ptrs, idx, g = _rmat(cabi, 12)
     assert cabi.ns_win_tuning()["staged"] == 2
     B = 4
-    for nb, fan, want in ((12288, [15, 10], True), (12287, [15, 10], False), (12288, [4, 20], False)):
+    for nb, fan, want in ((4096, [15, 10], True), (4095, [15, 10], False), (4096, [4, 20], False)):
         ws = cabi.ns_homo_workspace(nb, B, fan, dev, graph=g)                     # sized as the rule says
         push_only = cabi.ns_homo_workspace(nb, B, fan, dev, staged=False, graph=g)
         assert (ws.numel() > push_only.numel()) == want
