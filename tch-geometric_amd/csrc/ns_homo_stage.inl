@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(WIN_PART_THREADS) win_hist8_kernel(const WinPa
 // key's run depends on which tile's atomic came first; it does not matter (outputs are addressed by the item's own slot).
 // Bins beyond the tile's first two coarse buckets are clamped into the last bin of the second (possible only when coarse
 // buckets hold fewer items than a tile): the order only matters for speed, and COUNT and PLACE clamp alike.
-constexpr int WIN_FINE_TILE = 4096, WIN_FINE_THREADS = 512, WIN_FINE_BINS_MAX = 2 * WIN_FINE_PER_COARSE_MAX;
+constexpr int WIN_FINE_TILE = 8192, WIN_FINE_THREADS = 1024, WIN_FINE_BINS_MAX = 2 * WIN_FINE_PER_COARSE_MAX;
 template <bool PLACE>
 __global__ void __launch_bounds__(WIN_FINE_THREADS) win_sort_fine_kernel(const WinParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
