@@ -192,7 +192,7 @@ typedef struct {
     int32_t emit_blocks;     /* workgroups of the persistent emit kernels (default 768, at most 1024) */
     int32_t staged;          /* gather first, emit afterwards through packed 64-byte stage slots: 0 = never,
                                 1 = whenever it applies, 2 (default) = where it measures faster than the push form: launches
-                                of >= 4 096 batches whose slots are one chunk; launches it does not fit -- ordered fan-outs
+                                of >= 2 048 batches whose slots are one chunk; launches it does not fit -- ordered fan-outs
                                 > 30, ids beyond 32 bits, a workspace without the slots -- take the push form anyway;
                                 < 0 in _set keeps */
     int32_t stage_round_chunks;   /* staged emit kernel: 64-slot chunks per round (default 2: the smaller tile lets five workgroups share a CU, emit 3.15 -> 3.07 ms; at most 16) */

@@ -1002,10 +1002,10 @@ static int win_run(WinParams p, int64_t n_batches, const int64_t *fanout, int32_
 
 // ---------------------------------------------------------------- staged form: host side
 // tg_ns_win_tuning.staged: 0 = never, 1 = whenever it applies, 2 (default) = where it measures faster than the push form:
-// launches of >= 4 096 batches whose stage slots are ONE chunk (RMAT-24, [15, 10], with the 128-sub-range second sort level:
-// 2.13 against 2.21 ms at 4 096 batches, 4.03 against 4.28 at 8 192, 6.9 against 7.7-8.1 at 16 384; level at 2 048;
-// profiles/r04/sweep_launch_size.jsonl)
-constexpr int64_t WIN_STAGED_AUTO_MIN_BATCHES = 4096;
+// launches of >= 2 048 batches (every launch that takes a window-ordered form at all) whose stage slots are ONE chunk
+// (RMAT-24, [15, 10], final build of round 4: 1.24 against 1.29 ms at 2 048 batches, 2.07 / 2.10 at 4 096, 3.61 / 4.09 at
+// 8 192, 5.12 / 5.91 at 12 288, 6.7 / 7.9-8.2 at 16 384; profiles/r04/sweep_launch_size_final.jsonl)
+constexpr int64_t WIN_STAGED_AUTO_MIN_BATCHES = 2048;
 static bool win_staged_wanted(const WinTuning &t, int64_t n_batches, int stage_words) {
     if (t.staged == 2) return n_batches >= WIN_STAGED_AUTO_MIN_BATCHES && stage_words == 16;
     return t.staged != 0;

@@ -365,14 +365,14 @@ def test_frontiers_of_several_scatter_tiles_and_both_store_alignments(cabi, alig
 
 
 def test_pipeline_is_chosen_by_launch_size_by_default(cabi):
-    """tg_ns_win_tuning.staged = 2 (the default): the staged pipeline from 4 096 batches on when the stage slots are one
+    """tg_ns_win_tuning.staged = 2 (the default): the staged pipeline from 2 048 batches on when the stage slots are one
     chunk, the push pipeline below that and for two-chunk slots; the workspace query follows the same rule; both equal the
     fused kernel"""
     dev = torch.device(DEV)
     n, ptrs, idx, g = _rmat(cabi, 12)
     assert cabi.ns_win_tuning()["staged"] == 2
     B = 4
-    for nb, fan, want in ((4096, [15, 10], True), (4095, [15, 10], False), (4096, [4, 20], False)):
+    for nb, fan, want in ((2048, [15, 10], True), (2047, [15, 10], False), (2048, [4, 20], False)):
         ws = cabi.ns_homo_workspace(nb, B, fan, dev, graph=g)                     # sized as the rule says
         push_only = cabi.ns_homo_workspace(nb, B, fan, dev, staged=False, graph=g)
         assert (ws.numel() > push_only.numel()) == want
